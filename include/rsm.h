@@ -1,0 +1,152 @@
+/*
+ * rsm.h -- C ABI of librsm_mi355.so: the MI355X-native (gfx950 / HIP) drop-in for the
+ * CStereoMatching pyramidal dense-stereo path of seed93/reconstruction.
+ *
+ * The reference has no FFI layer; the seam this library replaces is the C++ class
+ * surface the orchestrator uses (reference file:line, relative to the reference root):
+ *   CStereoMatching::Init(...)            reconstruction/CStereoMatching.h:47, .cpp:5-13
+ *   CStereoMatching::MatchAllLayer()      reconstruction/CStereoMatching.h:48, .cpp:15-34
+ *   public fields Q,R_final,T_final,margin[2],MatchBlockRadius,m_ws,m_offset,Verbose
+ *                                         reconstruction/CStereoMatching.h:38-45
+ *   downstream contract: per emitted point CCloudOptimization::InsertPoint(3x1 CV_64F) in
+ *   row-major pixel order (.cpp:749-751), cam[pair][v].bound = margin[v] (.cpp:27-28).
+ * include/CStereoMatchingMI355.hpp is a header-only C++ adapter with exactly that surface
+ * built on these entry points; INTEGRATION.md shows the patch a maintainer would apply.
+ *
+ * All entry points return 0 on success or a negative rsm_status; the library never calls
+ * exit() (the reference does at CStereoMatching.cpp:827-830 -> RSM_E_DEGENERATE_MARGIN).
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * One rsm_ctx per GPU; a ctx is not re-entrant (like CStereoMatching), different ctxs
+ * may be driven from different threads.
+ */
+#ifndef RSM_H
+#define RSM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSM_NOMATCH (-10000) /* NOMATCH, reconstruction/CStereoMatching.h:9 */
+#define RSM_MAX_LEVELS 12
+
+typedef enum rsm_status {
+    RSM_OK = 0,
+    RSM_E_INVALID = -1,           /* bad argument */
+    RSM_E_DEGENERATE_MARGIN = -2, /* YL>=YR || XL>=XR (reference: exit(0), .cpp:827-830) */
+    RSM_E_HIP = -3,               /* HIP runtime error (rsm_last_error() has the text) */
+    RSM_E_NOMEM = -4,
+    RSM_E_STATE = -5              /* call order (e.g. run before upload) */
+} rsm_status;
+
+/* struct Boundary, reconstruction/CManageData.h:10-14 (same field order) */
+typedef struct rsm_boundary {
+    int YL, YR, XL, XR;
+    int width, height;
+} rsm_boundary;
+
+/* Inputs of one stereo pair = what MatchAllLayer reads after Rectify()
+ * (.cpp:20: cam[pair][v].image/.mask, Q, R_final, T_final) + the Init() parameters. */
+typedef struct rsm_pair_in {
+    const uint8_t *image[2]; /* rectified top-level BGR 8UC3, row-major, stride 3*width  */
+    const uint8_t *mask[2];  /* rectified+eroded top-level mask 8UC1, stride width       */
+    int width, height;       /* top level = m_LowestLevelSize * 2^(m_PyrmNum-1) (.cpp:120) */
+    int pyr_levels;          /* m_PyrmNum                                                */
+    int radius;              /* MatchBlockRadius (Init radii; CReconstruction.cpp:17: 2)  */
+    double ws;               /* m_ws (CReconstruction.cpp:17: 0.03)                       */
+    int offset;              /* m_offset (CStereoMatching.h:47: 2)                        */
+    int origin_width;        /* m_OriginSize.width (scale of .cpp:692)                    */
+    double Q[16];            /* 4x4 row-major, after the sign flip of .cpp:138            */
+    double R_final[9];       /* 3x3 row-major (.cpp:132)                                  */
+    double T_final[3];       /* (.cpp:133)                                                */
+    int verbose;             /* Verbose (.cpp:12)                                         */
+} rsm_pair_in;
+
+/* Outputs of one pair. Buffers are caller-allocated; NULL skips that output. */
+typedef struct rsm_pair_out {
+    double *disparity[2];   /* width*height fp64 each: disparity[0|1] after the last level  */
+    rsm_boundary margin[2]; /* margin[0|1] at the top level (-> cam[pair][v].bound)         */
+    int64_t n_points;       /* points DisparityToCloud emits (.cpp:732-759)                  */
+    int64_t max_points;     /* capacity of xyz / bgr in points                               */
+    double *xyz;            /* 3*max_points fp64: R_final*X + T_final, InsertPoint order     */
+    uint8_t *bgr;           /* 3*max_points: colour of imagePyrm[top][0] (.cpp:756)          */
+    int64_t v_top;          /* masked view-0 pixels inside margin[0] at the top level        */
+} rsm_pair_out;
+
+typedef struct rsm_ctx rsm_ctx;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int rsm_create(rsm_ctx **ctx, int hip_device);
+void rsm_destroy(rsm_ctx *ctx);
+const char *rsm_last_error(const rsm_ctx *ctx);
+const char *rsm_version(void);
+
+/* ---- one pair: host buffers in, host buffers out (replaces the loop body .cpp:20-31) ----- */
+int rsm_match_pair(rsm_ctx *ctx, const rsm_pair_in *in, rsm_pair_out *out);
+
+/* ---- the same, split so inputs can stay resident in HBM --------------------------------- */
+/* H2D of the two rectified images + masks; (re)sizes the ctx workspace. */
+int rsm_upload_pair(rsm_ctx *ctx, const rsm_pair_in *in);
+/* Same, but image[]/mask[] are DEVICE pointers on this ctx's GPU (copied device-to-device). */
+int rsm_upload_pair_device(rsm_ctx *ctx, const rsm_pair_in *in);
+/* ConstructPyrm + all MatchOneLayer levels + DisparityToCloud on the resident pair.
+ * Synchronous with respect to the host on return. */
+int rsm_run_pair(rsm_ctx *ctx);
+/* D2H of the results of the last rsm_run_pair. */
+int rsm_download_pair(rsm_ctx *ctx, rsm_pair_out *out);
+/* Device pointers of the last results (valid until the next upload/run/destroy):
+ * fp64 disparity maps, n_points, packed cloud xyz (fp64 x3) and bgr (u8 x3). */
+int rsm_result_device(rsm_ctx *ctx, const double **disparity0, const double **disparity1,
+                      int64_t *n_points, const double **xyz, const uint8_t **bgr);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* Per-stage device time of the last rsm_run_pair, measured with hipEvents on the ctx stream.
+ * Enable before the run. Stage names: rsm_profile_stage_name(i), i < rsm_profile_stage_count(). */
+int rsm_profile_enable(rsm_ctx *ctx, int on);
+int rsm_profile_stage_count(void);
+const char *rsm_profile_stage_name(int stage);
+/* ms[i] = summed device milliseconds of stage i, launches[i] = kernel launches in it,
+ * bytes[i] = algorithmic bytes (SURVEY 8(d) model) those launches moved. */
+int rsm_profile_get(rsm_ctx *ctx, double *ms, int64_t *launches, double *bytes);
+
+/* ---- per-stage entry points (one direction; host buffers) for parity tests --------------- */
+/* own/oth = margin[!IsZeroOne] / margin[IsZeroOne] of the reference functions. */
+int rsm_stage_find_margin(rsm_ctx *ctx, const uint8_t *mask, int W, int H, int r, rsm_boundary *m);
+int rsm_stage_pyr_down(rsm_ctx *ctx, const uint8_t *src, int W, int H, int channels, uint8_t *dst);
+int rsm_stage_erode_ellipse(rsm_ctx *ctx, const uint8_t *mask, int W, int H, int ksize, uint8_t *dst255);
+int rsm_stage_initial_match(rsm_ctx *ctx, const uint8_t *img_own, const uint8_t *img_oth,
+                            const uint8_t *mask_own, const uint8_t *mask_oth, int W, int H, int r,
+                            int offset, const rsm_boundary *own, const rsm_boundary *oth,
+                            const double *parent /* NULL = lowest level */, int Wp, int Hp,
+                            int16_t *disp);
+int rsm_stage_smooth(rsm_ctx *ctx, int16_t *disp, int W, int H, const rsm_boundary *own);
+int rsm_stage_order(rsm_ctx *ctx, int16_t *disp, int W, int H, const rsm_boundary *own);
+int rsm_stage_uniqueness_pass_s16(rsm_ctx *ctx, int16_t *p, const int16_t *q, int W, int H,
+                                  const rsm_boundary *own, const rsm_boundary *oth);
+int rsm_stage_uniqueness_pass_f64(rsm_ctx *ctx, double *p, const double *q, int W, int H,
+                                  const rsm_boundary *own, const rsm_boundary *oth);
+int rsm_stage_set_boundary(rsm_ctx *ctx, const int16_t *disp, const uint8_t *mask_own, int W, int H,
+                           const rsm_boundary *own, const rsm_boundary *oth, int16_t *BL, int16_t *BR);
+int rsm_stage_rematch(rsm_ctx *ctx, const uint8_t *img_own, const uint8_t *img_oth,
+                      const uint8_t *mask_own, const uint8_t *mask_oth, int W, int H, int r,
+                      const rsm_boundary *own, const rsm_boundary *oth, int16_t *disp);
+int rsm_stage_median(rsm_ctx *ctx, int16_t *disp, const uint8_t *mask_own, int W, int H,
+                     const rsm_boundary *own);
+int rsm_stage_refine(rsm_ctx *ctx, const int16_t *disp_in, const uint8_t *img_own,
+                     const uint8_t *img_oth, int W, int H, int iterations, double ws,
+                     const rsm_boundary *own, double *disp_out);
+int rsm_stage_cloud(rsm_ctx *ctx, const double *disp, const uint8_t *mask_org, const uint8_t *img_own,
+                    int W, int H, const double *Q, double scale, const double *R_final,
+                    const double *T_final, const rsm_boundary *own, double *xyz, uint8_t *bgr,
+                    int64_t max_points, int64_t *n_points);
+
+/* ---- kernel microbenchmark (MDE/s: pixel x candidate NCC evaluations) -------------------- */
+/* Runs the NCC interval-argmax kernel `iters` times on a resident level-sized problem with
+ * `cands` candidates per pixel and returns average milliseconds per launch. */
+int rsm_bench_ncc(rsm_ctx *ctx, int W, int H, int r, int cands, int iters, double *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSM_H */

@@ -1,0 +1,973 @@
+/*
+ * stereo_oracle.c -- TEST INFRASTRUCTURE ONLY (parity oracle / CPU baseline).
+ *
+ * Plain-C (C11 + OpenMP) restatement of reconstruction/CStereoMatching.cpp and
+ * CManageData.cpp:81-90 of seed93/reconstruction on flat buffers: same stage
+ * order, same per-candidate fp64 window recompute, same row-parallel OpenMP
+ * loops, same quirks (see DESIGN.md "Quirks kept").  No OpenCV, no Armadillo:
+ * the five Armadillo primitives are restated with their exact accumulation
+ * order.  Build with -ffp-contract=off (the reference is MSVC x64 /O2: SSE2,
+ * no FMA contraction).
+ *
+ * Defined behaviour where the reference reads out of bounds (UB there):
+ *   - DisparityRefine right-window reads (:628) and UniquenessContraint_
+ *     q[boundary_L+1] reads (:492) are emulated on the flat row-major buffer;
+ *     an index outside the whole buffer reads 0 (image) / NOMATCH (disparity).
+ *   - Rematch candidates whose window would leave the image (only reachable
+ *     through the :938-939 typo) are skipped.
+ *
+ * PARITY PINNING: see stereo_oracle.h.
+ */
+#include "stereo_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NOMATCH ORC_NOMATCH
+#define MAX_DISPARITY 2 /* CStereoMatching.cpp:4 */
+#define IMAX(a, b) ((a) > (b) ? (a) : (b))
+#define IMIN(a, b) ((a) < (b) ? (a) : (b))
+
+static double wall_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------ */
+/* Armadillo 4.200 primitives (exact accumulation order)               */
+/* ------------------------------------------------------------------ */
+
+/* arrayops::accumulate, arrayops_meat.hpp:902-921 */
+static double arma_accumulate(const double *src, int n) {
+    double acc1 = 0.0, acc2 = 0.0;
+    int i, j;
+    for (i = 0, j = 1; j < n; i += 2, j += 2) {
+        acc1 += src[i];
+        acc2 += src[j];
+    }
+    if (i < n) acc1 += src[i];
+    return acc1 + acc2;
+}
+
+/* op_mean::direct_mean_robust, op_mean_meat.hpp:91-121 */
+static double arma_mean_robust(const double *X, int n) {
+    double r_mean = 0.0;
+    int i, j;
+    for (i = 0, j = 1; j < n; i += 2, j += 2) {
+        const double Xi = X[i], Xj = X[j];
+        r_mean = r_mean + (Xi - r_mean) / (double)j;
+        r_mean = r_mean + (Xj - r_mean) / (double)(j + 1);
+    }
+    if (i < n) r_mean = r_mean + (X[i] - r_mean) / (double)(i + 1);
+    return r_mean;
+}
+
+/* op_mean::direct_mean, op_mean_meat.hpp:77-86 */
+double orc_arma_mean(const double *a, int n) {
+    const double result = arma_accumulate(a, n) / (double)n;
+    return isfinite(result) ? result : arma_mean_robust(a, n);
+}
+
+/* arma_vec_norm_2 (direct-memory branch), fn_norm.hpp:99-130,171 */
+double orc_arma_norm2(const double *A, int n) {
+    double acc1 = 0.0, acc2 = 0.0;
+    int i, j;
+    for (i = 0, j = 1; j < n; i += 2, j += 2) {
+        const double ti = A[i], tj = A[j];
+        acc1 += ti * ti;
+        acc2 += tj * tj;
+    }
+    if (i < n) {
+        const double ti = A[i];
+        acc1 += ti * ti;
+    }
+    return sqrt(acc1 + acc2);
+}
+
+/* op_dot::direct_dot_arma, op_dot_meat.hpp:20-55 (BLAS is off: config.hpp:11-19) */
+double orc_arma_dot(const double *A, const double *B, int n) {
+    double v1 = 0.0, v2 = 0.0;
+    int i, j;
+    for (i = 0, j = 1; j < n; i += 2, j += 2) {
+        v1 += A[i] * B[i];
+        v2 += A[j] * B[j];
+    }
+    if (i < n) v1 += A[i] * B[i];
+    return v1 + v2;
+}
+
+static int cmp_int(const void *a, const void *b) {
+    const int x = *(const int *)a, y = *(const int *)b;
+    return (x > y) - (x < y);
+}
+
+/* op_median::direct_median on arma::ivec (sword = s32), op_median_meat.hpp:361-373;
+ * even count: op_mean::robust_mean(A,B) = A + (B-A)/2, op_mean_meat.hpp:358-361
+ * (A = largest of the lower half, B = element at `half`; integer division). */
+int orc_arma_median_int(int *v, int n) {
+    qsort(v, (size_t)n, sizeof(int), cmp_int);
+    const int half = n / 2;
+    if ((n % 2) == 0) {
+        const int A = v[half - 1], B = v[half];
+        return A + (B - A) / 2;
+    }
+    return v[half];
+}
+
+/* CManageData::WindowToVec(uchar**, x, w, u), CManageData.cpp:81-90.
+ * Column-major gather (byte column j outer, window row i inner). */
+double orc_window_to_vec(const uint8_t *const *rows, int x, int w, double *u) {
+    int k = 0;
+    for (int j = x * 3; j < (w + x) * 3; j++)
+        for (int i = 0; i < w; i++) u[k++] = (double)rows[i][j];
+    const int n = k;
+    const double m = orc_arma_mean(u, n);
+    for (int i = 0; i < n; i++) u[i] -= m; /* Mat::operator-=(scalar) */
+    const double normu = orc_arma_norm2(u, n);
+    return normu == 0 ? 1 : normu;
+}
+
+/* Same gather on a flat buffer with whole-buffer bounds emulation (see header). */
+static double window_to_vec_flat(const uint8_t *img, long total, long row_stride,
+                                 long first_row, int x, int w, double *u) {
+    int k = 0;
+    for (int j = x * 3; j < (w + x) * 3; j++)
+        for (int i = 0; i < w; i++) {
+            const long idx = (first_row + i) * row_stride + j;
+            u[k++] = (idx >= 0 && idx < total) ? (double)img[idx] : 0.0;
+        }
+    const int n = k;
+    const double m = orc_arma_mean(u, n);
+    for (int i = 0; i < n; i++) u[i] -= m;
+    const double normu = orc_arma_norm2(u, n);
+    return normu == 0 ? 1 : normu;
+}
+
+/* ------------------------------------------------------------------ */
+/* FindMargin, CStereoMatching.cpp:1011-1038                           */
+/* ------------------------------------------------------------------ */
+void orc_find_margin(const uint8_t *mask, int W, int H, int r, orc_boundary *m) {
+    m->YL = H - 1 - r;
+    m->YR = r;
+    m->XL = W - 1 - r;
+    m->XR = r;
+    for (int y = r; y < H - r; y++) {
+        const uint8_t *p = mask + (long)y * W;
+        int flag = 0;
+        for (int x = r; x < W - r; x++) {
+            if (p[x] != 255) continue;
+            m->XL = IMIN(m->XL, x);
+            m->XR = IMAX(m->XR, x);
+            flag = 1;
+        }
+        if (flag) {
+            m->YL = IMIN(m->YL, y);
+            m->YR = IMAX(m->YR, y);
+        }
+    }
+    m->width = m->XR - m->XL + 1;
+    m->height = m->YR - m->YL + 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* cv::pyrDown 8U (call sites CStereoMatching.cpp:1049-1050).          */
+/* OpenCV 2.4.5 source is not in the reference tree: restated from the */
+/* documented algorithm (5x5 [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101,  */
+/* round (v+128)>>8, dst = ((W+1)/2,(H+1)/2)).  PARITY UNPINNED.       */
+/* ------------------------------------------------------------------ */
+static inline int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        else p = 2 * n - 2 - p;
+    }
+    return p;
+}
+
+void orc_pyr_down_u8(const uint8_t *src, int W, int H, int C, uint8_t *dst) {
+    const int Wd = (W + 1) / 2, Hd = (H + 1) / 2;
+#pragma omp parallel for
+    for (int y = 0; y < Hd; y++) {
+        int sy[5];
+        for (int k = 0; k < 5; k++) sy[k] = reflect101(2 * y - 2 + k, H);
+        for (int x = 0; x < Wd; x++) {
+            int sx[5];
+            for (int k = 0; k < 5; k++) sx[k] = reflect101(2 * x - 2 + k, W);
+            for (int c = 0; c < C; c++) {
+                static const int wt[5] = {1, 4, 6, 4, 1};
+                int acc = 0;
+                for (int j = 0; j < 5; j++) {
+                    const uint8_t *row = src + (long)sy[j] * W * C;
+                    int h = 0;
+                    for (int i = 0; i < 5; i++) h += wt[i] * row[sx[i] * C + c];
+                    acc += wt[j] * h;
+                }
+                dst[((long)y * Wd + x) * C + c] = (uint8_t)((acc + 128) >> 8);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* cv::getStructuringElement(MORPH_ELLIPSE,(k,k)) + cv::erode          */
+/* (call site CStereoMatching.cpp:703-705).  Restated from OpenCV 2.4  */
+/* (not in tree).  Border pixels outside the image are ignored (+inf). */
+/* PARITY UNPINNED.                                                    */
+/* ------------------------------------------------------------------ */
+static void ellipse_spans(int k, int *j1, int *j2) {
+    const int r = k / 2, c = k / 2;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < k; i++) {
+        const int dy = i - r;
+        j1[i] = 0;
+        j2[i] = 0;
+        if (abs(dy) <= r) {
+            /* saturate_cast<int>(double) == cvRound == round-half-even (lrint) */
+            const int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));
+            j1[i] = IMAX(c - dx, 0);
+            j2[i] = IMIN(c + dx + 1, k);
+        }
+    }
+}
+
+void orc_erode_ellipse_u8(const uint8_t *src, int W, int H, int ksize, uint8_t *dst) {
+    int *j1 = (int *)malloc(sizeof(int) * (size_t)ksize * 2);
+    int *j2 = j1 + ksize;
+    ellipse_spans(ksize, j1, j2);
+    const int ax = ksize / 2, ay = ksize / 2; /* anchor = centre */
+#pragma omp parallel for
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            int v = 255;
+            for (int i = 0; i < ksize; i++) {
+                const int yy = y + i - ay;
+                if (yy < 0 || yy >= H) continue;
+                const uint8_t *row = src + (long)yy * W;
+                for (int j = j1[i]; j < j2[i]; j++) {
+                    const int xx = x + j - ax;
+                    if (xx < 0 || xx >= W) continue;
+                    if (row[xx] < v) v = row[xx];
+                }
+            }
+            dst[(long)y * W + x] = (uint8_t)v;
+        }
+    }
+    free(j1);
+}
+
+/* ------------------------------------------------------------------ */
+/* NCC matchers                                                        */
+/* ------------------------------------------------------------------ */
+
+/* Shared candidate loop of :207-218 / :289-300 / :551-562.
+ * Returns best column or -1; strict '>' from -1, ascending columns. */
+static int ncc_best(const uint8_t *const *winL, const uint8_t *const *winR,
+                    const uint8_t *q, int x, int L, int R, int r, int W,
+                    double *vecL, double *vecR) {
+    const int ws = 2 * r + 1, n = ws * ws * 3;
+    const double normL = orc_window_to_vec(winL, x - r, ws, vecL);
+    for (int i = 0; i < n; i++) vecL[i] /= normL; /* vecL /= normL */
+    int best = -1;
+    double best_v = -1;
+    for (int iMatch = L; iMatch <= R; iMatch++) {
+        if (iMatch - r < 0 || iMatch + r >= W) continue; /* see header: UB in reference */
+        if (q[iMatch] != 255) continue;
+        const double normR = orc_window_to_vec(winR, iMatch - r, ws, vecR);
+        const double v = orc_arma_dot(vecL, vecR, n) / normR;
+        if (v > best_v) {
+            best = iMatch;
+            best_v = v;
+        }
+    }
+    return best;
+}
+
+/* LowestLevelInitialMatch, CStereoMatching.cpp:170-227 */
+void orc_lowest_level_initial_match(const uint8_t *img_own, const uint8_t *img_oth,
+                                    const uint8_t *mask_own, const uint8_t *mask_oth,
+                                    int W, int H, int r,
+                                    const orc_boundary *own, const orc_boundary *oth,
+                                    int16_t *disp) {
+    for (long i = 0; i < (long)W * H; i++) disp[i] = NOMATCH; /* :174 */
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    const int XL1 = oth->XL, XR1 = oth->XR;
+    const int ws = 2 * r + 1, n = ws * ws * 3;
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        const uint8_t *p = mask_own + (long)y * W;
+        const uint8_t *q = mask_oth + (long)y * W;
+        int16_t *s = disp + (long)y * W;
+        const uint8_t *winL[64], *winR[64];
+        for (int i = -r; i <= r; i++) {
+            winL[i + r] = img_own + (long)(y + i) * W * 3;
+            winR[i + r] = img_oth + (long)(y + i) * W * 3;
+        }
+        double *vecL = (double *)malloc(sizeof(double) * (size_t)n * 2);
+        double *vecR = vecL + n;
+        for (int x = XL; x <= XR; x++) {
+            if (p[x] != 255) continue;
+            const int best = ncc_best(winL, winR, q, x, XL1, XR1, r, W, vecL, vecR);
+            if (best != -1) s[x] = (int16_t)(best - x);
+        }
+        free(vecL);
+    }
+}
+
+/* HighLevelInitialMatch, CStereoMatching.cpp:231-308 */
+void orc_high_level_initial_match(const uint8_t *img_own, const uint8_t *img_oth,
+                                  const uint8_t *mask_own, const uint8_t *mask_oth,
+                                  int W, int H, int r, int offset,
+                                  const orc_boundary *own, const orc_boundary *oth,
+                                  const double *parent, int Wp, int Hp,
+                                  int16_t *disp) {
+    (void)Hp;
+    for (long i = 0; i < (long)W * H; i++) disp[i] = NOMATCH; /* :235 */
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    const int XL1 = oth->XL, XR1 = oth->XR;
+    const int ws = 2 * r + 1, n = ws * ws * 3;
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        const uint8_t *p = mask_own + (long)y * W;
+        const uint8_t *q = mask_oth + (long)y * W;
+        const uint8_t *winL[64], *winR[64];
+        for (int i = -r; i <= r; i++) {
+            winL[i + r] = img_own + (long)(y + i) * W * 3;
+            winR[i + r] = img_oth + (long)(y + i) * W * 3;
+        }
+        int16_t *d = disp + (long)y * W;
+        const double *s = parent + (long)((int)((y + 1) / 2.0)) * Wp; /* :259 */
+        int boundary_L = XL1; /* :260 */
+        int boundary_R = XR1; /* :261 */
+        double *vecL = (double *)malloc(sizeof(double) * (size_t)n * 2);
+        double *vecR = vecL + n;
+        for (int x = XL; x <= XR; x++) {
+            if (p[x] != 255) continue;
+            const int temp2 = (int)((x + 1) / 2.0); /* :267 */
+            if (s[temp2] == NOMATCH) {              /* :273-283 */
+                for (int i = temp2 + 1; i <= (XR >> 1); i++) {
+                    if (s[i] != NOMATCH) {
+                        boundary_R = IMIN(i + (int)(s[i] * 2) + offset + 1, XR1);
+                        break;
+                    }
+                }
+            } else { /* :286-287 */
+                boundary_L = IMAX(x + (int)(s[temp2] * 2 + 0.5) - offset, XL1);
+                boundary_R = IMIN(x + (int)(s[temp2] * 2 + 0.5) + offset, XR1);
+            }
+            const int best = ncc_best(winL, winR, q, x, boundary_L, boundary_R, r, W, vecL, vecR);
+            if (best != -1) d[x] = (int16_t)(best - x); /* :301-302: max > -1 <=> found */
+        }
+        free(vecL);
+    }
+}
+
+/* Rematch, CStereoMatching.cpp:499-570 (calls SetBoundary_smooth<short> :514) */
+int orc_rematch(const uint8_t *img_own, const uint8_t *img_oth,
+                const uint8_t *mask_own, const uint8_t *mask_oth,
+                int W, int H, int r,
+                const orc_boundary *own, const orc_boundary *oth,
+                int16_t *disp) {
+    int16_t *BL = (int16_t *)malloc(sizeof(int16_t) * (size_t)W * H * 2);
+    int16_t *BR = BL + (long)W * H;
+    const int st = orc_set_boundary_smooth(disp, mask_own, W, H, own, oth, BL, BR);
+    if (st != 0) {
+        free(BL);
+        return st;
+    }
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    const int ws = 2 * r + 1, n = ws * ws * 3;
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        const uint8_t *p = mask_own + (long)y * W;
+        const uint8_t *q = mask_oth + (long)y * W;
+        int16_t *s = disp + (long)y * W;
+        const int16_t *bl = BL + (long)y * W, *br = BR + (long)y * W;
+        const uint8_t *winL[64], *winR[64];
+        for (int i = -r; i <= r; i++) {
+            winL[i + r] = img_own + (long)(y + i) * W * 3;
+            winR[i + r] = img_oth + (long)(y + i) * W * 3;
+        }
+        double *vecL = (double *)malloc(sizeof(double) * (size_t)n * 2);
+        double *vecR = vecL + n;
+        for (int x = XL; x <= XR; x++) {
+            if (p[x] != 255) continue;
+            if (s[x] == NOMATCH) {
+                /* (the reference also normalises the left window of matched
+                 * pixels, :535-537 -- dead work, result unused) */
+                const int best = ncc_best(winL, winR, q, x, (int)bl[x], (int)br[x], r, W, vecL, vecR);
+                if (best != -1) s[x] = (int16_t)(best - x);
+            } else {
+                (void)orc_window_to_vec(winL, x - r, ws, vecL); /* keep the CPU cost structure */
+            }
+        }
+        free(vecL);
+    }
+    free(BL);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* SmoothConstraint, CStereoMatching.cpp:370-448 (scatter form, serial */
+/* accumulation; the SE total-count index slip of :423-424 is kept)    */
+/* ------------------------------------------------------------------ */
+#define DIFFER(a, b) (abs((int)(a) - (int)(b)) > 1) /* :3 */
+void orc_smooth_constraint(int16_t *disp, int W, int H, const orc_boundary *own) {
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    uint8_t *tmp = (uint8_t *)calloc((size_t)W * H * 2, 1); /* CV_8UC2 zeros :379 */
+    for (int y = YL; y <= YR; y++) {
+        const int16_t *pup = disp + (long)y * W;
+        const int16_t *pdown = disp + (long)(y + 1) * W;
+        uint8_t *qup = tmp + (long)y * W * 2;
+        uint8_t *qdown = tmp + (long)(y + 1) * W * 2;
+        for (int x = XL; x <= XR; x++) {
+            if (pup[x] == NOMATCH) continue;
+            const int dx = x << 1;
+            if (pup[x + 1] != NOMATCH) { /* east */
+                qup[dx]++;
+                qup[dx + 2]++;
+                if (DIFFER(pup[x], pup[x + 1])) {
+                    qup[dx + 1]++;
+                    qup[dx + 3]++;
+                }
+            }
+            if (pdown[x - 1] != NOMATCH) { /* southwest */
+                qup[dx]++;
+                qdown[dx - 2]++;
+                if (DIFFER(pup[x], pdown[x - 1])) {
+                    qup[dx + 1]++;
+                    qdown[dx - 1]++;
+                }
+            }
+            if (pdown[x] != NOMATCH) { /* south */
+                qup[dx]++;
+                qdown[dx]++;
+                if (DIFFER(pup[x], pdown[x])) {
+                    qup[dx + 1]++;
+                    qdown[dx + 1]++;
+                }
+            }
+            if (pdown[x + 1] != NOMATCH) { /* southeast */
+                qup[x]++;       /* :423 -- byte index x, not 2x (reference quirk) */
+                qdown[x + 2]++; /* :424 -- byte index x+2, not 2x+2 */
+                if (DIFFER(pup[x], pdown[x + 1])) {
+                    qup[dx + 1]++;
+                    qdown[dx + 3]++;
+                }
+            }
+        }
+    }
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        const uint8_t *pcheck = tmp + (long)y * W * 2 + (XL << 1);
+        int16_t *pDis = disp + (long)y * W;
+        for (int x = XL; x <= XR; x++) {
+            if ((pcheck[0] == 0) || ((pcheck[1] << 1) > pcheck[0])) pDis[x] = NOMATCH;
+            pcheck += 2;
+        }
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ */
+/* OrderConstraint, CStereoMatching.cpp:310-368.  Same greedy as the   */
+/* reference's symmetric 0/1 matrix A (:337-351) without storing it:   */
+/* A(i,j)=1 <=> (j<i && m_j>m_i) || (j>i && m_j<m_i); max(idx) returns */
+/* the first maximum (op_max strict '>').                              */
+/* ------------------------------------------------------------------ */
+void orc_order_constraint(int16_t *disp, int W, int H, const orc_boundary *own) {
+    (void)H;
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    const int max_L = XR - XL + 1;
+    if (max_L <= 0) return;
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        int16_t *line = (int16_t *)malloc(sizeof(int16_t) * (size_t)max_L * 2);
+        int16_t *index = line + max_L;
+        int *cnt = (int *)malloc(sizeof(int) * (size_t)max_L);
+        uint8_t *dead = (uint8_t *)calloc((size_t)max_L, 1);
+        int16_t *p = disp + (long)y * W;
+        int valid = 0;
+        for (int x = XL; x <= XR; x++) {
+            if (p[x] == NOMATCH) continue;
+            line[valid] = (int16_t)(p[x] + x);
+            index[valid] = (int16_t)x;
+            valid++;
+        }
+        long ones = 0;
+        for (int i = 0; i < valid; i++) cnt[i] = 0;
+        for (int i = 0; i < valid; i++)
+            for (int j = 0; j < i; j++)
+                if (line[j] > line[i]) {
+                    cnt[i]++;
+                    cnt[j]++;
+                    ones++;
+                }
+        while (ones) {
+            int mi = 0, mv = cnt[0];
+            for (int i = 1; i < valid; i++)
+                if (cnt[i] > mv) {
+                    mv = cnt[i];
+                    mi = i;
+                }
+            for (int j = 0; j < valid; j++) {
+                if (dead[j] || j == mi) continue;
+                if ((j < mi && line[j] > line[mi]) || (j > mi && line[j] < line[mi])) cnt[j]--;
+            }
+            cnt[mi] = 0;
+            dead[mi] = 1;
+            ones -= mv;
+            p[index[mi]] = NOMATCH;
+        }
+        free(line);
+        free(cnt);
+        free(dead);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* UniquenessContraint_<T>, CStereoMatching.cpp:463-497                */
+/* ------------------------------------------------------------------ */
+void orc_uniqueness_pass_s16(int16_t *P, const int16_t *Q, int W, int H,
+                             const orc_boundary *own, const orc_boundary *oth) {
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    const int XL1 = oth->XL, XR1 = oth->XR;
+    const long total = (long)W * H;
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        int16_t *p = P + (long)y * W;
+        const int16_t *q = Q + (long)y * W;
+        for (int x = XL; x <= XR; x++) {
+            if (p[x] == NOMATCH) continue;
+            const int bL = IMAX((int)(p[x] + 0.5) + x - 1, XL1);
+            const int bR = IMIN(bL + 2, XR1);
+            int iMatch;
+            for (iMatch = bL; iMatch <= bR; iMatch++)
+                if (abs(q[iMatch] + p[x]) < 2) break;
+            if (iMatch > bR) {
+                const long fi = (long)y * W + bL + 1;
+                const int qv = (fi >= 0 && fi < total) ? Q[fi] : NOMATCH;
+                if (abs(qv + p[x - 1]) >= 2 && abs(qv + p[x + 1]) >= 2) p[x] = NOMATCH;
+            }
+        }
+    }
+}
+
+void orc_uniqueness_pass_f64(double *P, const double *Q, int W, int H,
+                             const orc_boundary *own, const orc_boundary *oth) {
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    const int XL1 = oth->XL, XR1 = oth->XR;
+    const long total = (long)W * H;
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        double *p = P + (long)y * W;
+        const double *q = Q + (long)y * W;
+        for (int x = XL; x <= XR; x++) {
+            if (p[x] == NOMATCH) continue;
+            const int bL = IMAX((int)(p[x] + 0.5) + x - 1, XL1);
+            const int bR = IMIN(bL + 2, XR1);
+            int iMatch;
+            for (iMatch = bL; iMatch <= bR; iMatch++)
+                if (fabs(q[iMatch] + p[x]) < 2) break;
+            if (iMatch > bR) {
+                const long fi = (long)y * W + bL + 1;
+                const double qv = (fi >= 0 && fi < total) ? Q[fi] : (double)NOMATCH;
+                if (fabs(qv + p[x - 1]) >= 2 && fabs(qv + p[x + 1]) >= 2) p[x] = NOMATCH;
+            }
+        }
+    }
+}
+
+/* UniquenessContraint<T>, CStereoMatching.cpp:450-461: (d0|d1,true) (d1|d0,false) (d0|d1,true) */
+void orc_uniqueness_s16(int16_t *d0, int16_t *d1, int W, int H,
+                        const orc_boundary *m0, const orc_boundary *m1) {
+    orc_uniqueness_pass_s16(d0, d1, W, H, m0, m1);
+    orc_uniqueness_pass_s16(d1, d0, W, H, m1, m0);
+    orc_uniqueness_pass_s16(d0, d1, W, H, m0, m1);
+}
+void orc_uniqueness_f64(double *d0, double *d1, int W, int H,
+                        const orc_boundary *m0, const orc_boundary *m1) {
+    orc_uniqueness_pass_f64(d0, d1, W, H, m0, m1);
+    orc_uniqueness_pass_f64(d1, d0, W, H, m1, m0);
+    orc_uniqueness_pass_f64(d0, d1, W, H, m0, m1);
+}
+
+/* ------------------------------------------------------------------ */
+/* SetBoundary_smooth<short>, CStereoMatching.cpp:817-942              */
+/* ------------------------------------------------------------------ */
+int orc_set_boundary_smooth(const int16_t *disp, const uint8_t *mask, int W, int H,
+                            const orc_boundary *own, const orc_boundary *oth,
+                            int16_t *BL, int16_t *BR) {
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    const int XL1 = oth->XL, XR1 = oth->XR;
+    if (YL >= YR || XL >= XR) return -2; /* :827-830 exit(0) */
+    for (long i = 0; i < (long)W * H; i++) {
+        BL[i] = -10000; /* :832 */
+        BR[i] = 10000;  /* :833 */
+    }
+    /* up -> down, :842-869 */
+    for (int y = YL; y <= YR - 1; y++) {
+        const int16_t *src = disp + (long)y * W;
+        const uint8_t *mk = mask + (long)y * W;
+        int16_t *bl_src = BL + (long)y * W, *br_src = BR + (long)y * W;
+        int16_t *bl_dst = BL + (long)(y + 1) * W, *br_dst = BR + (long)(y + 1) * W;
+#pragma omp parallel for
+        for (int x = XL; x <= XR; x++) {
+            if (mk[x] != 255) continue;
+            const int16_t ref = src[x];
+            if (ref == NOMATCH) {
+                bl_dst[x] = (int16_t)IMAX(bl_src[x] - MAX_DISPARITY, bl_dst[x]);
+                br_dst[x] = (int16_t)IMIN(br_src[x] + MAX_DISPARITY, br_dst[x]);
+            } else {
+                bl_src[x] = ref;
+                br_src[x] = ref;
+                bl_dst[x] = (int16_t)IMAX(ref - MAX_DISPARITY, bl_dst[x]);
+                br_dst[x] = (int16_t)IMIN(ref + MAX_DISPARITY, br_dst[x]);
+            }
+        }
+    }
+    /* down -> up, :872-901 */
+    for (int y = YR; y >= YL + 1; y--) {
+        const int16_t *src = disp + (long)y * W;
+        const uint8_t *mk = mask + (long)y * W;
+        int16_t *bl_src = BL + (long)y * W, *br_src = BR + (long)y * W;
+        int16_t *bl_dst = BL + (long)(y - 1) * W, *br_dst = BR + (long)(y - 1) * W;
+#pragma omp parallel for
+        for (int x = XL; x <= XR; x++) {
+            if (mk[x] != 255) continue;
+            const int16_t ref = src[x];
+            if (ref == NOMATCH) {
+                bl_dst[x] = (int16_t)IMAX(bl_src[x] - MAX_DISPARITY, bl_dst[x]);
+                br_dst[x] = (int16_t)IMIN(br_src[x] + MAX_DISPARITY, br_dst[x]);
+            } else {
+                bl_src[x] = ref;
+                br_src[x] = ref;
+                bl_dst[x] = (int16_t)IMAX(ref - MAX_DISPARITY, bl_dst[x]);
+                br_dst[x] = (int16_t)IMIN(ref + MAX_DISPARITY, br_dst[x]);
+            }
+        }
+    }
+    /* left <-> right, :903-941 */
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        int16_t *bl = BL + (long)y * W, *br = BR + (long)y * W;
+        const uint8_t *mk = mask + (long)y * W;
+        for (int x = XL; x <= XR - 1; x++) {
+            if (mk[x] == 255) {
+                bl[x + 1] = (int16_t)IMAX(bl[x] - 1, bl[x + 1]);
+                br[x + 1] = (int16_t)IMIN(br[x] + MAX_DISPARITY, br[x + 1]);
+            }
+        }
+        for (int x = XR; x >= XL + 1; x--) {
+            if (mk[x] == 255) {
+                bl[x] = (int16_t)(bl[x] + x);
+                br[x] = (int16_t)(br[x] + x);
+                if (bl[x] < XL1) bl[x] = (int16_t)XL1;
+                if (br[x] > XR1) br[x] = (int16_t)XR1;
+                bl[x - 1] = (int16_t)IMAX(bl[x] - x - MAX_DISPARITY, bl[x - 1]);
+                br[x - 1] = (int16_t)IMIN(br[x] - x + 1, br[x - 1]);
+            }
+        }
+        if (mk[XL] == 255) {
+            bl[XL] = (int16_t)(bl[XL] + XL);
+            br[XL] = (int16_t)(br[XL] + XL);
+            if (bl[XL] < XL1) bl[XL] = (int16_t)XL1;
+            if (br[XL] > XR1) bl[XL] = (int16_t)XR1; /* :938-939 typo kept (bl, not br) */
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* MedianFilter (iteration = 1), CStereoMatching.cpp:763-815           */
+/* ------------------------------------------------------------------ */
+void orc_median_filter(int16_t *disp, const uint8_t *mask, int W, int H,
+                       const orc_boundary *own) {
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * (size_t)W * H);
+    for (long i = 0; i < (long)W * H; i++) tmp[i] = NOMATCH; /* :772 */
+#pragma omp parallel for
+    for (int y = YL; y <= YR; y++) {
+        const uint8_t *mk = mask + (long)y * W;
+        int16_t *p = tmp + (long)y * W;
+        const int16_t *win[3];
+        for (int i = -1; i <= 1; i++) win[i + 1] = disp + (long)(y + i) * W;
+        for (int x = XL; x <= XR; x++) {
+            if (mk[x] != 255) continue;
+            int u[9], k = 0;
+            for (int i = x - 1; i < x + 1; i++) /* :792 -- columns x-1 and x only */
+                for (int j = 0; j < 3; j++)
+                    if (win[j][i] != NOMATCH) u[k++] = win[j][i];
+            if (win[1][x] == NOMATCH) {
+                if (k >= 4) p[x] = (int16_t)orc_arma_median_int(u, k);
+                else p[x] = NOMATCH;
+            } else {
+                if (k <= 2) p[x] = NOMATCH;
+                else p[x] = (int16_t)orc_arma_median_int(u, k);
+            }
+        }
+    }
+    memcpy(disp, tmp, sizeof(int16_t) * (size_t)W * H); /* swap :811-813 */
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ */
+/* DisparityRefine, CStereoMatching.cpp:572-680                        */
+/* ------------------------------------------------------------------ */
+#define SQUARE_(x) ((x) * (x))
+void orc_disparity_refine(const int16_t *disp_in, double *disp_out_final,
+                          const uint8_t *img_own, const uint8_t *img_oth,
+                          int W, int H, int iterations, double ws,
+                          const orc_boundary *own) {
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    const long N = (long)W * H;
+    const long total = N * 3;
+    double *out = (double *)malloc(sizeof(double) * (size_t)N);
+    double *cur = (double *)malloc(sizeof(double) * (size_t)N);
+    for (long i = 0; i < N; i++) out[i] = (double)disp_in[i]; /* convertTo :585 */
+    memcpy(cur, out, sizeof(double) * (size_t)N);              /* copyTo :587 */
+    for (int iter = 0; iter < iterations; iter++) {
+#pragma omp parallel for
+        for (int y = YL + 1; y <= YR - 1; y++) {
+            const double *pdis0 = out + (long)(y - 1) * W;
+            const double *pdis1 = out + (long)y * W;
+            const double *pdis2 = out + (long)(y + 1) * W;
+            double *pcur = cur + (long)y * W;
+            double vecL[27], vecR[27];
+            double xi[3];
+            double pdp = 0, pwp = 0;
+            for (int x = XL + 1; x <= XR - 1; x++) {
+                if (pdis1[x] == NOMATCH) continue;
+                const double dCenter = pdis1[x];
+                const double dEast = pdis1[x + 1];
+                const double dWest = pdis1[x - 1];
+                const double dNorth = pdis0[x];
+                const double dSouth = pdis2[x];
+                const int mode = (dEast != NOMATCH && dWest != NOMATCH) +
+                                 (dSouth != NOMATCH && dNorth != NOMATCH) * 2;
+                if (mode != 0) {
+                    const double normL = window_to_vec_flat(img_own, total, (long)W * 3, y - 1, x - 1, 3, vecL);
+                    const int iMatch = (int)(dCenter - 1.5) + x; /* :625 */
+                    for (int i = 0; i < 3; i++) {
+                        const double normR = window_to_vec_flat(img_oth, total, (long)W * 3, y - 1, iMatch + i, 3, vecR);
+                        xi[i] = (1 - orc_arma_dot(vecL, vecR, 27) / (normL * normR)) / 2;
+                    }
+                    int index = xi[0] >= xi[1];
+                    if (xi[index] > xi[2]) index = 2;
+                    switch (index) {
+                    case 0:
+                        pwp = xi[1] - xi[0];
+                        pdp = dCenter - 0.5;
+                        break;
+                    case 1:
+                        pwp = 0.5 * (xi[0] + xi[2]) - xi[1];
+                        pdp = dCenter + 0.5 * (xi[0] - xi[2]) / (xi[0] + xi[2] - 2 * xi[1]);
+                        if (pwp == 0) pdp = 0;
+                        break;
+                    case 2:
+                        pwp = xi[1] - xi[2];
+                        pdp = dCenter + 0.5;
+                        break;
+                    default:;
+                    }
+                }
+                switch (mode) {
+                case 0:
+                    pcur[x] = dCenter;
+                    break;
+                case 1:
+                    pcur[x] = (pdp * pwp + ws * (dEast + dWest) / 2) / (pwp + ws);
+                    break;
+                case 2:
+                    pcur[x] = (pdp * pwp + ws * (dNorth + dSouth) / 2) / (pwp + ws);
+                    break;
+                case 3: {
+                    double wx, wy, ds;
+                    wx = exp(-SQUARE_(fabs(dEast - dCenter) - fabs(dWest - dCenter)));
+                    wy = exp(-SQUARE_(fabs(dSouth - dCenter) - fabs(dNorth - dCenter)));
+                    if (wx + wy == 0) ds = (dEast + dWest + dSouth + dNorth) / 4;
+                    else ds = (wx * (dEast + dWest) + wy * (dNorth + dSouth)) / (2 * (wx + wy));
+                    pcur[x] = (pdp * pwp + ws * ds) / (pwp + ws);
+                } break;
+                }
+            }
+        }
+        /* :675-677 rotate */
+        double *t = out;
+        out = cur;
+        cur = t;
+    }
+    memcpy(disp_out_final, out, sizeof(double) * (size_t)N); /* :679 */
+    free(out);
+    free(cur);
+}
+
+/* ------------------------------------------------------------------ */
+/* DisparityToCloud<double>, CStereoMatching.cpp:682-761               */
+/* ------------------------------------------------------------------ */
+int64_t orc_disparity_to_cloud(const double *disp, const uint8_t *mask_org,
+                               const uint8_t *img_own, int W, int H,
+                               const double *Q, double scale,
+                               const double *R, const double *T,
+                               const orc_boundary *own,
+                               double *xyz, uint8_t *bgr, int64_t max_points) {
+    const int YL = own->YL, YR = own->YR, XL = own->XL, XR = own->XR;
+    double q[4][4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) q[i][j] = Q[i * 4 + j];
+    for (int i = 0; i < 4; i++) q[i][3] *= scale; /* _Q.col(3) *= scale :698 */
+    const double qz = q[2][3], qw = q[3][3];
+    uint8_t *mask = (uint8_t *)malloc((size_t)W * H);
+    const int erode_size = (int)ceil(0.02 * H); /* :703 */
+    orc_erode_ellipse_u8(mask_org, W, H, erode_size, mask);
+    int64_t n = 0;
+    for (int y = YL; y <= YR; y++) {
+        const double *sptr = disp + (long)y * W;
+        const uint8_t *s = img_own + (long)y * W * 3;
+        const double qy = y + q[1][3];
+        const uint8_t *p = mask + (long)y * W;
+        for (int x = XL; x <= XR; x++) {
+            if (p[x] != 255) continue;
+            if (sptr[x] == NOMATCH) continue;
+            const double iW = 1. / (qw + q[3][2] * sptr[x]);
+            const double F0 = (q[0][3] + (double)x) * iW;
+            const double F1 = qy * iW;
+            const double F2 = qz * iW;
+            if (n < max_points) {
+                if (xyz) {
+                    /* R_final*Fout + T_final :749 (3x3 gemm, k ascending, then + T) */
+                    for (int i = 0; i < 3; i++)
+                        xyz[3 * n + i] = (R[3 * i] * F0 + R[3 * i + 1] * F1 + R[3 * i + 2] * F2) + T[i];
+                }
+                if (bgr) memcpy(bgr + 3 * n, s + 3 * x, 3);
+            }
+            n++;
+        }
+    }
+    free(mask);
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* MatchAllLayer body for one pair, CStereoMatching.cpp:21-29, and     */
+/* MatchOneLayer, :36-113                                              */
+/* ------------------------------------------------------------------ */
+int orc_match_pair(const orc_pair_in *in, orc_pair_out *out) {
+    const int N = in->pyr_levels, r = in->radius;
+    if (N < 1 || N > 16 || r < 1 || r > 31) return -1;
+    if ((in->width % (1 << (N - 1))) || (in->height % (1 << (N - 1)))) return -1;
+    uint8_t *img[16][2], *msk[16][2];
+    int Wk[16], Hk[16];
+    /* ConstructPyrm :1040-1053 */
+    for (int k = N - 1; k >= 0; k--) {
+        Wk[k] = in->width >> (N - 1 - k);
+        Hk[k] = in->height >> (N - 1 - k);
+        for (int v = 0; v < 2; v++) {
+            img[k][v] = (uint8_t *)malloc((size_t)Wk[k] * Hk[k] * 3);
+            msk[k][v] = (uint8_t *)malloc((size_t)Wk[k] * Hk[k]);
+            if (k == N - 1) {
+                memcpy(img[k][v], in->image[v], (size_t)Wk[k] * Hk[k] * 3);
+                memcpy(msk[k][v], in->mask[v], (size_t)Wk[k] * Hk[k]);
+            } else {
+                orc_pyr_down_u8(img[k + 1][v], Wk[k + 1], Hk[k + 1], 3, img[k][v]);
+                orc_pyr_down_u8(msk[k + 1][v], Wk[k + 1], Hk[k + 1], 1, msk[k][v]);
+            }
+        }
+    }
+    int status = 0;
+    double *dd[2] = {NULL, NULL}; /* fp64 disparity of the previous level */
+    orc_boundary margin[2];
+    out->refine_seconds = 0;
+    out->match_seconds = 0;
+    for (int k = 0; k < N && status == 0; k++) {
+        const double t0 = wall_now();
+        const int W = Wk[k], H = Hk[k];
+        const long NP = (long)W * H;
+        orc_find_margin(msk[k][0], W, H, r, &margin[0]); /* :51-52 */
+        orc_find_margin(msk[k][1], W, H, r, &margin[1]);
+        int16_t *ds[2];
+        for (int v = 0; v < 2; v++) ds[v] = (int16_t *)malloc(sizeof(int16_t) * (size_t)NP);
+        double tm = wall_now();
+        for (int v = 0; v < 2; v++) {
+            const int o = 1 - v;
+            if (k == 0)
+                orc_lowest_level_initial_match(img[k][v], img[k][o], msk[k][v], msk[k][o], W, H, r,
+                                               &margin[v], &margin[o], ds[v]);
+            else
+                orc_high_level_initial_match(img[k][v], img[k][o], msk[k][v], msk[k][o], W, H, r,
+                                             in->offset, &margin[v], &margin[o], dd[v], Wk[k - 1],
+                                             Hk[k - 1], ds[v]);
+        }
+        out->match_seconds += wall_now() - tm;
+        for (int v = 0; v < 2; v++) orc_smooth_constraint(ds[v], W, H, &margin[v]); /* :66-67 */
+        for (int v = 0; v < 2; v++) orc_order_constraint(ds[v], W, H, &margin[v]);  /* :71-72 */
+        orc_uniqueness_s16(ds[0], ds[1], W, H, &margin[0], &margin[1]);             /* :75 */
+        tm = wall_now();
+        for (int v = 0; v < 2 && status == 0; v++)                                   /* :80-81 */
+            status = orc_rematch(img[k][v], img[k][1 - v], msk[k][v], msk[k][1 - v], W, H, r,
+                                 &margin[v], &margin[1 - v], ds[v]);
+        out->match_seconds += wall_now() - tm;
+        if (status == 0) {
+            orc_uniqueness_s16(ds[0], ds[1], W, H, &margin[0], &margin[1]);          /* :86 */
+            for (int v = 0; v < 2; v++) orc_median_filter(ds[v], msk[k][v], W, H, &margin[v]); /* :89-90 */
+            const int iteration = 30 + k * 30;                                        /* :95 */
+            tm = wall_now();
+            for (int v = 0; v < 2; v++) {
+                free(dd[v]);
+                dd[v] = (double *)malloc(sizeof(double) * (size_t)NP);
+                orc_disparity_refine(ds[v], dd[v], img[k][v], img[k][1 - v], W, H, iteration,
+                                     in->ws, &margin[v]);                             /* :97-98 */
+            }
+            out->refine_seconds += wall_now() - tm;
+            orc_uniqueness_f64(dd[0], dd[1], W, H, &margin[0], &margin[1]);          /* :109 */
+        }
+        for (int v = 0; v < 2; v++) free(ds[v]);
+        out->level_seconds[k] = wall_now() - t0;
+        if (in->verbose >= 1)
+            fprintf(stderr, "\t[oracle] layer %d (%dx%d) time: %.3f s\n", k, W, H, out->level_seconds[k]);
+    }
+    if (status == 0) {
+        const int k = N - 1, W = Wk[k], H = Hk[k];
+        out->margin[0] = margin[0]; /* :27-28 */
+        out->margin[1] = margin[1];
+        for (int v = 0; v < 2; v++)
+            if (out->disparity[v]) memcpy(out->disparity[v], dd[v], sizeof(double) * (size_t)W * H);
+        int64_t vt = 0;
+        for (int y = margin[0].YL; y <= margin[0].YR; y++)
+            for (int x = margin[0].XL; x <= margin[0].XR; x++) vt += msk[k][0][(long)y * W + x] == 255;
+        out->v_top = vt;
+        /* scale :692 = double(LowestLevelSize.width)/OriginSize.width*(1<<depth) */
+        const double scale = (double)Wk[0] / in->origin_width * (1 << k);
+        out->n_points = orc_disparity_to_cloud(dd[0], msk[k][0], img[k][0], W, H, in->Q, scale,
+                                               in->R_final, in->T_final, &margin[0], out->xyz,
+                                               out->bgr, out->max_points); /* :29 */
+    }
+    for (int v = 0; v < 2; v++) free(dd[v]);
+    for (int k = 0; k < N; k++)
+        for (int v = 0; v < 2; v++) {
+            free(img[k][v]);
+            free(msk[k][v]);
+        }
+    return status;
+}

@@ -1,0 +1,386 @@
+"""Host-side mirror of the reference's call surface for the CStereoMatching path.
+
+`StereoMatching` keeps the names, argument meaning and error behaviour of
+reconstruction/CStereoMatching.h:35-48 (Init / MatchAllLayer, public fields Q, R_final, T_final,
+margin, MatchBlockRadius, m_ws, m_offset, Verbose); `ManageData` / `Camera` carry the fields of
+CManageData.h:16-40 this path reads and writes.  All compute goes through the C ABI of
+include/rsm.h (librsm_mi355.so, hand-written HIP for gfx950) -- there is no CPU path here.
+
+Scope note: CStereoMatching::Rectify (.cpp:117-168, OpenCV stereoRectify/remap) is a "next" row
+(SURVEY.md 8(f1)); MatchAllLayer here starts from rectified top-level images, i.e. each
+`ManageData.cam[pair][v]` must already hold `.image` / `.mask` (what Rectify leaves there, .cpp:154-158)
+and `ManageData.rectified[pair]` the Q / R_final / T_final Rectify computes (.cpp:128-138).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import Boundary, NOMATCH, PairIn, PairOut, RsmError  # noqa: F401
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _bd(t) -> Boundary:
+    if isinstance(t, Boundary):
+        return t
+    return Boundary(*t)
+
+
+@dataclass
+class PairResult:
+    disparity: list            # [2] float64 HxW (NOMATCH = -10000)
+    margin: list               # [2] (YL, YR, XL, XR, width, height)
+    n_points: int
+    xyz: np.ndarray            # n_points x 3 float64, InsertPoint order
+    bgr: np.ndarray            # n_points x 3 uint8
+    v_top: int
+
+
+class Context:
+    """One rsm_ctx = one GPU. Not re-entrant (like CStereoMatching)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        st = self._lib.rsm_create(C.byref(h), int(device))
+        if st != 0:
+            raise RsmError(st, "rsm_create(device=%d) failed -- is an MI355X visible? (no CPU fallback)" % device)
+        self._h = h
+        self.device = device
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rsm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, st):
+        if st != 0:
+            raise RsmError(st, (self._lib.rsm_last_error(self._h) or b"").decode())
+
+    # ---- whole pair ------------------------------------------------------------------------------
+    @staticmethod
+    def _pair_in(cfg, imgs=None, msks=None):
+        pin = PairIn()
+        imgs = imgs or [_u8(cfg.image[0]), _u8(cfg.image[1])]
+        msks = msks or [_u8(cfg.mask[0]), _u8(cfg.mask[1])]
+        H, W = msks[0].shape
+        assert imgs[0].shape == (H, W, 3) and imgs[1].shape == (H, W, 3) and msks[1].shape == (H, W)
+        assert (W, H) == (cfg.width, cfg.height)
+        for v in range(2):
+            pin.image[v] = imgs[v].ctypes.data
+            pin.mask[v] = msks[v].ctypes.data
+        pin.width, pin.height, pin.pyr_levels = W, H, cfg.pyr_levels
+        pin.radius, pin.ws, pin.offset = cfg.radius, cfg.ws, cfg.offset
+        pin.origin_width = cfg.origin_width or W
+        pin.Q[:] = list(np.asarray(cfg.Q, np.float64).ravel())
+        pin.R_final[:] = list(np.asarray(cfg.R_final, np.float64).ravel())
+        pin.T_final[:] = list(np.asarray(cfg.T_final, np.float64).ravel())
+        pin.verbose = int(getattr(cfg, "verbose", 0))
+        return pin, (imgs, msks)
+
+    def upload_pair(self, cfg):
+        pin, keep = self._pair_in(cfg)
+        self._chk(self._lib.rsm_upload_pair(self._h, C.byref(pin)))
+        self._shape = (cfg.height, cfg.width)
+
+    def upload_pair_device(self, cfg, image_ptrs, mask_ptrs):
+        """image_ptrs / mask_ptrs: device addresses (e.g. torch.Tensor.data_ptr()) on this ctx's GPU."""
+        pin, _ = self._pair_in(cfg)
+        for v in range(2):
+            pin.image[v] = int(image_ptrs[v])
+            pin.mask[v] = int(mask_ptrs[v])
+        self._chk(self._lib.rsm_upload_pair_device(self._h, C.byref(pin)))
+        self._shape = (cfg.height, cfg.width)
+
+    def run_pair(self):
+        self._chk(self._lib.rsm_run_pair(self._h))
+
+    def download_pair(self, want_cloud=True, want_disparity=True) -> PairResult:
+        H, W = self._shape
+        d = [np.zeros((H, W), np.float64), np.zeros((H, W), np.float64)] if want_disparity else [None, None]
+        pout = PairOut()
+        if want_disparity:
+            pout.disparity[0] = d[0].ctypes.data
+            pout.disparity[1] = d[1].ctypes.data
+        # first call learns n_points, second copies exactly that many
+        pout.max_points = 0
+        self._chk(self._lib.rsm_download_pair(self._h, C.byref(pout)))
+        n = int(pout.n_points)
+        xyz = np.zeros((n, 3), np.float64)
+        bgr = np.zeros((n, 3), np.uint8)
+        if want_cloud and n > 0:
+            p2 = PairOut()
+            p2.max_points = n
+            p2.xyz = xyz.ctypes.data
+            p2.bgr = bgr.ctypes.data
+            self._chk(self._lib.rsm_download_pair(self._h, C.byref(p2)))
+        return PairResult(disparity=d, margin=[pout.margin[0].astuple(), pout.margin[1].astuple()],
+                          n_points=n, xyz=xyz, bgr=bgr, v_top=int(pout.v_top))
+
+    def match_pair(self, cfg, want_cloud=True) -> PairResult:
+        self.upload_pair(cfg)
+        self.run_pair()
+        return self.download_pair(want_cloud=want_cloud)
+
+    def result_device(self):
+        """(disparity0_ptr, disparity1_ptr, n_points, xyz_ptr, bgr_ptr) device addresses of the last run."""
+        d0, d1, xyz, bgr = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = C.c_int64()
+        self._chk(self._lib.rsm_result_device(self._h, C.byref(d0), C.byref(d1), C.byref(n), C.byref(xyz), C.byref(bgr)))
+        return d0.value, d1.value, int(n.value), xyz.value, bgr.value
+
+    # ---- measurement -----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self._lib.rsm_profile_enable(self._h, int(bool(on))))
+
+    def profile_get(self):
+        n = self._lib.rsm_profile_stage_count()
+        ms = (C.c_double * n)()
+        launches = (C.c_int64 * n)()
+        byt = (C.c_double * n)()
+        self._chk(self._lib.rsm_profile_get(self._h, ms, launches, byt))
+        return {self._lib.rsm_profile_stage_name(i).decode(): {"ms": ms[i], "launches": int(launches[i]), "bytes": byt[i]}
+                for i in range(n)}
+
+    def bench_ncc(self, W, H, r, cands, iters=5) -> float:
+        ms = C.c_double()
+        self._chk(self._lib.rsm_bench_ncc(self._h, W, H, r, cands, iters, C.byref(ms)))
+        return ms.value
+
+    # ---- per-stage entry points (parity tests) -----------------------------------------------------
+    def find_margin(self, mask, r):
+        mask = _u8(mask); H, W = mask.shape
+        m = Boundary()
+        self._chk(self._lib.rsm_stage_find_margin(self._h, _p(mask), W, H, r, C.byref(m)))
+        return m
+
+    def pyr_down(self, src):
+        src = _u8(src); H, W = src.shape[:2]
+        ch = 1 if src.ndim == 2 else src.shape[2]
+        dst = np.zeros(((H + 1) // 2, (W + 1) // 2) + (() if src.ndim == 2 else (ch,)), np.uint8)
+        self._chk(self._lib.rsm_stage_pyr_down(self._h, _p(src), W, H, ch, _p(dst)))
+        return dst
+
+    def erode_ellipse_is255(self, mask, ksize):
+        mask = _u8(mask); H, W = mask.shape
+        dst = np.zeros_like(mask)
+        self._chk(self._lib.rsm_stage_erode_ellipse(self._h, _p(mask), W, H, ksize, _p(dst)))
+        return dst
+
+    def initial_match(self, img_own, img_oth, mask_own, mask_oth, r, offset, own, oth, parent=None):
+        img_own, img_oth, mask_own, mask_oth = map(_u8, (img_own, img_oth, mask_own, mask_oth))
+        H, W = mask_own.shape
+        d = np.zeros((H, W), np.int16)
+        if parent is None:
+            pp, Wp, Hp = None, 0, 0
+        else:
+            parent = np.ascontiguousarray(parent, np.float64)
+            Hp, Wp = parent.shape
+            pp = _p(parent)
+        self._chk(self._lib.rsm_stage_initial_match(self._h, _p(img_own), _p(img_oth), _p(mask_own), _p(mask_oth),
+                                                    W, H, r, offset, C.byref(_bd(own)), C.byref(_bd(oth)),
+                                                    pp, Wp, Hp, _p(d)))
+        return d
+
+    def smooth_constraint(self, disp, own):
+        d = np.array(disp, dtype=np.int16, order="C"); H, W = d.shape
+        self._chk(self._lib.rsm_stage_smooth(self._h, _p(d), W, H, C.byref(_bd(own))))
+        return d
+
+    def order_constraint(self, disp, own):
+        d = np.array(disp, dtype=np.int16, order="C"); H, W = d.shape
+        self._chk(self._lib.rsm_stage_order(self._h, _p(d), W, H, C.byref(_bd(own))))
+        return d
+
+    def uniqueness_pass(self, p, q, own, oth):
+        if np.asarray(p).dtype == np.float64:
+            p = np.array(p, dtype=np.float64, order="C"); q = np.ascontiguousarray(q, np.float64)
+            fn = self._lib.rsm_stage_uniqueness_pass_f64
+        else:
+            p = np.array(p, dtype=np.int16, order="C"); q = np.ascontiguousarray(q, np.int16)
+            fn = self._lib.rsm_stage_uniqueness_pass_s16
+        H, W = p.shape
+        self._chk(fn(self._h, _p(p), _p(q), W, H, C.byref(_bd(own)), C.byref(_bd(oth))))
+        return p
+
+    def uniqueness(self, d0, d1, m0, m1):
+        """UniquenessContraint<T> (.cpp:450-461): three passes."""
+        d0 = self.uniqueness_pass(d0, d1, m0, m1)
+        d1 = self.uniqueness_pass(d1, d0, m1, m0)
+        d0 = self.uniqueness_pass(d0, d1, m0, m1)
+        return d0, d1
+
+    def set_boundary_smooth(self, disp, mask_own, own, oth):
+        d = np.ascontiguousarray(disp, np.int16); mask_own = _u8(mask_own); H, W = d.shape
+        BL = np.zeros((H, W), np.int16); BR = np.zeros((H, W), np.int16)
+        st = self._lib.rsm_stage_set_boundary(self._h, _p(d), _p(mask_own), W, H, C.byref(_bd(own)),
+                                              C.byref(_bd(oth)), _p(BL), _p(BR))
+        if st not in (0, _lib.RSM_E_DEGENERATE_MARGIN):
+            self._chk(st)
+        return st, BL, BR
+
+    def rematch(self, img_own, img_oth, mask_own, mask_oth, r, own, oth, disp):
+        img_own, img_oth, mask_own, mask_oth = map(_u8, (img_own, img_oth, mask_own, mask_oth))
+        d = np.array(disp, dtype=np.int16, order="C"); H, W = d.shape
+        st = self._lib.rsm_stage_rematch(self._h, _p(img_own), _p(img_oth), _p(mask_own), _p(mask_oth), W, H, r,
+                                         C.byref(_bd(own)), C.byref(_bd(oth)), _p(d))
+        if st not in (0, _lib.RSM_E_DEGENERATE_MARGIN):
+            self._chk(st)
+        return st, d
+
+    def median_filter(self, disp, mask_own, own):
+        d = np.array(disp, dtype=np.int16, order="C"); mask_own = _u8(mask_own); H, W = d.shape
+        self._chk(self._lib.rsm_stage_median(self._h, _p(d), _p(mask_own), W, H, C.byref(_bd(own))))
+        return d
+
+    def disparity_refine(self, disp, img_own, img_oth, iterations, ws, own):
+        d = np.ascontiguousarray(disp, np.int16); img_own = _u8(img_own); img_oth = _u8(img_oth)
+        H, W = d.shape
+        out = np.zeros((H, W), np.float64)
+        self._chk(self._lib.rsm_stage_refine(self._h, _p(d), _p(img_own), _p(img_oth), W, H, iterations,
+                                             C.c_double(ws), C.byref(_bd(own)), _p(out)))
+        return out
+
+    def disparity_to_cloud(self, disp, mask_org, img_own, Q, scale, R, T, own):
+        d = np.ascontiguousarray(disp, np.float64); mask_org = _u8(mask_org); img_own = _u8(img_own)
+        H, W = d.shape
+        Q = np.ascontiguousarray(Q, np.float64); R = np.ascontiguousarray(R, np.float64)
+        T = np.ascontiguousarray(T, np.float64)
+        cap = W * H
+        xyz = np.zeros((cap, 3), np.float64); bgr = np.zeros((cap, 3), np.uint8)
+        n = C.c_int64()
+        self._chk(self._lib.rsm_stage_cloud(self._h, _p(d), _p(mask_org), _p(img_own), W, H, _p(Q), C.c_double(scale),
+                                            _p(R), _p(T), C.byref(_bd(own)), _p(xyz), _p(bgr), C.c_int64(cap),
+                                            C.byref(n)))
+        return xyz[:n.value].copy(), bgr[:n.value].copy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Mirror of the reference's data / matching classes
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class Camera:
+    """struct camera (CManageData.h:16-26), the fields this path touches."""
+    camID: int = 0
+    image: np.ndarray | None = None   # rectified top-level BGR (what Rectify stores, .cpp:154)
+    mask: np.ndarray | None = None    # rectified + eroded mask (.cpp:156-158)
+    P: np.ndarray | None = None       # 3x4 projection (.cpp:143-145), carried through untouched
+    bound: tuple | None = None        # written by MatchAllLayer (.cpp:27-28)
+    image_name: str = ""
+    mask_name: str = ""
+
+
+@dataclass
+class ManageData:
+    """CManageData (CManageData.h:28-61), the members MatchAllLayer reads."""
+    cam: list = field(default_factory=list)          # cam[pair][0..1] -> Camera
+    m_PyrmNum: int = 4
+    m_LowestLevelSize: tuple = (160, 240)            # (width, height)
+    m_OriginSize: tuple = (0, 0)                     # (width, height)
+    isoutput: int = 0
+    rectified: list = field(default_factory=list)    # per pair: dict(Q=4x4, R_final=3x3, T_final=3)
+
+    @property
+    def m_CampairNum(self):
+        return len(self.cam)
+
+
+class _PairCfg:
+    pass
+
+
+class StereoMatching:
+    """CStereoMatching (CStereoMatching.h:35-71) on MI355X.
+
+    Init(data, CloudOptimization, radii=2, ws=0.5, disparity_offset=2) and MatchAllLayer() keep the
+    reference's signatures; per point `CloudOptimization.InsertPoint(point3)` is called in the
+    reference's row-major order (or `InsertPoints(xyz)` once per pair when the sink offers it),
+    then `CloudOptimization.filter(CamPair)` (.cpp:29-31).
+    """
+
+    def __init__(self, device: int = 0):
+        self._ctx = Context(device)
+        self.m_data = None
+        self.m_CloudOptimization = None
+        self.MatchBlockRadius = 2
+        self.m_ws = 0.5
+        self.m_offset = 2
+        self.Q = None
+        self.R_final = None
+        self.T_final = None
+        self.margin = [None, None]
+        self.Verbose = 1
+        self.disparity = [None, None]   # last pair's fp64 disparity maps (the reference keeps them local)
+
+    def Init(self, data, CloudOptimization=None, radii=2, ws=0.5, disparity_offset=2):
+        self.m_data = data
+        self.m_CloudOptimization = CloudOptimization
+        self.MatchBlockRadius = radii
+        self.m_ws = ws
+        self.m_offset = disparity_offset
+        self.Verbose = 1
+
+    def MatchAllLayer(self):
+        data = self.m_data
+        top = 1 << (data.m_PyrmNum - 1)
+        W, H = data.m_LowestLevelSize[0] * top, data.m_LowestLevelSize[1] * top  # .cpp:120
+        for CamPair in range(data.m_CampairNum):
+            cams = data.cam[CamPair]
+            if self.Verbose >= 1:
+                print("processing pair %d: cam %d and cam %d..." % (CamPair + 1, cams[0].camID, cams[1].camID))
+            if cams[0].image is None or cams[1].image is None:
+                # reference: "read image ... error" then silent return from Rectify (.cpp:147-151)
+                print("read image %s error" % (cams[0].image_name or cams[1].image_name))
+                return
+            rect = data.rectified[CamPair]
+            self.Q = np.asarray(rect["Q"], np.float64)
+            self.R_final = np.asarray(rect["R_final"], np.float64)
+            self.T_final = np.asarray(rect["T_final"], np.float64)
+            cfg = _PairCfg()
+            cfg.width, cfg.height, cfg.pyr_levels = W, H, data.m_PyrmNum
+            cfg.radius, cfg.ws, cfg.offset = self.MatchBlockRadius, self.m_ws, self.m_offset
+            cfg.origin_width = data.m_OriginSize[0] or W
+            cfg.image = [cams[0].image, cams[1].image]
+            cfg.mask = [cams[0].mask, cams[1].mask]
+            cfg.Q, cfg.R_final, cfg.T_final = self.Q, self.R_final, self.T_final
+            cfg.verbose = self.Verbose
+            res = self._ctx.match_pair(cfg)
+            self.margin = [res.margin[0], res.margin[1]]
+            cams[0].bound = res.margin[0]     # .cpp:27-28
+            cams[1].bound = res.margin[1]
+            self.disparity = res.disparity
+            if self.Verbose >= 1:
+                print("\tconverting disparity to cloud %d..." % CamPair)
+            sink = self.m_CloudOptimization
+            if sink is not None:
+                if hasattr(sink, "InsertPoints"):
+                    sink.InsertPoints(res.xyz, res.bgr)
+                else:
+                    for p in res.xyz:
+                        sink.InsertPoint(p)
+                if hasattr(sink, "filter"):
+                    sink.filter(CamPair)      # .cpp:31
+            self.last_result = res

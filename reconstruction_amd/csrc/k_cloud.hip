@@ -1,0 +1,194 @@
+// k_cloud.hip -- CStereoMatching::DisparityToCloud<double>, reconstruction/CStereoMatching.cpp:682-761.
+//   mask erosion by an ellipse of size ceil(0.02*rows) (.cpp:703-705): only "eroded == 255" is ever
+//   tested (.cpp:741), i.e. a binary question -> per-row prefix counts of non-255 pixels + one span
+//   test per structuring-element row (pixels outside the image are ignored, as cv::erode's default
+//   border does).
+//   Q-reprojection + R_final*X + T_final (.cpp:745-749), emitted in row-major pixel order: per-row
+//   counts -> exclusive scan -> ordered compaction (wave ballots), so the point list has exactly the
+//   InsertPoint order of the reference.
+#include "rsm_dev.h"
+
+// prefix[y*(W+1) + x] = number of pixels != 255 in row y, columns [0, x)
+__global__ __launch_bounds__(256) void k_bad_prefix(const uint8_t *__restrict__ mask, int W, int H,
+                                                    int32_t *__restrict__ prefix) {
+    const int y = blockIdx.x;
+    if (y >= H) return;
+    __shared__ int s_w[4], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint8_t *m = mask + (size_t)y * W;
+    int32_t *o = prefix + (size_t)y * (W + 1);
+    if (tid == 0) {
+        s_base = 0;
+        o[0] = 0;
+    }
+    __syncthreads();
+    for (int x0 = 0; x0 < W; x0 += 256) {
+        const int x = x0 + tid;
+        const bool bad = (x < W) && (m[x] != 255);
+        const unsigned long long b = __ballot(bad);
+        const int incl = __popcll(b & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull)));
+        if (lane == 0) s_w[wid] = __popcll(b);
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < wid; w++) base += s_w[w];
+        if (x < W) o[x + 1] = base + incl;
+        __syncthreads();
+        if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+
+void launch_bad_prefix(const uint8_t *mask, int W, int H, int32_t *prefix, hipStream_t st) {
+    hipLaunchKernelGGL(k_bad_prefix, dim3(H), dim3(256), 0, st, mask, W, H, prefix);
+}
+
+__device__ __forceinline__ bool eroded_is_255(const int32_t *__restrict__ prefix, int W, int H, int ksize,
+                                              const int *__restrict__ j1, const int *__restrict__ j2, int x,
+                                              int y) {
+    const int ax = ksize / 2, ay = ksize / 2;
+    for (int i = 0; i < ksize; i++) {
+        const int yy = y + i - ay;
+        if (yy < 0 || yy >= H) continue;
+        const int a = j1[i], b = j2[i];
+        if (b <= a) continue;
+        const int lo = max(x + a - ax, 0), hi = min(x + b - 1 - ax, W - 1);
+        if (lo > hi) continue;
+        const int32_t *p = prefix + (size_t)yy * (W + 1);
+        if (p[hi + 1] - p[lo] != 0) return false;
+    }
+    return true;
+}
+
+__global__ void k_erode_binary(const int32_t *__restrict__ prefix, int W, int H, int ksize,
+                               const int *__restrict__ j1, const int *__restrict__ j2,
+                               uint8_t *__restrict__ dst) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    dst[(size_t)y * W + x] = eroded_is_255(prefix, W, H, ksize, j1, j2, x, y) ? 255 : 0;
+}
+
+void launch_erode_binary(const int32_t *prefix, int W, int H, int ksize, const int *d_j1, const int *d_j2,
+                         uint8_t *dst255, hipStream_t st) {
+    hipLaunchKernelGGL(k_erode_binary, dim3((W + 255) / 256, H), dim3(256), 0, st, prefix, W, H, ksize, d_j1,
+                       d_j2, dst255);
+}
+
+struct CloudArgs {
+    const double *disp;
+    const int32_t *prefix;
+    const uint8_t *img;
+    int W, H, ksize;
+    const int *j1, *j2;
+    const double *q; // 16 doubles, column 3 already scaled (.cpp:698)
+    const double *R, *T;
+    Mg own;
+    int32_t *row_count;
+    int64_t *row_offset;
+    int64_t *npoints;
+    double *xyz;
+    uint8_t *bgr;
+    int64_t max_points;
+};
+
+__device__ __forceinline__ bool cloud_flag(const CloudArgs &c, int x, int y) {
+    if (x > c.own.XR) return false;
+    if (c.disp[(size_t)y * c.W + x] == (double)NOMATCH) return false; // .cpp:743
+    return eroded_is_255(c.prefix, c.W, c.H, c.ksize, c.j1, c.j2, x, y); // .cpp:741
+}
+
+// pass 0: count per row; pass 1: ordered write. One 256-thread workgroup per margin row.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_cloud(CloudArgs c) {
+    const int y = c.own.YL + blockIdx.x;
+    if (y > c.own.YR) return;
+    __shared__ int s_w[4];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_base = (PASS == 1) ? (long long)c.row_offset[blockIdx.x] : 0ll;
+    __syncthreads();
+    double q03 = 0, q13 = 0, qz = 0, qw = 0, q32 = 0;
+    if (PASS == 1) {
+        q03 = c.q[3];
+        q13 = c.q[7];
+        qz = c.q[11];
+        qw = c.q[15];
+        q32 = c.q[14];
+    }
+    for (int x0 = c.own.XL; x0 <= c.own.XR; x0 += 256) {
+        const int x = x0 + tid;
+        const bool f = cloud_flag(c, x, y);
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) s_w[wid] = __popcll(b);
+        __syncthreads();
+        if (PASS == 1 && f) {
+            long long pos = s_base + __popcll(b & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wid; w++) pos += s_w[w];
+            if (pos < c.max_points) {
+                const double dv = c.disp[(size_t)y * c.W + x];
+                const double qy = y + q13;           // .cpp:736
+                const double iW = 1. / (qw + q32 * dv); // .cpp:745
+                const double F0 = (q03 + (double)x) * iW;
+                const double F1 = qy * iW;
+                const double F2 = qz * iW;
+                if (c.xyz) {
+                    for (int i = 0; i < 3; i++) // R_final*Fout + T_final, .cpp:749
+                        c.xyz[3 * pos + i] = (c.R[3 * i] * F0 + c.R[3 * i + 1] * F1 + c.R[3 * i + 2] * F2) + c.T[i];
+                }
+                if (c.bgr) {
+                    const uint8_t *s = c.img + ((size_t)y * c.W + x) * 3; // .cpp:735,740,756
+                    c.bgr[3 * pos] = s[0];
+                    c.bgr[3 * pos + 1] = s[1];
+                    c.bgr[3 * pos + 2] = s[2];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (PASS == 0 && tid == 0) c.row_count[blockIdx.x] = (int)s_base;
+}
+
+// exclusive scan of row counts (single workgroup; rows <= a few thousand)
+__global__ __launch_bounds__(256) void k_row_scan(const int32_t *__restrict__ cnt, int rows, int64_t *__restrict__ off,
+                                                  int64_t *__restrict__ total) {
+    __shared__ long long s_w[4];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < rows; r0 += 256) {
+        const int r = r0 + tid;
+        const long long v = (r < rows) ? cnt[r] : 0;
+        long long incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_w[wid] = incl;
+        __syncthreads();
+        long long base = s_base;
+        for (int w = 0; w < wid; w++) base += s_w[w];
+        if (r < rows) off[r] = base + incl - v;
+        __syncthreads();
+        if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_base;
+}
+
+void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *img, int W, int H, int ksize,
+                  const int *d_j1, const int *d_j2, const double *q16_scaled, const double *R, const double *T,
+                  Mg own, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints, double *xyz,
+                  uint8_t *bgr, int64_t max_points, hipStream_t st) {
+    const int rows = own.YR - own.YL + 1;
+    if (rows <= 0 || own.XR < own.XL) {
+        (void)hipMemsetAsync(d_npoints, 0, sizeof(int64_t), st);
+        return;
+    }
+    CloudArgs c{disp, bad_prefix, img, W, H, ksize, d_j1, d_j2, q16_scaled, R, T, own,
+                row_count, row_offset, d_npoints, xyz, bgr, max_points};
+    hipLaunchKernelGGL(k_cloud<0>, dim3(rows), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(256), 0, st, row_count, rows, row_offset, d_npoints);
+    hipLaunchKernelGGL(k_cloud<1>, dim3(rows), dim3(256), 0, st, c);
+}

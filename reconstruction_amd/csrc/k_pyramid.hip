@@ -1,0 +1,180 @@
+// k_pyramid.hip -- pyramid construction, margins and NCC window-sum tables.
+//   pyr_down      replaces cv::pyrDown at reconstruction/CStereoMatching.cpp:1049-1050
+//   find_margin   replaces CStereoMatching::FindMargin, .cpp:1011-1038
+//   box_sums      hoists the per-candidate mean/norm of CManageData::WindowToVec
+//                 (CManageData.cpp:81-90) into exact int32 window sums, computed once per level
+#include "rsm_dev.h"
+
+// ---------------------------------------------------------------- fills
+template <typename T>
+__global__ void k_fill(T *p, size_t n, T v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+template <typename T>
+static void fill_t(T *p, size_t n, T v, hipStream_t st) {
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_fill<T>, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
+}
+void launch_fill_i16(int16_t *p, size_t n, int16_t v, hipStream_t st) { fill_t(p, n, v, st); }
+void launch_fill_f64(double *p, size_t n, double v, hipStream_t st) { fill_t(p, n, v, st); }
+void launch_fill_i32(int32_t *p, size_t n, int32_t v, hipStream_t st) { fill_t(p, n, v, st); }
+
+// ---------------------------------------------------------------- pyrDown (8U, C = 1 or 3)
+// 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, (v + 128) >> 8; dst = ((W+1)/2, (H+1)/2).
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = (p < 0) ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+template <int C>
+__global__ void k_pyr_down(const uint8_t *__restrict__ src, int W, int H, uint8_t *__restrict__ dst, int Wd, int Hd) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= Wd || y >= Hd) return;
+    int sx[5], sy[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        sx[k] = reflect101(2 * x - 2 + k, W) * C;
+        sy[k] = reflect101(2 * y - 2 + k, H);
+    }
+    int acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint8_t *row = src + (size_t)sy[j] * W * C;
+        const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int h = row[sx[0] + c] + row[sx[4] + c] + 4 * (row[sx[1] + c] + row[sx[3] + c]) + 6 * row[sx[2] + c];
+            acc[c] += wj * h;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) dst[((size_t)y * Wd + x) * C + c] = (uint8_t)((acc[c] + 128) >> 8);
+}
+
+void launch_pyr_down(const uint8_t *src, int W, int H, int C, uint8_t *dst, hipStream_t st) {
+    const int Wd = (W + 1) / 2, Hd = (H + 1) / 2;
+    dim3 grid((Wd + 255) / 256, Hd);
+    if (C == 3) hipLaunchKernelGGL(k_pyr_down<3>, grid, dim3(256), 0, st, src, W, H, dst, Wd, Hd);
+    else hipLaunchKernelGGL(k_pyr_down<1>, grid, dim3(256), 0, st, src, W, H, dst, Wd, Hd);
+}
+
+// ---------------------------------------------------------------- FindMargin
+__global__ void k_margin_init(int *out4, int W, int H, int r) {
+    out4[0] = W - 1 - r; // XL
+    out4[1] = r;         // XR
+    out4[2] = H - 1 - r; // YL
+    out4[3] = r;         // YR
+}
+
+// one block per row y in [r, H-r); columns [r, W-r)
+__global__ void k_find_margin(const uint8_t *__restrict__ mask, int W, int H, int r, int *out4) {
+    const int y = r + blockIdx.x;
+    if (y >= H - r) return;
+    const uint8_t *p = mask + (size_t)y * W;
+    int lo = 0x7fffffff, hi = -1;
+    for (int x = r + threadIdx.x; x < W - r; x += blockDim.x) {
+        if (p[x] == 255) {
+            lo = min(lo, x);
+            hi = max(hi, x);
+        }
+    }
+    // wave reduce
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    __shared__ int slo[4], shi[4];
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        slo[wid] = lo;
+        shi[wid] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); i++) {
+            lo = min(lo, slo[i]);
+            hi = max(hi, shi[i]);
+        }
+        if (hi >= 0) {
+            atomicMin(&out4[0], lo);
+            atomicMax(&out4[1], hi);
+            atomicMin(&out4[2], y);
+            atomicMax(&out4[3], y);
+        }
+    }
+}
+
+void launch_find_margin(const uint8_t *mask, int W, int H, int r, int *out4, hipStream_t st) {
+    hipLaunchKernelGGL(k_margin_init, dim3(1), dim3(1), 0, st, out4, W, H, r);
+    const int rows = H - 2 * r;
+    if (rows <= 0 || W - 2 * r <= 0) return;
+    hipLaunchKernelGGL(k_find_margin, dim3(rows), dim3(256), 0, st, mask, W, H, r, out4);
+}
+
+__global__ void k_count_masked(const uint8_t *__restrict__ mask, int W, Mg m, unsigned long long *count) {
+    const int y = m.YL + blockIdx.x;
+    if (y > m.YR) return;
+    int c = 0;
+    for (int x = m.XL + threadIdx.x; x <= m.XR; x += blockDim.x) c += mask[(size_t)y * W + x] == 255;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long long *d_count, hipStream_t st) {
+    (void)H;
+    (void)hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st);
+    if (m.YR < m.YL || m.XR < m.XL) return;
+    hipLaunchKernelGGL(k_count_masked, dim3(m.YR - m.YL + 1), dim3(256), 0, st, mask, W, m, d_count);
+}
+
+// ---------------------------------------------------------------- window-sum tables
+// S1(x,y) = sum of the (2r+1)x(2r+1)x3 bytes centred on (x,y); S2 = sum of their squares.
+// Defined where the window fits; 0 elsewhere. Separable: horizontal then vertical.
+__global__ void k_box_h(const uint8_t *__restrict__ img, int W, int H, int r, int32_t *__restrict__ h1,
+                        int32_t *__restrict__ h2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    int s1 = 0, s2 = 0;
+    if (x - r >= 0 && x + r < W) {
+        const uint8_t *p = img + ((size_t)y * W + (x - r)) * 3;
+        const int n = (2 * r + 1) * 3;
+        for (int i = 0; i < n; i++) {
+            const int v = p[i];
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    h1[(size_t)y * W + x] = s1;
+    h2[(size_t)y * W + x] = s2;
+}
+
+__global__ void k_box_v(const int32_t *__restrict__ h1, const int32_t *__restrict__ h2, int W, int H, int r,
+                        int32_t *__restrict__ S1, int32_t *__restrict__ S2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    int s1 = 0, s2 = 0;
+    if (y - r >= 0 && y + r < H) {
+        for (int j = -r; j <= r; j++) {
+            s1 += h1[(size_t)(y + j) * W + x];
+            s2 += h2[(size_t)(y + j) * W + x];
+        }
+    }
+    S1[(size_t)y * W + x] = s1;
+    S2[(size_t)y * W + x] = s2;
+}
+
+void launch_box_sums(const uint8_t *img, int W, int H, int r, int32_t *tmp1, int32_t *tmp2, int32_t *S1,
+                     int32_t *S2, hipStream_t st) {
+    dim3 grid((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_box_h, grid, dim3(256), 0, st, img, W, H, r, tmp1, tmp2);
+    hipLaunchKernelGGL(k_box_v, grid, dim3(256), 0, st, tmp1, tmp2, W, H, r, S1, S2);
+}

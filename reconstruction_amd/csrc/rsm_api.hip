@@ -1,0 +1,983 @@
+// rsm_api.hip -- host side of librsm_mi355.so: context, per-pair pipeline and the C ABI of include/rsm.h.
+//
+// Pipeline = CStereoMatching::MatchAllLayer loop body (reconstruction/CStereoMatching.cpp:21-29) from the
+// rectified top-level images: ConstructPyrm (:1040-1053) -> MatchOneLayer x PyrmNum (:36-113, stage order
+// kept exactly) -> DisparityToCloud<double> (:682-761).  Everything stays resident in HBM between the one
+// upload and the one download; both matching directions run in the same launches (gridDim.z).
+#include "../../include/rsm.h"
+#include "rsm_dev.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+enum Stage {
+    ST_PYRAMID = 0,
+    ST_MARGIN,
+    ST_BOXSUM,
+    ST_INITIAL_MATCH,
+    ST_SMOOTH,
+    ST_ORDER,
+    ST_UNIQ16,
+    ST_REMATCH,
+    ST_MEDIAN,
+    ST_REFINE_INIT,
+    ST_REFINE_SWEEP,     // all levels below the top
+    ST_REFINE_SWEEP_TOP, // the top level's sweeps (the dominant kernel)
+    ST_UNIQ64,
+    ST_CLOUD,
+    ST_COUNT
+};
+static const char *kStageNames[ST_COUNT] = {"pyramid", "margin", "boxsum", "initial_match", "smooth", "order",
+                                            "uniqueness_s16", "rematch", "median", "refine_init",
+                                            "refine_sweep", "refine_sweep_top", "uniqueness_f64", "cloud"};
+
+struct EvPair {
+    hipEvent_t a, b;
+    int stage;
+};
+
+struct rsm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // resident pair
+    bool have_pair = false, have_result = false;
+    rsm_pair_in in{};
+    int N = 0;
+    int Wk[RSM_MAX_LEVELS]{}, Hk[RSM_MAX_LEVELS]{};
+    uint8_t *img[RSM_MAX_LEVELS][2]{}, *msk[RSM_MAX_LEVELS][2]{};
+    Mg mg[RSM_MAX_LEVELS][2]{};
+
+    // workspace (sized for the top level)
+    size_t cap_px = 0;
+    std::vector<void *> allocs;
+    int *d_margins = nullptr; // N*2*4 ints
+    int32_t *S1[2]{}, *S2[2]{}, *tmp1 = nullptr, *tmp2 = nullptr;
+    int16_t *d16a[2]{}, *d16b[2]{}, *BL[2]{}, *BR[2]{};
+    double *f64[3][2]{};
+    int32_t *nv[2]{};
+    int32_t *rf_key[2]{};
+    double *rf_pwp[2]{}, *rf_delta[2]{};
+    int32_t *prefix = nullptr;
+    int *d_j1 = nullptr, *d_j2 = nullptr;
+    int32_t *row_count = nullptr;
+    int64_t *row_offset = nullptr;
+    int64_t *d_npoints = nullptr;
+    unsigned long long *d_vtop = nullptr;
+    double *d_q = nullptr, *d_R = nullptr, *d_T = nullptr;
+    double *xyz = nullptr;
+    uint8_t *bgr = nullptr;
+
+    // results
+    double *res_disp[2]{};
+    int64_t n_points = 0;
+    int64_t v_top = 0;
+
+    // profiling
+    bool profile = false;
+    std::vector<EvPair> evpool;
+    size_t ev_used = 0;
+    double prof_ms[ST_COUNT]{};
+    int64_t prof_launches[ST_COUNT]{};
+    double prof_bytes[ST_COUNT]{};
+};
+
+static int set_err(rsm_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                               \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return set_err((c), RSM_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),    \
+                           __FILE__, __LINE__);                                                       \
+    } while (0)
+
+static Mg to_mg(const rsm_boundary &b) { return Mg{b.YL, b.YR, b.XL, b.XR}; }
+static rsm_boundary to_boundary(const Mg &m) {
+    return rsm_boundary{m.YL, m.YR, m.XL, m.XR, m.XR - m.XL + 1, m.YR - m.YL + 1};
+}
+
+// ---- cv::getStructuringElement(MORPH_ELLIPSE) row spans (OpenCV 2.4; see oracle + DESIGN.md) ----
+static void ellipse_spans(int k, std::vector<int> &j1, std::vector<int> &j2) {
+    j1.assign(k, 0);
+    j2.assign(k, 0);
+    const int r = k / 2, c = k / 2;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < k; i++) {
+        const int dy = i - r;
+        if (abs(dy) <= r) {
+            const int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));
+            j1[i] = (c - dx > 0) ? c - dx : 0;
+            j2[i] = (c + dx + 1 < k) ? c + dx + 1 : k;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char *rsm_version(void) { return "rsm-mi355 0.1 (gfx950)"; }
+
+extern "C" const char *rsm_last_error(const rsm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int rsm_create(rsm_ctx **out, int hip_device) {
+    if (!out) return RSM_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RSM_E_HIP;
+    if (hip_device < 0 || hip_device >= ndev) return RSM_E_INVALID;
+    rsm_ctx *c = new rsm_ctx();
+    c->device = hip_device;
+    if (hipSetDevice(hip_device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return RSM_E_HIP;
+    }
+    *out = c;
+    return RSM_OK;
+}
+
+static void free_workspace(rsm_ctx *c) {
+    for (void *p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    c->cap_px = 0;
+    c->have_pair = c->have_result = false;
+}
+
+extern "C" void rsm_destroy(rsm_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_workspace(c);
+    for (auto &e : c->evpool) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+template <typename T>
+static int dalloc(rsm_ctx *c, T **p, size_t n) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
+    if (e != hipSuccess) return set_err(c, RSM_E_NOMEM, "hipMalloc(%zu) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return RSM_OK;
+}
+#define DALLOC(c, p, n)                         \
+    do {                                        \
+        int s__ = dalloc((c), &(p), (size_t)(n)); \
+        if (s__ != RSM_OK) return s__;          \
+    } while (0)
+
+static int validate(rsm_ctx *c, const rsm_pair_in *in) {
+    if (!c || !in) return RSM_E_INVALID;
+    if (in->pyr_levels < 1 || in->pyr_levels > RSM_MAX_LEVELS) return set_err(c, RSM_E_INVALID, "pyr_levels");
+    if (in->radius < 1 || in->radius > 15) return set_err(c, RSM_E_INVALID, "radius");
+    if (in->width <= 0 || in->height <= 0 || in->width > 32000 || in->height > 32000)
+        return set_err(c, RSM_E_INVALID, "size");
+    const int top = 1 << (in->pyr_levels - 1);
+    if ((in->width % top) || (in->height % top)) return set_err(c, RSM_E_INVALID, "size not divisible by 2^(levels-1)");
+    if ((in->width / top) <= 2 * in->radius + 2 || (in->height / top) <= 2 * in->radius + 2)
+        return set_err(c, RSM_E_INVALID, "lowest level smaller than the match window");
+    if (!in->image[0] || !in->image[1] || !in->mask[0] || !in->mask[1]) return set_err(c, RSM_E_INVALID, "null image/mask");
+    if (in->origin_width <= 0) return set_err(c, RSM_E_INVALID, "origin_width");
+    return RSM_OK;
+}
+
+static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
+    const size_t px = (size_t)in->width * in->height;
+    const bool same = c->N > 0 && c->cap_px == px && c->N == in->pyr_levels && c->Wk[c->N - 1] == in->width;
+    c->in = *in;
+    c->in.image[0] = c->in.image[1] = c->in.mask[0] = c->in.mask[1] = nullptr;
+    if (same) return RSM_OK;
+    free_workspace(c);
+    const int N = in->pyr_levels;
+    c->N = N;
+    for (int k = N - 1; k >= 0; k--) {
+        c->Wk[k] = in->width >> (N - 1 - k);
+        c->Hk[k] = in->height >> (N - 1 - k);
+        for (int v = 0; v < 2; v++) {
+            DALLOC(c, c->img[k][v], (size_t)c->Wk[k] * c->Hk[k] * 3);
+            DALLOC(c, c->msk[k][v], (size_t)c->Wk[k] * c->Hk[k]);
+        }
+    }
+    DALLOC(c, c->d_margins, RSM_MAX_LEVELS * 2 * 4);
+    DALLOC(c, c->tmp1, px);
+    DALLOC(c, c->tmp2, px);
+    for (int v = 0; v < 2; v++) {
+        DALLOC(c, c->S1[v], px);
+        DALLOC(c, c->S2[v], px);
+        DALLOC(c, c->d16a[v], px);
+        DALLOC(c, c->d16b[v], px);
+        DALLOC(c, c->BL[v], px);
+        DALLOC(c, c->BR[v], px);
+        for (int i = 0; i < 3; i++) DALLOC(c, c->f64[i][v], px);
+        DALLOC(c, c->nv[v], px / 4 + 16);
+        DALLOC(c, c->rf_key[v], px);
+        DALLOC(c, c->rf_pwp[v], px);
+        DALLOC(c, c->rf_delta[v], px);
+    }
+    DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
+    DALLOC(c, c->d_j1, 4096);
+    DALLOC(c, c->d_j2, 4096);
+    DALLOC(c, c->row_count, (size_t)in->height);
+    DALLOC(c, c->row_offset, (size_t)in->height);
+    DALLOC(c, c->d_npoints, 2);
+    DALLOC(c, c->d_vtop, 2);
+    DALLOC(c, c->d_q, 16);
+    DALLOC(c, c->d_R, 9);
+    DALLOC(c, c->d_T, 3);
+    DALLOC(c, c->xyz, px * 3);
+    DALLOC(c, c->bgr, px * 3);
+    c->cap_px = px;
+    return RSM_OK;
+}
+
+static int upload_common(rsm_ctx *c, const rsm_pair_in *in, hipMemcpyKind kind) {
+    int s = validate(c, in);
+    if (s != RSM_OK) return s;
+    HIPCHK(c, hipSetDevice(c->device));
+    s = ensure_workspace(c, in);
+    if (s != RSM_OK) return s;
+    const int top = c->N - 1;
+    const size_t px = (size_t)in->width * in->height;
+    for (int v = 0; v < 2; v++) {
+        HIPCHK(c, hipMemcpyAsync(c->img[top][v], in->image[v], px * 3, kind, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->msk[top][v], in->mask[v], px, kind, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_pair = true;
+    c->have_result = false;
+    return RSM_OK;
+}
+
+extern "C" int rsm_upload_pair(rsm_ctx *c, const rsm_pair_in *in) { return upload_common(c, in, hipMemcpyHostToDevice); }
+extern "C" int rsm_upload_pair_device(rsm_ctx *c, const rsm_pair_in *in) {
+    return upload_common(c, in, hipMemcpyDeviceToDevice);
+}
+
+// ---- profiling helpers --------------------------------------------------------------------------
+static void prof_begin(rsm_ctx *c, int stage) {
+    if (!c->profile) return;
+    if (c->ev_used == c->evpool.size()) {
+        EvPair e{};
+        (void)hipEventCreate(&e.a);
+        (void)hipEventCreate(&e.b);
+        c->evpool.push_back(e);
+    }
+    c->evpool[c->ev_used].stage = stage;
+    (void)hipEventRecord(c->evpool[c->ev_used].a, c->stream);
+}
+static void prof_end(rsm_ctx *c, int stage, int launches, double bytes) {
+    if (!c->profile) return;
+    (void)hipEventRecord(c->evpool[c->ev_used].b, c->stream);
+    c->ev_used++;
+    c->prof_launches[stage] += launches;
+    c->prof_bytes[stage] += bytes;
+}
+
+extern "C" int rsm_profile_enable(rsm_ctx *c, int on) {
+    if (!c) return RSM_E_INVALID;
+    c->profile = on != 0;
+    return RSM_OK;
+}
+extern "C" int rsm_profile_stage_count(void) { return ST_COUNT; }
+extern "C" const char *rsm_profile_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
+extern "C" int rsm_profile_get(rsm_ctx *c, double *ms, int64_t *launches, double *bytes) {
+    if (!c) return RSM_E_INVALID;
+    for (int i = 0; i < ST_COUNT; i++) {
+        if (ms) ms[i] = c->prof_ms[i];
+        if (launches) launches[i] = c->prof_launches[i];
+        if (bytes) bytes[i] = c->prof_bytes[i];
+    }
+    return RSM_OK;
+}
+
+// ---- stage-argument assembly ---------------------------------------------------------------------
+static StageArgs level_args(rsm_ctx *c, int k) {
+    StageArgs a{};
+    a.ndir = 2;
+    a.W = c->Wk[k];
+    a.H = c->Hk[k];
+    a.Wp = k > 0 ? c->Wk[k - 1] : 0;
+    a.Hp = k > 0 ? c->Hk[k - 1] : 0;
+    a.r = c->in.radius;
+    a.offset = c->in.offset;
+    a.ws = c->in.ws;
+    for (int v = 0; v < 2; v++) {
+        DirArgs &d = a.d[v];
+        const int o = 1 - v;
+        d.img_own = c->img[k][v];
+        d.img_oth = c->img[k][o];
+        d.mask_own = c->msk[k][v];
+        d.mask_oth = c->msk[k][o];
+        d.S1_own = c->S1[v];
+        d.S2_own = c->S2[v];
+        d.S1_oth = c->S1[o];
+        d.S2_oth = c->S2[o];
+        d.own = c->mg[k][v];
+        d.oth = c->mg[k][o];
+        d.BL = c->BL[v];
+        d.BR = c->BR[v];
+        d.parent_nv = c->nv[v];
+        d.rf_key = c->rf_key[v];
+        d.rf_pwp = c->rf_pwp[v];
+        d.rf_delta = c->rf_delta[v];
+    }
+    return a;
+}
+
+static bool degenerate(const Mg &m) { return m.YL >= m.YR || m.XL >= m.XR; } // .cpp:827
+
+extern "C" int rsm_run_pair(rsm_ctx *c) {
+    if (!c) return RSM_E_INVALID;
+    if (!c->have_pair) return set_err(c, RSM_E_STATE, "rsm_run_pair before rsm_upload_pair");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int N = c->N, r = c->in.radius;
+    c->have_result = false;
+    c->ev_used = 0;
+    for (int i = 0; i < ST_COUNT; i++) {
+        c->prof_ms[i] = 0;
+        c->prof_launches[i] = 0;
+        c->prof_bytes[i] = 0;
+    }
+    const double P_top_full = (double)c->Wk[N - 1] * c->Hk[N - 1];
+
+    // ConstructPyrm, .cpp:1040-1053 (top level = uploaded images)
+    prof_begin(c, ST_PYRAMID);
+    for (int k = N - 2; k >= 0; k--)
+        for (int v = 0; v < 2; v++) {
+            launch_pyr_down(c->img[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 3, c->img[k][v], st);
+            launch_pyr_down(c->msk[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 1, c->msk[k][v], st);
+        }
+    prof_end(c, ST_PYRAMID, 4 * (N - 1), 14.0 * P_top_full);
+
+    // FindMargin for every level and view (.cpp:51-52): depends on the masks only
+    prof_begin(c, ST_MARGIN);
+    for (int k = 0; k < N; k++)
+        for (int v = 0; v < 2; v++)
+            launch_find_margin(c->msk[k][v], c->Wk[k], c->Hk[k], r, c->d_margins + (k * 2 + v) * 4, st);
+    prof_end(c, ST_MARGIN, 4 * N, 0);
+    int hm[RSM_MAX_LEVELS * 2 * 4];
+    HIPCHK(c, hipMemcpyAsync(hm, c->d_margins, sizeof(int) * N * 2 * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int k = 0; k < N; k++)
+        for (int v = 0; v < 2; v++) {
+            const int *m = hm + (k * 2 + v) * 4;
+            c->mg[k][v] = Mg{m[2], m[3], m[0], m[1]};
+        }
+    launch_count_masked(c->msk[N - 1][0], c->Wk[N - 1], c->Hk[N - 1], c->mg[N - 1][0], c->d_vtop, st);
+
+    int par = 0; // index of the fp64 buffer holding the previous level's disparity (this is `disparity[]`)
+    for (int k = 0; k < N; k++) {
+        const int W = c->Wk[k], H = c->Hk[k];
+        const size_t px = (size_t)W * H;
+        StageArgs a = level_args(c, k);
+        const double Pk = 0.5 * ((double)(a.d[0].own.XR - a.d[0].own.XL + 1) * (a.d[0].own.YR - a.d[0].own.YL + 1) +
+                                 (double)(a.d[1].own.XR - a.d[1].own.XL + 1) * (a.d[1].own.YR - a.d[1].own.YL + 1));
+        // Rematch -> SetBoundary_smooth exits on a degenerate margin (.cpp:827-830)
+        if (degenerate(c->mg[k][0]) || degenerate(c->mg[k][1]))
+            return set_err(c, RSM_E_DEGENERATE_MARGIN, "level %d: YL>=YR || XL>=XR", k);
+
+        prof_begin(c, ST_BOXSUM);
+        for (int v = 0; v < 2; v++) launch_box_sums(c->img[k][v], W, H, r, c->tmp1, c->tmp2, c->S1[v], c->S2[v], st);
+        prof_end(c, ST_BOXSUM, 4, 0);
+
+        // ---- initial match (.cpp:53-62) -> d16a
+        prof_begin(c, ST_INITIAL_MATCH);
+        for (int v = 0; v < 2; v++) {
+            launch_fill_i16(c->d16a[v], px, (int16_t)NOMATCH, st);
+            a.d[v].d16_in = c->d16a[v];
+            a.d[v].d16_out = c->d16a[v];
+        }
+        if (k == 0) {
+            launch_ncc_argmax(a, 0, st);
+        } else {
+            for (int v = 0; v < 2; v++) {
+                a.d[v].parent = c->f64[par][v];
+                launch_next_valid(c->f64[par][v], a.Wp, a.Hp, c->nv[v], st);
+            }
+            launch_hl_interval(a, st);
+            launch_ncc_argmax(a, 1, st);
+        }
+        prof_end(c, ST_INITIAL_MATCH, k == 0 ? 3 : 6, 24.0 * Pk);
+
+        // ---- SmoothConstraint (.cpp:66-67): d16a -> d16b
+        prof_begin(c, ST_SMOOTH);
+        for (int v = 0; v < 2; v++) {
+            a.d[v].d16_in = c->d16a[v];
+            a.d[v].d16_out = c->d16b[v];
+        }
+        launch_smooth(a, st);
+        prof_end(c, ST_SMOOTH, 1, 8.0 * Pk);
+
+        // ---- OrderConstraint (.cpp:71-72): d16b in place
+        prof_begin(c, ST_ORDER);
+        for (int v = 0; v < 2; v++) a.d[v].d16_in = a.d[v].d16_out = c->d16b[v];
+        launch_order(a, st);
+        prof_end(c, ST_ORDER, 1, 8.0 * Pk);
+
+        // ---- UniquenessContraint<short> (.cpp:75)
+        prof_begin(c, ST_UNIQ16);
+        launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
+        launch_uniq_s16(c->d16b[1], c->d16b[0], W, H, c->mg[k][1], c->mg[k][0], st);
+        launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
+        prof_end(c, ST_UNIQ16, 3, 18.0 * Pk);
+
+        // ---- Rematch (.cpp:80-81): SetBoundary_smooth + NCC on still-unmatched pixels, in place
+        prof_begin(c, ST_REMATCH);
+        launch_set_boundary(a, st);
+        launch_ncc_argmax(a, 2, st);
+        prof_end(c, ST_REMATCH, 3, 46.0 * Pk);
+
+        // ---- UniquenessContraint<short> (.cpp:86)
+        prof_begin(c, ST_UNIQ16);
+        launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
+        launch_uniq_s16(c->d16b[1], c->d16b[0], W, H, c->mg[k][1], c->mg[k][0], st);
+        launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
+        prof_end(c, ST_UNIQ16, 3, 18.0 * Pk);
+
+        // ---- MedianFilter (.cpp:89-90): d16b -> d16a (pre-filled NOMATCH, .cpp:772)
+        prof_begin(c, ST_MEDIAN);
+        for (int v = 0; v < 2; v++) {
+            launch_fill_i16(c->d16a[v], px, (int16_t)NOMATCH, st);
+            a.d[v].d16_in = c->d16b[v];
+            a.d[v].d16_out = c->d16a[v];
+        }
+        launch_median(a, st);
+        prof_end(c, ST_MEDIAN, 3, 10.0 * Pk);
+
+        // ---- DisparityRefine (.cpp:95-98): int16 d16a -> fp64, 30 + 30k Jacobi sweeps
+        const int iters = 30 + k * 30;
+        const int ia = (par + 1) % 3, ib = (par + 2) % 3;
+        prof_begin(c, ST_REFINE_INIT);
+        for (int v = 0; v < 2; v++) {
+            a.d[v].d16_in = c->d16a[v];
+            a.d[v].f64_a = c->f64[ia][v];
+            a.d[v].f64_b = c->f64[ib][v];
+        }
+        launch_refine_init(a, st);
+        prof_end(c, ST_REFINE_INIT, 1, 12.0 * Pk);
+        const int st_sweep = (k == N - 1) ? ST_REFINE_SWEEP_TOP : ST_REFINE_SWEEP;
+        prof_begin(c, st_sweep);
+        int cur = ia, nxt = ib;
+        for (int it = 0; it < iters; it++) {
+            for (int v = 0; v < 2; v++) {
+                a.d[v].f64_a = c->f64[cur][v];
+                a.d[v].f64_b = c->f64[nxt][v];
+            }
+            a.flag = (k == N - 1);
+            launch_refine_sweep(a, st);
+            const int t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        prof_end(c, st_sweep, iters, 32.0 * Pk * iters);
+
+        // ---- UniquenessContraint<double> (.cpp:109) on the refined maps (now in f64[cur])
+        prof_begin(c, ST_UNIQ64);
+        launch_uniq_f64(c->f64[cur][0], c->f64[cur][1], W, H, c->mg[k][0], c->mg[k][1], st);
+        launch_uniq_f64(c->f64[cur][1], c->f64[cur][0], W, H, c->mg[k][1], c->mg[k][0], st);
+        launch_uniq_f64(c->f64[cur][0], c->f64[cur][1], W, H, c->mg[k][0], c->mg[k][1], st);
+        prof_end(c, ST_UNIQ64, 3, 72.0 * Pk);
+        par = cur;
+    }
+
+    // ---- DisparityToCloud<double>(disparity[0], maskPyrm[top][0], Q, top, true) (.cpp:29)
+    {
+        const int k = N - 1, W = c->Wk[k], H = c->Hk[k];
+        prof_begin(c, ST_CLOUD);
+        const int ksize = (int)ceil(0.02 * H); // .cpp:703
+        if (ksize > 4096) return set_err(c, RSM_E_INVALID, "erode size");
+        std::vector<int> j1, j2;
+        ellipse_spans(ksize, j1, j2);
+        HIPCHK(c, hipMemcpyAsync(c->d_j1, j1.data(), sizeof(int) * ksize, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_j2, j2.data(), sizeof(int) * ksize, hipMemcpyHostToDevice, st));
+        double q[16];
+        memcpy(q, c->in.Q, sizeof q);
+        const double scale = (double)c->Wk[0] / c->in.origin_width * (1 << k); // .cpp:692
+        for (int i = 0; i < 4; i++) q[i * 4 + 3] *= scale;                     // .cpp:698
+        HIPCHK(c, hipMemcpyAsync(c->d_q, q, sizeof q, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_R, c->in.R_final, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_T, c->in.T_final, sizeof(double) * 3, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st)); // j1/j2/q are stack/vector storage
+        launch_bad_prefix(c->msk[k][0], W, H, c->prefix, st);
+        launch_cloud(c->f64[par][0], c->prefix, c->img[k][0], W, H, ksize, c->d_j1, c->d_j2, c->d_q, c->d_R, c->d_T,
+                     c->mg[k][0], c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
+        const Mg &m = c->mg[k][0];
+        prof_end(c, ST_CLOUD, 4, 28.0 * (double)(m.XR - m.XL + 1) * (m.YR - m.YL + 1));
+    }
+    int64_t np = 0;
+    unsigned long long vt = 0;
+    HIPCHK(c, hipMemcpyAsync(&np, c->d_npoints, sizeof np, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&vt, c->d_vtop, sizeof vt, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    c->n_points = np;
+    c->v_top = (int64_t)vt;
+    c->res_disp[0] = c->f64[par][0];
+    c->res_disp[1] = c->f64[par][1];
+    c->have_result = true;
+    if (c->profile) {
+        for (size_t i = 0; i < c->ev_used; i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, c->evpool[i].a, c->evpool[i].b) == hipSuccess) c->prof_ms[c->evpool[i].stage] += ms;
+        }
+    }
+    return RSM_OK;
+}
+
+extern "C" int rsm_download_pair(rsm_ctx *c, rsm_pair_out *out) {
+    if (!c || !out) return RSM_E_INVALID;
+    if (!c->have_result) return set_err(c, RSM_E_STATE, "no result to download");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int k = c->N - 1;
+    const size_t px = (size_t)c->Wk[k] * c->Hk[k];
+    for (int v = 0; v < 2; v++) {
+        out->margin[v] = to_boundary(c->mg[k][v]); // .cpp:27-28
+        if (out->disparity[v])
+            HIPCHK(c, hipMemcpyAsync(out->disparity[v], c->res_disp[v], px * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    out->n_points = c->n_points;
+    out->v_top = c->v_top;
+    int64_t n = c->n_points;
+    if (n > out->max_points) n = out->max_points;
+    if (n > (int64_t)c->cap_px) n = (int64_t)c->cap_px;
+    if (n > 0 && out->xyz) HIPCHK(c, hipMemcpyAsync(out->xyz, c->xyz, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (n > 0 && out->bgr) HIPCHK(c, hipMemcpyAsync(out->bgr, c->bgr, (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RSM_OK;
+}
+
+extern "C" int rsm_result_device(rsm_ctx *c, const double **d0, const double **d1, int64_t *n_points,
+                                 const double **xyz, const uint8_t **bgr) {
+    if (!c) return RSM_E_INVALID;
+    if (!c->have_result) return set_err(c, RSM_E_STATE, "no result");
+    if (d0) *d0 = c->res_disp[0];
+    if (d1) *d1 = c->res_disp[1];
+    if (n_points) *n_points = c->n_points;
+    if (xyz) *xyz = c->xyz;
+    if (bgr) *bgr = c->bgr;
+    return RSM_OK;
+}
+
+extern "C" int rsm_match_pair(rsm_ctx *c, const rsm_pair_in *in, rsm_pair_out *out) {
+    int s = rsm_upload_pair(c, in);
+    if (s != RSM_OK) return s;
+    s = rsm_run_pair(c);
+    if (s != RSM_OK) return s;
+    return rsm_download_pair(c, out);
+}
+
+// =================================================================================================
+// Per-stage entry points (host buffers, one direction) for the parity tests.
+// =================================================================================================
+namespace {
+struct Tmp { // scoped device allocations of one stage call
+    rsm_ctx *c;
+    std::vector<void *> ptrs;
+    bool ok = true;
+    explicit Tmp(rsm_ctx *c_) : c(c_) {}
+    ~Tmp() {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    T *alloc(size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T) + 64) != hipSuccess) {
+            ok = false;
+            return nullptr;
+        }
+        ptrs.push_back(p);
+        return (T *)p;
+    }
+    template <typename T>
+    T *up(const T *h, size_t n) {
+        T *d = alloc<T>(n);
+        if (d && (hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                  hipStreamSynchronize(c->stream) != hipSuccess))
+            ok = false;
+        return d;
+    }
+    template <typename T>
+    void down(T *h, const T *d, size_t n) {
+        if (hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            ok = false;
+    }
+};
+int finish(rsm_ctx *c, Tmp &t) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return set_err(c, RSM_E_HIP, "stage failed: %s", hipGetErrorString(e));
+    if (!t.ok) return set_err(c, RSM_E_HIP, "stage alloc/copy failed");
+    return RSM_OK;
+}
+bool stage_ok(rsm_ctx *c, int W, int H) { return c && W > 0 && H > 0 && hipSetDevice(c->device) == hipSuccess; }
+} // namespace
+
+extern "C" int rsm_stage_find_margin(rsm_ctx *c, const uint8_t *mask, int W, int H, int r, rsm_boundary *m) {
+    if (!stage_ok(c, W, H) || !mask || !m) return RSM_E_INVALID;
+    Tmp t(c);
+    uint8_t *dm = t.up(mask, (size_t)W * H);
+    int *d4 = t.alloc<int>(4);
+    if (!t.ok) return finish(c, t);
+    launch_find_margin(dm, W, H, r, d4, c->stream);
+    int h[4];
+    t.down(h, d4, 4);
+    *m = to_boundary(Mg{h[2], h[3], h[0], h[1]});
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_pyr_down(rsm_ctx *c, const uint8_t *src, int W, int H, int ch, uint8_t *dst) {
+    if (!stage_ok(c, W, H) || !src || !dst || (ch != 1 && ch != 3)) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t nd = (size_t)((W + 1) / 2) * ((H + 1) / 2) * ch;
+    uint8_t *ds = t.up(src, (size_t)W * H * ch);
+    uint8_t *dd = t.alloc<uint8_t>(nd);
+    if (!t.ok) return finish(c, t);
+    launch_pyr_down(ds, W, H, ch, dd, c->stream);
+    t.down(dst, dd, nd);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_erode_ellipse(rsm_ctx *c, const uint8_t *mask, int W, int H, int ksize, uint8_t *dst) {
+    if (!stage_ok(c, W, H) || !mask || !dst || ksize < 1 || ksize > 4096) return RSM_E_INVALID;
+    Tmp t(c);
+    std::vector<int> j1, j2;
+    ellipse_spans(ksize, j1, j2);
+    uint8_t *dm = t.up(mask, (size_t)W * H);
+    int *d1 = t.up(j1.data(), (size_t)ksize), *d2 = t.up(j2.data(), (size_t)ksize);
+    int32_t *pre = t.alloc<int32_t>((size_t)(W + 1) * H);
+    uint8_t *dd = t.alloc<uint8_t>((size_t)W * H);
+    if (!t.ok) return finish(c, t);
+    launch_bad_prefix(dm, W, H, pre, c->stream);
+    launch_erode_binary(pre, W, H, ksize, d1, d2, dd, c->stream);
+    t.down(dst, dd, (size_t)W * H);
+    return finish(c, t);
+}
+
+namespace {
+// uploads the images/masks of one direction and builds the window-sum tables
+struct MatchBufs {
+    uint8_t *io, *it, *mo, *mt;
+    int32_t *S1o, *S2o, *S1t, *S2t;
+};
+bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_oth, const uint8_t *mask_own,
+                 const uint8_t *mask_oth, int W, int H, int r, MatchBufs &b) {
+    const size_t px = (size_t)W * H;
+    b.io = t.up(img_own, px * 3);
+    b.it = t.up(img_oth, px * 3);
+    b.mo = t.up(mask_own, px);
+    b.mt = t.up(mask_oth, px);
+    b.S1o = t.alloc<int32_t>(px);
+    b.S2o = t.alloc<int32_t>(px);
+    b.S1t = t.alloc<int32_t>(px);
+    b.S2t = t.alloc<int32_t>(px);
+    int32_t *t1 = t.alloc<int32_t>(px), *t2 = t.alloc<int32_t>(px);
+    if (!t.ok) return false;
+    launch_box_sums(b.io, W, H, r, t1, t2, b.S1o, b.S2o, c->stream);
+    launch_box_sums(b.it, W, H, r, t1, t2, b.S1t, b.S2t, c->stream);
+    return true;
+}
+StageArgs one_dir(int W, int H, int r, const rsm_boundary *own, const rsm_boundary *oth) {
+    StageArgs a{};
+    a.ndir = 1;
+    a.W = W;
+    a.H = H;
+    a.r = r;
+    a.d[0].own = to_mg(*own);
+    if (oth) a.d[0].oth = to_mg(*oth);
+    return a;
+}
+void bind_match(StageArgs &a, const MatchBufs &b) {
+    DirArgs &d = a.d[0];
+    d.img_own = b.io;
+    d.img_oth = b.it;
+    d.mask_own = b.mo;
+    d.mask_oth = b.mt;
+    d.S1_own = b.S1o;
+    d.S2_own = b.S2o;
+    d.S1_oth = b.S1t;
+    d.S2_oth = b.S2t;
+}
+} // namespace
+
+extern "C" int rsm_stage_initial_match(rsm_ctx *c, const uint8_t *img_own, const uint8_t *img_oth,
+                                       const uint8_t *mask_own, const uint8_t *mask_oth, int W, int H, int r,
+                                       int offset, const rsm_boundary *own, const rsm_boundary *oth,
+                                       const double *parent, int Wp, int Hp, int16_t *disp) {
+    if (!stage_ok(c, W, H) || !img_own || !img_oth || !mask_own || !mask_oth || !own || !oth || !disp) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    MatchBufs b{};
+    if (!setup_match(c, t, img_own, img_oth, mask_own, mask_oth, W, H, r, b)) return finish(c, t);
+    StageArgs a = one_dir(W, H, r, own, oth);
+    bind_match(a, b);
+    a.offset = offset;
+    a.Wp = Wp;
+    a.Hp = Hp;
+    int16_t *dd = t.alloc<int16_t>(px);
+    a.d[0].BL = t.alloc<int16_t>(px);
+    a.d[0].BR = t.alloc<int16_t>(px);
+    if (!t.ok) return finish(c, t);
+    launch_fill_i16(dd, px, (int16_t)NOMATCH, c->stream);
+    a.d[0].d16_in = a.d[0].d16_out = dd;
+    if (!parent) {
+        launch_ncc_argmax(a, 0, c->stream);
+    } else {
+        double *dp = t.up(parent, (size_t)Wp * Hp);
+        int32_t *nv = t.alloc<int32_t>((size_t)Wp * Hp);
+        if (!t.ok) return finish(c, t);
+        a.d[0].parent = dp;
+        a.d[0].parent_nv = nv;
+        launch_next_valid(dp, Wp, Hp, nv, c->stream);
+        launch_hl_interval(a, c->stream);
+        launch_ncc_argmax(a, 1, c->stream);
+    }
+    t.down(disp, dd, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_smooth(rsm_ctx *c, int16_t *disp, int W, int H, const rsm_boundary *own) {
+    if (!stage_ok(c, W, H) || !disp || !own) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    StageArgs a = one_dir(W, H, 0, own, nullptr);
+    a.d[0].d16_in = t.up(disp, px);
+    a.d[0].d16_out = t.alloc<int16_t>(px);
+    if (!t.ok) return finish(c, t);
+    launch_smooth(a, c->stream);
+    t.down(disp, a.d[0].d16_out, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_order(rsm_ctx *c, int16_t *disp, int W, int H, const rsm_boundary *own) {
+    if (!stage_ok(c, W, H) || !disp || !own) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    StageArgs a = one_dir(W, H, 0, own, nullptr);
+    a.d[0].d16_in = a.d[0].d16_out = t.up(disp, px);
+    if (!t.ok) return finish(c, t);
+    launch_order(a, c->stream);
+    t.down(disp, a.d[0].d16_in, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_uniqueness_pass_s16(rsm_ctx *c, int16_t *p, const int16_t *q, int W, int H,
+                                             const rsm_boundary *own, const rsm_boundary *oth) {
+    if (!stage_ok(c, W, H) || !p || !q || !own || !oth) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    int16_t *dp = t.up(p, px);
+    int16_t *dq = t.up(q, px);
+    if (!t.ok) return finish(c, t);
+    launch_uniq_s16(dp, dq, W, H, to_mg(*own), to_mg(*oth), c->stream);
+    t.down(p, dp, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_uniqueness_pass_f64(rsm_ctx *c, double *p, const double *q, int W, int H,
+                                             const rsm_boundary *own, const rsm_boundary *oth) {
+    if (!stage_ok(c, W, H) || !p || !q || !own || !oth) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    double *dp = t.up(p, px);
+    double *dq = t.up(q, px);
+    if (!t.ok) return finish(c, t);
+    launch_uniq_f64(dp, dq, W, H, to_mg(*own), to_mg(*oth), c->stream);
+    t.down(p, dp, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_set_boundary(rsm_ctx *c, const int16_t *disp, const uint8_t *mask_own, int W, int H,
+                                      const rsm_boundary *own, const rsm_boundary *oth, int16_t *BL, int16_t *BR) {
+    if (!stage_ok(c, W, H) || !disp || !mask_own || !own || !oth || !BL || !BR) return RSM_E_INVALID;
+    if (degenerate(to_mg(*own))) return set_err(c, RSM_E_DEGENERATE_MARGIN, "YL>=YR || XL>=XR");
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    StageArgs a = one_dir(W, H, 0, own, oth);
+    a.d[0].d16_in = t.up(disp, px);
+    a.d[0].mask_own = t.up(mask_own, px);
+    a.d[0].BL = t.alloc<int16_t>(px);
+    a.d[0].BR = t.alloc<int16_t>(px);
+    if (!t.ok) return finish(c, t);
+    launch_fill_i16(a.d[0].BL, px, (int16_t)-10000, c->stream);
+    launch_fill_i16(a.d[0].BR, px, (int16_t)10000, c->stream);
+    launch_set_boundary(a, c->stream);
+    t.down(BL, a.d[0].BL, px);
+    t.down(BR, a.d[0].BR, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_rematch(rsm_ctx *c, const uint8_t *img_own, const uint8_t *img_oth, const uint8_t *mask_own,
+                                 const uint8_t *mask_oth, int W, int H, int r, const rsm_boundary *own,
+                                 const rsm_boundary *oth, int16_t *disp) {
+    if (!stage_ok(c, W, H) || !img_own || !img_oth || !mask_own || !mask_oth || !own || !oth || !disp) return RSM_E_INVALID;
+    if (degenerate(to_mg(*own))) return set_err(c, RSM_E_DEGENERATE_MARGIN, "YL>=YR || XL>=XR");
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    MatchBufs b{};
+    if (!setup_match(c, t, img_own, img_oth, mask_own, mask_oth, W, H, r, b)) return finish(c, t);
+    StageArgs a = one_dir(W, H, r, own, oth);
+    bind_match(a, b);
+    a.d[0].d16_in = a.d[0].d16_out = t.up(disp, px);
+    a.d[0].BL = t.alloc<int16_t>(px);
+    a.d[0].BR = t.alloc<int16_t>(px);
+    if (!t.ok) return finish(c, t);
+    launch_set_boundary(a, c->stream);
+    launch_ncc_argmax(a, 2, c->stream);
+    t.down(disp, a.d[0].d16_in, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_median(rsm_ctx *c, int16_t *disp, const uint8_t *mask_own, int W, int H,
+                                const rsm_boundary *own) {
+    if (!stage_ok(c, W, H) || !disp || !mask_own || !own) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    StageArgs a = one_dir(W, H, 0, own, nullptr);
+    a.d[0].d16_in = t.up(disp, px);
+    a.d[0].mask_own = t.up(mask_own, px);
+    a.d[0].d16_out = t.alloc<int16_t>(px);
+    if (!t.ok) return finish(c, t);
+    launch_fill_i16(a.d[0].d16_out, px, (int16_t)NOMATCH, c->stream);
+    launch_median(a, c->stream);
+    t.down(disp, a.d[0].d16_out, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_t *img_own, const uint8_t *img_oth,
+                                int W, int H, int iterations, double ws, const rsm_boundary *own, double *disp_out) {
+    if (!stage_ok(c, W, H) || !disp_in || !img_own || !img_oth || !own || !disp_out || iterations < 0) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    StageArgs a = one_dir(W, H, 0, own, nullptr);
+    a.ws = ws;
+    DirArgs &d = a.d[0];
+    d.d16_in = t.up(disp_in, px);
+    d.img_own = t.up(img_own, px * 3);
+    d.img_oth = t.up(img_oth, px * 3);
+    double *A = t.alloc<double>(px), *B = t.alloc<double>(px);
+    d.rf_key = t.alloc<int32_t>(px);
+    d.rf_pwp = t.alloc<double>(px);
+    d.rf_delta = t.alloc<double>(px);
+    if (!t.ok) return finish(c, t);
+    d.f64_a = A;
+    d.f64_b = B;
+    launch_refine_init(a, c->stream);
+    for (int it = 0; it < iterations; it++) {
+        launch_refine_sweep(a, c->stream);
+        double *x = d.f64_a;
+        d.f64_a = d.f64_b;
+        d.f64_b = x;
+    }
+    t.down(disp_out, (const double *)d.f64_a, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_cloud(rsm_ctx *c, const double *disp, const uint8_t *mask_org, const uint8_t *img_own, int W,
+                               int H, const double *Q, double scale, const double *R_final, const double *T_final,
+                               const rsm_boundary *own, double *xyz, uint8_t *bgr, int64_t max_points,
+                               int64_t *n_points) {
+    if (!stage_ok(c, W, H) || !disp || !mask_org || !img_own || !Q || !R_final || !T_final || !own || !n_points)
+        return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    const int ksize = (int)ceil(0.02 * H);
+    if (ksize < 1 || ksize > 4096) return RSM_E_INVALID;
+    std::vector<int> j1, j2;
+    ellipse_spans(ksize, j1, j2);
+    double q[16];
+    memcpy(q, Q, sizeof q);
+    for (int i = 0; i < 4; i++) q[i * 4 + 3] *= scale;
+    double *dd = t.up(disp, px);
+    uint8_t *dm = t.up(mask_org, px);
+    uint8_t *di = t.up(img_own, px * 3);
+    int *d1 = t.up(j1.data(), (size_t)ksize), *d2 = t.up(j2.data(), (size_t)ksize);
+    double *dq = t.up(q, 16), *dR = t.up(R_final, 9), *dT = t.up(T_final, 3);
+    int32_t *pre = t.alloc<int32_t>((size_t)(W + 1) * H);
+    int32_t *rc = t.alloc<int32_t>((size_t)H);
+    int64_t *ro = t.alloc<int64_t>((size_t)H);
+    int64_t *dn = t.alloc<int64_t>(1);
+    const int64_t cap = max_points > 0 ? max_points : 0;
+    double *dx = (xyz && cap) ? t.alloc<double>((size_t)cap * 3) : nullptr;
+    uint8_t *db = (bgr && cap) ? t.alloc<uint8_t>((size_t)cap * 3) : nullptr;
+    if (!t.ok) return finish(c, t);
+    launch_bad_prefix(dm, W, H, pre, c->stream);
+    launch_cloud(dd, pre, di, W, H, ksize, d1, d2, dq, dR, dT, to_mg(*own), rc, ro, dn, dx, db, cap, c->stream);
+    int64_t n = 0;
+    t.down(&n, (const int64_t *)dn, 1);
+    *n_points = n;
+    const int64_t m = n < cap ? n : cap;
+    if (m > 0 && dx) t.down(xyz, (const double *)dx, (size_t)m * 3);
+    if (m > 0 && db) t.down(bgr, (const uint8_t *)db, (size_t)m * 3);
+    return finish(c, t);
+}
+
+// ---- NCC kernel microbenchmark --------------------------------------------------------------------
+extern "C" int rsm_bench_ncc(rsm_ctx *c, int W, int H, int r, int cands, int iters, double *ms_per_launch) {
+    if (!stage_ok(c, W, H) || r < 1 || r > 15 || cands < 1 || iters < 1 || !ms_per_launch) return RSM_E_INVALID;
+    if (W <= 2 * r + cands + 2 || H <= 2 * r + 2) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    std::vector<uint8_t> hi(px * 3), hm(px, 255);
+    uint32_t s = 12345u;
+    for (auto &v : hi) {
+        s = s * 1664525u + 1013904223u;
+        v = (uint8_t)(s >> 24);
+    }
+    MatchBufs b{};
+    if (!setup_match(c, t, hi.data(), hi.data(), hm.data(), hm.data(), W, H, r, b)) return finish(c, t);
+    rsm_boundary m{r, H - 1 - r, r, W - 1 - r, W - 2 * r, H - 2 * r};
+    StageArgs a = one_dir(W, H, r, &m, &m);
+    bind_match(a, b);
+    std::vector<int16_t> hl(px), hr(px);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int L = x - cands / 2, R = L + cands - 1;
+            if (L < r) { L = r; R = L + cands - 1; }
+            if (R > W - 1 - r) { R = W - 1 - r; L = R - cands + 1; }
+            hl[(size_t)y * W + x] = (int16_t)L;
+            hr[(size_t)y * W + x] = (int16_t)R;
+        }
+    a.d[0].BL = t.up(hl.data(), px);
+    a.d[0].BR = t.up(hr.data(), px);
+    int16_t *dd = t.alloc<int16_t>(px);
+    if (!t.ok) return finish(c, t);
+    a.d[0].d16_in = a.d[0].d16_out = dd;
+    launch_fill_i16(dd, px, (int16_t)NOMATCH, c->stream);
+    launch_ncc_argmax(a, 1, c->stream); // warm-up
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; i++) launch_ncc_argmax(a, 1, c->stream);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / iters;
+    return finish(c, t);
+}

@@ -1,0 +1,77 @@
+// rsm_dev.h -- internal declarations shared by the HIP translation units of librsm_mi355.so.
+// gfx950 (MI355X) only: wave = 64 lanes, no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NOMATCH (-10000) // reconstruction/CStereoMatching.h:9
+#define WAVE 64
+
+// Margin of one view at one level (struct Boundary, CManageData.h:10-14, without width/height).
+struct Mg {
+    int YL, YR, XL, XR;
+};
+
+// Everything one direction of one stage may need. Direction v: own view = v, other = 1-v
+// (IsZeroOne = (v == 0) in the reference's signatures).
+struct DirArgs {
+    const uint8_t *img_own, *img_oth;   // BGR interleaved, stride 3*W
+    const uint8_t *mask_own, *mask_oth; // stride W
+    const int32_t *S1_own, *S2_own;     // (2r+1)^2*3 window sums of bytes / squared bytes, centre-indexed
+    const int32_t *S1_oth, *S2_oth;
+    Mg own, oth;
+    int16_t *d16_in, *d16_out; // int16 disparity maps (in may alias out when the stage allows it)
+    int16_t *BL, *BR;          // candidate intervals (absolute columns)
+    const double *parent;      // fp64 disparity of level k-1 (this direction)
+    const int32_t *parent_nv;  // next-valid-column table of `parent`
+    double *f64_a, *f64_b;     // fp64 disparity ping-pong / uniqueness maps
+    int32_t *rf_key;           // refine cache: iMatch key
+    double *rf_pwp, *rf_delta; // refine cache: data-term weight and offset
+};
+
+struct StageArgs {
+    DirArgs d[2];
+    int ndir;    // 1 or 2 (gridDim.z)
+    int W, H;    // this level
+    int Wp, Hp;  // parent level
+    int r;       // MatchBlockRadius
+    int offset;  // m_offset
+    double ws;   // m_ws
+    int flag;    // stage-specific
+};
+
+// ---- launchers (each enqueues on `st`, no sync) ----------------------------------------------
+void launch_fill_i16(int16_t *p, size_t n, int16_t v, hipStream_t st);
+void launch_fill_f64(double *p, size_t n, double v, hipStream_t st);
+void launch_fill_i32(int32_t *p, size_t n, int32_t v, hipStream_t st);
+void launch_pyr_down(const uint8_t *src, int W, int H, int C, uint8_t *dst, hipStream_t st);
+// out4 = {XL, XR, YL, YR} initialised by the kernel launcher (inverted defaults, .cpp:1014-1017)
+void launch_find_margin(const uint8_t *mask, int W, int H, int r, int *out4, hipStream_t st);
+void launch_box_sums(const uint8_t *img, int W, int H, int r, int32_t *tmp1, int32_t *tmp2,
+                     int32_t *S1, int32_t *S2, hipStream_t st);
+
+void launch_next_valid(const double *parent, int Wp, int Hp, int32_t *nv, hipStream_t st);
+void launch_hl_interval(const StageArgs &a, hipStream_t st);
+// mode 0: lowest level (interval = other margin), 1: interval arrays BL/BR into NOMATCH-filled out,
+// 2: rematch (only pixels whose d16_in is NOMATCH; in place)
+void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st);
+
+void launch_smooth(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out
+void launch_order(const StageArgs &a, hipStream_t st);         // d16_in in place
+void launch_uniq_s16(int16_t *p, const int16_t *q, int W, int H, Mg own, Mg oth, hipStream_t st);
+void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, hipStream_t st);
+void launch_set_boundary(const StageArgs &a, hipStream_t st);  // d16_in, mask_own -> BL, BR
+void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out (pre-filled NOMATCH)
+void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
+void launch_refine_sweep(const StageArgs &a, hipStream_t st);  // f64_a -> f64_b
+
+// cloud: returns nothing; *d_npoints (device int64) receives the point count
+void launch_bad_prefix(const uint8_t *mask, int W, int H, int32_t *prefix, hipStream_t st);
+void launch_erode_binary(const int32_t *prefix, int W, int H, int ksize, const int *d_j1, const int *d_j2,
+                         uint8_t *dst255, hipStream_t st);
+void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *img, int W, int H, int ksize,
+                  const int *d_j1, const int *d_j2, const double *q16_scaled, const double *R,
+                  const double *T, Mg own, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints,
+                  double *xyz, uint8_t *bgr, int64_t max_points, hipStream_t st);
+void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long long *d_count, hipStream_t st);

@@ -1,0 +1,252 @@
+"""GPU parity: every HIP stage (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Integer / index stages must be bit-exact; fp64 stages (refine, cloud) within 1e-9 relative here
+(north_star's bar is 1e-3 relative; the exact-integer NCC and the device exp() differ from the
+oracle's fp64 NCC and libm exp() only at the 1e-15 level)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from reconstruction_amd import synth
+
+from helpers import NOMATCH, cloud_scale, diff_report, oracle_stages
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "s96x64_r2": dict(width=96, height=64, levels=2, radius=2, offset=2, pair=0),
+    "s128x96_r2_neg_holes": dict(width=128, height=96, levels=3, radius=2, offset=2, pair=1, holes=True,
+                                 mask_l0_width=20, border_l0=4),
+    "s160x96_r5_off4": dict(width=160, height=96, levels=2, radius=5, offset=4, pair=2, border_l0=7),
+    "s192x128_ellipse": dict(width=192, height=128, levels=3, radius=2, offset=2, pair=3, mask_kind="ellipse",
+                             holes=True),
+    "s640x256_r3_wide": dict(width=640, height=256, levels=2, radius=3, offset=2, pair=4, mask_l0_width=300,
+                             border_l0=9),
+    "s256x128_occluded": dict(width=256, height=128, levels=3, radius=2, offset=2, pair=5, occlude=True,
+                              mask_l0_width=48, border_l0=5),
+    "s320x160_occluded_neg_r4": dict(width=320, height=160, levels=2, radius=4, offset=3, pair=7, occlude=True,
+                                     holes=True, mask_l0_width=120, border_l0=6),
+}
+
+_cache = {}
+
+
+def stages(name):
+    if name not in _cache:
+        cfg = synth.config_small(**CASES[name])
+        rec, fin = oracle_stages(cfg)
+        _cache[name] = (cfg, rec, fin)
+    return _cache[name]
+
+
+def fp_close(a, b, rel=1e-9):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    na, nb = a == NOMATCH, b == NOMATCH
+    assert np.array_equal(na, nb), "NOMATCH sets differ: %d vs %d" % (na.sum(), nb.sum())
+    v = ~na
+    if v.any():
+        err = np.abs(a[v] - b[v]) / np.maximum(1.0, np.abs(b[v]))
+        assert err.max() <= rel, "max rel err %.3e" % err.max()
+        return float(err.max())
+    return 0.0
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_pyramid_and_margins(ctx, name):
+    cfg, rec, fin = stages(name)
+    N = cfg.pyr_levels
+    for k in range(N - 1, 0, -1):
+        for v in range(2):
+            g = ctx.pyr_down(fin["imgs"][k][v])
+            assert np.array_equal(g, fin["imgs"][k - 1][v]), diff_report("pyr_down img L%d" % k, g, fin["imgs"][k - 1][v])
+            g = ctx.pyr_down(fin["msks"][k][v])
+            assert np.array_equal(g, fin["msks"][k - 1][v]), diff_report("pyr_down mask L%d" % k, g, fin["msks"][k - 1][v])
+    for k in range(N):
+        for v in range(2):
+            assert ctx.find_margin(fin["msks"][k][v], cfg.radius).astuple() == orc.find_margin(fin["msks"][k][v], cfg.radius).astuple()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_integer_stages_bit_exact(ctx, name):
+    cfg, rec, fin = stages(name)
+    r, off = cfg.radius, cfg.offset
+    imgs, msks = fin["imgs"], fin["msks"]
+    fails = []
+    for q in rec:
+        k, st = q["level"], q["stage"]
+        mg = q["mg"]
+        tag = "%s L%d %s v%s" % (name, k, st, q.get("v"))
+        if st == "initial":
+            v = q["v"]; o = 1 - v
+            g = ctx.initial_match(imgs[k][v], imgs[k][o], msks[k][v], msks[k][o], r, off, mg[v], mg[o], q["parent"])
+            if not np.array_equal(g, q["out"]):
+                fails.append(diff_report(tag, g, q["out"]))
+        elif st == "smooth":
+            g = ctx.smooth_constraint(q["inp"], mg[q["v"]])
+            if not np.array_equal(g, q["out"]):
+                fails.append(diff_report(tag, g, q["out"]))
+        elif st == "order":
+            g = ctx.order_constraint(q["inp"], mg[q["v"]])
+            if not np.array_equal(g, q["out"]):
+                fails.append(diff_report(tag, g, q["out"]))
+        elif st == "uniq16":
+            g0, g1 = ctx.uniqueness(q["inp"][0], q["inp"][1], mg[0], mg[1])
+            if not np.array_equal(g0, q["out"][0]):
+                fails.append(diff_report(tag + " d0", g0, q["out"][0]))
+            if not np.array_equal(g1, q["out"][1]):
+                fails.append(diff_report(tag + " d1", g1, q["out"][1]))
+        elif st == "setb":
+            v = q["v"]; o = 1 - v
+            s, BL, BR = ctx.set_boundary_smooth(q["inp"], msks[k][v], mg[v], mg[o])
+            assert s == 0
+            # defined (and consumed by Rematch) only on masked pixels of the own margin
+            YL, YR, XL, XR = mg[v][:4]
+            sel = np.zeros(BL.shape, bool)
+            sel[YL:YR + 1, XL:XR + 1] = msks[k][v][YL:YR + 1, XL:XR + 1] == 255
+            if not np.array_equal(BL[sel], q["BL"][sel]):
+                fails.append(diff_report(tag + " BL", np.where(sel, BL, 0), np.where(sel, q["BL"], 0)))
+            if not np.array_equal(BR[sel], q["BR"][sel]):
+                fails.append(diff_report(tag + " BR", np.where(sel, BR, 0), np.where(sel, q["BR"], 0)))
+        elif st == "rematch":
+            v = q["v"]; o = 1 - v
+            s, g = ctx.rematch(imgs[k][v], imgs[k][o], msks[k][v], msks[k][o], r, mg[v], mg[o], q["inp"])
+            assert s == 0
+            if not np.array_equal(g, q["out"]):
+                fails.append(diff_report(tag, g, q["out"]))
+        elif st == "median":
+            g = ctx.median_filter(q["inp"], msks[k][q["v"]], mg[q["v"]])
+            if not np.array_equal(g, q["out"]):
+                fails.append(diff_report(tag, g, q["out"]))
+    assert not fails, "\n".join(fails[:12])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fp64_stages(ctx, name):
+    cfg, rec, fin = stages(name)
+    imgs, msks = fin["imgs"], fin["msks"]
+    worst = 0.0
+    for q in rec:
+        k, st = q["level"], q["stage"]
+        mg = q["mg"]
+        if st == "refine":
+            v = q["v"]
+            g = ctx.disparity_refine(q["inp"], imgs[k][v], imgs[k][1 - v], q["iters"], cfg.ws, mg[v])
+            worst = max(worst, fp_close(g, q["out"]))
+        elif st == "uniq64":
+            g0, g1 = ctx.uniqueness(q["inp"][0], q["inp"][1], mg[0], mg[1])
+            assert np.array_equal(g0, q["out"][0]), diff_report("uniq64 d0 L%d" % k, g0, q["out"][0])
+            assert np.array_equal(g1, q["out"][1]), diff_report("uniq64 d1 L%d" % k, g1, q["out"][1])
+    print("worst refine rel err", worst)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_cloud_and_erode(ctx, name):
+    cfg, rec, fin = stages(name)
+    k = cfg.pyr_levels - 1
+    mg = fin["margin"]
+    d0 = fin["disparity"][0]
+    scale = cloud_scale(cfg)
+    xo, bo = orc.disparity_to_cloud(d0, fin["msks"][k][0], fin["imgs"][k][0], cfg.Q, scale, cfg.R_final, cfg.T_final, mg[0])
+    xg, bg = ctx.disparity_to_cloud(d0, fin["msks"][k][0], fin["imgs"][k][0], cfg.Q, scale, cfg.R_final, cfg.T_final, mg[0])
+    assert xg.shape == xo.shape and len(xo) > 0
+    assert np.array_equal(bg, bo)
+    assert np.allclose(xg, xo, rtol=1e-12, atol=1e-9)
+    for ks in (3, 4, 7, 12):
+        e = orc.erode_ellipse(fin["msks"][k][0], ks)
+        g = ctx.erode_ellipse_is255(fin["msks"][k][0], ks)
+        assert np.array_equal(g == 255, e == 255), "erode ksize %d" % ks
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_full_pair_matches_oracle(ctx, name):
+    cfg, rec, fin = stages(name)
+    ref = orc.match_pair(cfg)
+    res = ctx.match_pair(cfg)
+    assert res.margin == ref["margin"]
+    assert res.v_top == ref["v_top"]
+    for v in range(2):
+        # same staged oracle as the C whole-pair oracle
+        assert np.array_equal(ref["disparity"][v], fin["disparity"][v])
+        fp_close(res.disparity[v], ref["disparity"][v], rel=1e-9)
+    assert res.n_points == ref["n_points"]
+    assert np.array_equal(res.bgr, ref["bgr"])
+    rel = np.abs(res.xyz - ref["xyz"]) / np.maximum(1e-9, np.abs(ref["xyz"]))
+    assert rel.max() < 1e-3  # north_star tolerance
+    assert np.allclose(res.xyz, ref["xyz"], rtol=1e-9, atol=1e-7)
+
+
+def test_run_is_deterministic_and_reusable(ctx):
+    cfg = synth.config_small(**CASES["s128x96_r2_neg_holes"])
+    a = ctx.match_pair(cfg)
+    cfg2 = synth.config_small(**CASES["s96x64_r2"])
+    ctx.match_pair(cfg2)  # different size in between: workspace is re-created
+    b = ctx.match_pair(cfg)
+    for v in range(2):
+        assert np.array_equal(a.disparity[v], b.disparity[v])
+    assert np.array_equal(a.xyz, b.xyz)
+
+
+def test_degenerate_margin_is_an_error_not_exit(ctx):
+    from reconstruction_amd import RsmError
+    cfg = synth.config_small(**CASES["s96x64_r2"])
+    cfg.mask = [np.zeros_like(cfg.mask[0]), np.zeros_like(cfg.mask[1])]
+    with pytest.raises(RsmError) as e:
+        ctx.match_pair(cfg)
+    assert e.value.code == -2
+
+
+# ---- adversarial stage inputs: random maps, far from what the pipeline would produce ----------------
+def _rand_maps(seed, H=72, W=200, p_nomatch=0.3, lo=-4, hi=5):
+    rng = np.random.default_rng(seed)
+    d = rng.integers(lo, hi, size=(H, W)).astype(np.int16)
+    d[rng.random((H, W)) < p_nomatch] = NOMATCH
+    mask = np.where(rng.random((H, W)) < 0.85, 255, rng.integers(0, 255, size=(H, W))).astype(np.uint8)
+    return d, mask
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_inputs_constraint_stages(ctx, seed):
+    rng = np.random.default_rng(100 + seed)
+    H, W = 72, 200 + 7 * seed
+    d0, m0 = _rand_maps(seed, H, W, p_nomatch=0.15 * seed)
+    d1, m1 = _rand_maps(50 + seed, H, W, p_nomatch=0.2)
+    r = 2
+    XL = int(rng.integers(r, 12)); XR = W - 1 - int(rng.integers(r, 12))
+    own = (r + seed, H - 1 - r - seed, XL, XR, XR - XL + 1, H - 2 * (r + seed))
+    oth = (r, H - 1 - r, XL + 3, XR - 5, XR - XL - 7, H - 2 * r)
+    for nm, fo, fg in [("smooth", orc.smooth_constraint, ctx.smooth_constraint),
+                       ("order", orc.order_constraint, ctx.order_constraint)]:
+        a, b = fg(d0, own), fo(d0, own)
+        assert np.array_equal(a, b), diff_report("%s seed %d" % (nm, seed), a, b)
+    a, b = ctx.median_filter(d0, m0, own), orc.median_filter(d0, m0, own)
+    assert np.array_equal(a, b), diff_report("median", a, b)
+    # uniqueness: disparities that actually point at each other some of the time
+    p = d0.copy(); q = d1.copy()
+    ys, xs = np.nonzero(p != NOMATCH)
+    for y, x in list(zip(ys, xs))[::3]:
+        t = x + int(p[y, x])
+        if 0 <= t < W:
+            q[y, t] = -p[y, x] + int(rng.integers(-2, 3))
+    a, b = ctx.uniqueness_pass(p, q, own, oth), orc.uniqueness_pass(p, q, own, oth)
+    assert np.array_equal(a, b), diff_report("uniq16 pass", a, b)
+    pf = np.where(p == NOMATCH, float(NOMATCH), p + rng.normal(0, 0.4, p.shape))
+    qf = np.where(q == NOMATCH, float(NOMATCH), q + rng.normal(0, 0.4, q.shape))
+    a, b = ctx.uniqueness_pass(pf, qf, own, oth), orc.uniqueness_pass(pf, qf, own, oth)
+    assert np.array_equal(a, b), diff_report("uniq64 pass", a, b)
+    s1, BLg, BRg = ctx.set_boundary_smooth(d0, m0, own, oth)
+    s2, BLo, BRo = orc.set_boundary_smooth(d0, m0, own, oth)
+    assert s1 == s2 == 0
+    sel = np.zeros((H, W), bool)
+    sel[own[0]:own[1] + 1, own[2]:own[3] + 1] = m0[own[0]:own[1] + 1, own[2]:own[3] + 1] == 255
+    assert np.array_equal(BLg[sel], BLo[sel]), diff_report("BL", np.where(sel, BLg, 0), np.where(sel, BLo, 0))
+    assert np.array_equal(BRg[sel], BRo[sel]), diff_report("BR", np.where(sel, BRg, 0), np.where(sel, BRo, 0))
+
+
+def test_order_constraint_heavy_crossings(ctx):
+    rng = np.random.default_rng(7)
+    H, W = 40, 300
+    d = rng.integers(-30, 31, size=(H, W)).astype(np.int16)   # lots of crossings and ties
+    d[rng.random((H, W)) < 0.5] = NOMATCH
+    own = (2, H - 3, 2, W - 3, W - 4, H - 4)
+    a, b = ctx.order_constraint(d, own), orc.order_constraint(d, own)
+    assert np.array_equal(a, b), diff_report("order heavy", a, b)
