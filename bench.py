@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py -- Mdisparities/s of the CStereoMatching hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (ConstructPyrm -> MatchOneLayer x PyrmNum, both directions ->
+DisparityToCloud) over one stereo pair per GPU, inputs already resident in HBM, followed (N > 1) by
+the RCCL fan-in gather of the per-pair clouds to rank 0.  Workload at every N: BASELINE.json
+configs[1] = C2 (4096x3072, 5 levels, 11x11 NCC, 128 disparities at the lowest level), one
+differently-seeded pair per rank (weak scaling).
+
+metric value = sum over ranks of V_top (masked view-0 top-level pixels inside the margin) per step
+             / (max-over-ranks wall time per step) / 1e6.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=["c2", "c2s", "c1", "c3", "c5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ncc-bench", action="store_true", help="also report the NCC kernel MDE/s microbenchmark")
+    args = ap.parse_args()
+
+    from reconstruction_amd import Context, synth
+    from reconstruction_amd.dist import gather_clouds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    make = {"c2": synth.config_c2, "c2s": synth.config_c2_sample, "c1": synth.config_c1,
+            "c3": synth.config_c3, "c5": synth.config_c5}[args.config]
+    cfg = make(pair=rank)  # a differently-seeded pair per rank
+    ctx = Context(local_rank)
+    # inputs -> HBM once, outside the timed region (torch owns the staging tensors: plumbing)
+    dev = torch.device("cuda", local_rank)
+    t_img = [torch.from_numpy(np.ascontiguousarray(cfg.image[v])).to(dev) for v in range(2)]
+    t_msk = [torch.from_numpy(np.ascontiguousarray(cfg.mask[v])).to(dev) for v in range(2)]
+    torch.cuda.synchronize()
+    ctx.upload_pair_device(cfg, [t.data_ptr() for t in t_img], [t.data_ptr() for t in t_msk])
+
+    def step():
+        ctx.run_pair()  # host-synchronous
+        if world > 1:
+            n = ctx.n_points
+            xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
+            bgr = torch.empty((n, 3), dtype=torch.uint8, device=dev)
+            ctx.export_cloud_device(xyz.data_ptr(), bgr.data_ptr(), n)
+            return gather_clouds([(rank, xyz, bgr)], dst=0)
+        return None
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.profile_enable(True)
+    prof_acc = {}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in ctx.profile_get().items():
+            a = prof_acc.setdefault(k, {"ms": 0.0, "launches": 0, "bytes": 0.0})
+            a["ms"] += v["ms"]; a["launches"] += v["launches"]; a["bytes"] += v["bytes"]
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+
+    res = ctx.download_pair(want_cloud=False, want_disparity=False)
+    v_top = res.v_top
+    if world > 1:
+        t = torch.tensor([dt, float(v_top)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        v_total = float(tsum[1])
+    else:
+        v_total = float(v_top)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = v_total / (dt / args.steps) / 1e6
+        # ---- roofline of the dominant kernel: the top level's Jacobi sweep (k_refine_sweep<1>)
+        top = prof_acc["refine_sweep_top"]
+        launches = max(1, top["launches"])
+        avg_ms = top["ms"] / launches
+        bytes_per_launch = top["bytes"] / launches  # 16 B x 2 directions x P_top
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        stage_ms = {k: round(v["ms"] / args.steps, 3) for k, v in prof_acc.items()}
+        total_alg_bytes = sum(v["bytes"] for v in prof_acc.values()) / args.steps
+        out = {
+            "metric": "Mdisparities/s per GPU (11x11 NCC, 128 disp)" if args.config == "c2" else "Mdisparities/s",
+            "value": round(value, 3), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg.name, "width": cfg.width, "height": cfg.height, "pyr_levels": cfg.pyr_levels,
+                       "ncc_window": 2 * cfg.radius + 1, "offset": cfg.offset, "pairs_per_gpu": 1,
+                       "v_top_per_pair": int(v_top), "n_points_last": int(res.n_points),
+                       "parallelism": "pairs sharded 1/GPU + RCCL fan-in gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_refine_sweep<1> (DisparityRefine Jacobi sweep, top level)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches // args.steps,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "whole_pair_algorithmic_GB": round(total_alg_bytes / 1e9, 3),
+                         "whole_pair_frac": round(total_alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+            "stage_ms_per_step": stage_ms,
+        }
+        if args.ncc_bench:
+            k = cfg.pyr_levels - 1
+            ms = ctx.bench_ncc(cfg.width, cfg.height, cfg.radius, 129, iters=3)
+            px = (cfg.width - 2 * cfg.radius) * (cfg.height - 2 * cfg.radius)
+            out["ncc_kernel"] = {"cands": 129, "ms_per_launch": round(ms, 3), "MDE_per_s": round(px * 129 / ms / 1e3, 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(synth)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(synth):
+    """The CPU oracle (a port of the reference's algorithm, OpenMP row loops) on a bounded sample of the
+    same workload, on this box's host cores."""
+    from oracle import oracle as orc
+    cores = orc.effective_cpus()
+    cfg = synth.config_c2_sample(pair=0)
+    t0 = time.perf_counter()
+    r = orc.match_pair(cfg, want_cloud=True, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(r["v_top"] / dt / 1e6, 5), "unit": "Mdisparities/s", "cores": cores, "kind": "port",
+            "sample": "%s: one pair, 5 levels, 11x11 NCC, offset 2, 9/64 of C2's area, %d masked pixels, %.1f s "
+                      "(refine %.1f s, NCC match %.1f s)" % (cfg.name, r["v_top"], dt, r["refine_seconds"], r["match_seconds"])}
+
+
+if __name__ == "__main__":
+    main()

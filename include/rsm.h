@@ -100,6 +100,10 @@ int rsm_download_pair(rsm_ctx *ctx, rsm_pair_out *out);
 int rsm_result_device(rsm_ctx *ctx, const double **disparity0, const double **disparity1,
                       int64_t *n_points, const double **xyz, const uint8_t **bgr);
 
+/* Copies the cloud of the last run device-to-device into caller-owned device buffers (e.g. the
+ * buffers an RCCL gather sends from): up to max_points points, xyz fp64 x3 and/or bgr u8 x3. */
+int rsm_export_cloud_device(rsm_ctx *ctx, double *d_xyz, uint8_t *d_bgr, int64_t max_points);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Per-stage device time of the last rsm_run_pair, measured with hipEvents on the ctx stream.
  * Enable before the run. Stage names: rsm_profile_stage_name(i), i < rsm_profile_stage_count(). */

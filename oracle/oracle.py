@@ -50,13 +50,36 @@ def build(force: bool = False) -> str:
     return so
 
 
+def effective_cpus() -> int:
+    """Cores this process may really use: min(affinity mask, cgroup cpu quota).  On the GPU box nproc
+    reports 256 while the cgroup grants 16 -- 256 spinning OpenMP threads on 16 cores is ~2000x slower."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _lib = C.CDLL(build())
+        _lib.orc_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", 0)) or effective_cpus())
         _lib.orc_window_to_vec.restype = C.c_double
         _lib.orc_arma_dot.restype = C.c_double
         _lib.orc_arma_mean.restype = C.c_double

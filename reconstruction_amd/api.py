@@ -152,6 +152,15 @@ class Context:
         self._chk(self._lib.rsm_result_device(self._h, C.byref(d0), C.byref(d1), C.byref(n), C.byref(xyz), C.byref(bgr)))
         return d0.value, d1.value, int(n.value), xyz.value, bgr.value
 
+    def export_cloud_device(self, xyz_ptr, bgr_ptr, max_points):
+        """D2D copy of the last cloud into caller-owned device buffers (addresses, e.g. tensor.data_ptr())."""
+        self._chk(self._lib.rsm_export_cloud_device(self._h, C.c_void_p(xyz_ptr or None), C.c_void_p(bgr_ptr or None),
+                                                    C.c_int64(max_points)))
+
+    @property
+    def n_points(self):
+        return self.result_device()[2]
+
     # ---- measurement -----------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self._lib.rsm_profile_enable(self._h, int(bool(on))))

@@ -8,13 +8,22 @@
 // (pwp, pdp - dCenter) depend only on (x, y, iMatch), not on the sweep: they are cached per pixel
 // keyed by iMatch and recomputed only when int(dCenter - 1.5) changes -- the same fp64 expression
 // tree is evaluated either way, so the sweep result is bit-identical to recomputing every time.
-// NCC itself is exact integer: ncc = (27*Sab - Sa*Sb) / sqrt((27*Saa - Sa^2)(27*Sbb - Sb^2)),
-// zero variance -> 0 (the reference's normu == 0 ? 1 path, CManageData.cpp:88-89).
+// The three NCC values are computed on a cache miss only, as a bit-faithful fp64 restatement of the
+// reference's WindowToVec + arma::dot (see the comment in the kernel).
 // Right-window reads have no bounds check in the reference (.cpp:628): emulated on the flat
 // row-major buffer, bytes outside the whole image read 0 (same rule as oracle/stereo_oracle.c).
 #include "rsm_dev.h"
 
 #include <limits.h>
+
+// exp(-n), n = 0..127, as glibc rounds them: in sweep 1 every state is an integer, so the smoothness weights are
+// exp(-k^2) and must equal the CPU libm's to keep the first (ill-conditioned) sweeps bit-identical.
+__constant__ double kExpNegInt[128] = {0x1.0000000000000p+0, 0x1.78b56362cef38p-2, 0x1.152aaa3bf81ccp-3, 0x1.97db0ccceb0afp-5, 0x1.2c155b8213cf4p-6, 0x1.b993fe00d5376p-8, 0x1.44e51f113d4d6p-9, 0x1.de16b9c24a98fp-11, 0x1.5fc21041027adp-12, 0x1.02cf22526545ap-13, 0x1.7cd79b5647c9bp-15, 0x1.18354238f6764p-16, 0x1.9c54c3b43bc8bp-18, 0x1.2f6053b981d98p-19, 0x1.be6c6fdb01612p-21, 0x1.4875ca227ec38p-22, 0x1.e355bbaee85cbp-24, 0x1.639e3175a689dp-25, 0x1.05a628c699fa1p-26, 0x1.81056ff2c5772p-28, 0x1.1b48655f37267p-29, 0x1.a0db0d0ddb3ecp-31, 0x1.32b48bf117da2p-32, 0x1.c3527e433fab1p-34, 0x1.4c1078fe9228ap-35, 0x1.e8a37a45fc32ep-37, 0x1.67852a7007e42p-38, 0x1.0885298767e9ap-39, 0x1.853f01d6d53bap-41, 0x1.1e642baeb84a0p-42, 0x1.a56e0c2ac7f75p-44, 0x1.36121e24d3bbap-45, 0x1.c8464f7616468p-47, 0x1.4fb547c775da8p-48, 0x1.ee001eed62aa0p-50, 0x1.6b7719a59f0e0p-51, 0x1.0b6c3afdde064p-52, 0x1.898471fca6055p-54, 0x1.2188ad6ae3303p-55, 0x1.aa0de4bf35b38p-57, 0x1.39792499b1a24p-58, 0x1.cd480a1b74820p-60, 0x1.536452ee2f75cp-61, 0x1.f36bd37f42f3ep-63, 0x1.6f741de1748ecp-64, 0x1.0e5b73d1ff53dp-65, 0x1.8dd5e1bb09d7ep-67, 0x1.24b6031b49bdap-68, 0x1.aebabae3a41b5p-70, 0x1.3ce9b9de78f85p-71, 0x1.d257d547e083fp-73, 0x1.571db733a9d61p-74, 0x1.f8e6c24b5592ep-76, 0x1.737c5645114b5p-77, 0x1.1152eaeb73c08p-78, 0x1.923372c67a074p-80, 0x1.27ec458c65e3cp-81, 0x1.b374b315f87c1p-83, 0x1.4063f8cc8bb98p-84, 0x1.d775d87da854dp-86, 0x1.5ae191a99585ap-87, 0x1.fe7116182e9ccp-89, 0x1.778fe2497184cp-90, 0x1.1452b7723aed2p-91, 0x1.969d47321e4ccp-93, 0x1.2b2b8dd05b318p-94, 0x1.b83bf23a9a9ebp-96, 0x1.43e7fc88b8056p-97, 0x1.dca23bae16424p-99, 0x1.5eafffb34ba31p-100, 0x1.02057d1245cebp-101, 0x1.7baee1bffa80bp-103, 0x1.175af0cf60ec5p-104, 0x1.9b138170d6bfep-106, 0x1.2e73f53fba844p-107, 0x1.bd109d9d94bdap-109, 0x1.4775e0840bfddp-110, 0x1.e1dd273aa8a4ap-112, 0x1.62891f06b3450p-113, 0x1.04da4d1452919p-114, 0x1.7fd974d372e45p-116, 0x1.1a6baeadb4fd1p-117, 0x1.9f96445648b9fp-119, 0x1.31c5957a47de2p-120, 0x1.c1f2daf3b6a46p-122, 0x1.4b0dc07cabf98p-123, 0x1.e726c3f64d0fep-125, 0x1.666d0dad2961dp-126, 0x1.07b7112bc1ffep-127, 0x1.840fbc08fdc8ap-129, 0x1.1d8508fa8246ap-130, 0x1.a425b317eeacdp-132, 0x1.35208867c2683p-133, 0x1.c6e2d05bbc000p-135, 0x1.4eafb87eab0f2p-136, 0x1.ec7f3b269efa8p-138, 0x1.6a5bea046b42ep-139, 0x1.0a9bdfb02d240p-140, 0x1.8851d84118908p-142, 0x1.20a717e64a9bdp-143, 0x1.a8c1f14e2af5dp-145, 0x1.3884e838aea68p-146, 0x1.cbe0a45f75eb1p-148, 0x1.525be4e4e601dp-149, 0x1.f1e6b68529e33p-151, 0x1.6e55d2bf838a7p-152, 0x1.0d88cf37f00ddp-153, 0x1.8c9feab89b876p-155, 0x1.23d1f3e5834a0p-156, 0x1.ad6b22f55db42p-158, 0x1.3bf2cf6722e46p-159, 0x1.d0ec7df4f7bd4p-161, 0x1.56126259e093cp-162, 0x1.f75d6040aeff6p-164, 0x1.725ae6e7b9d35p-165, 0x1.107df698da211p-166, 0x1.90fa1509bd50dp-168, 0x1.2705b5b153fb8p-169, 0x1.b2216c6efdac1p-171, 0x1.3f6a58b795de3p-172, 0x1.d606847fc727ap-174, 0x1.59d34dd8a5473p-175, 0x1.fce362fe6e7d0p-177, 0x1.766b45dd84f18p-178, 0x1.137b6ce8e052cp-179, 0x1.9560792d19314p-181, 0x1.2a42764857b19p-182, 0x1.b6e4f282b43f4p-184};
+
+__device__ __forceinline__ double exp_neg(double t) { // exp(-t), t >= 0
+    if (t < 128.0 && t == (double)(int)t) return kExpNegInt[(int)t];
+    return exp(-t);
+}
 
 __global__ void k_refine_init(StageArgs a) {
     const DirArgs &d = a.d[blockIdx.z];
@@ -62,46 +71,62 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         pwp = d.rf_pwp[pix];
         delta = d.rf_delta[pix];
     } else {
+        // Bit-faithful fp64 restatement of CManageData::WindowToVec (CManageData.cpp:81-90) + arma::dot on
+        // the 27-element windows, same gather order (byte column outer, row inner) and the same
+        // two-accumulator sums as Armadillo (op_dot_meat.hpp:20-55, fn_norm.hpp:99-130): the sweep is
+        // ill-conditioned at int(d - 1.5) boundaries, so xi must match the reference to the last bit.
         const uint8_t *A = d.img_own, *B = d.img_oth;
         const long long total = (long long)W * H * 3;
         const int rowB = W * 3;
-        int Sa = 0, Saa = 0;
-        int Sb[3] = {0, 0, 0}, Sbb[3] = {0, 0, 0}, Sab[3] = {0, 0, 0};
+        int aw[27], bw[3][15];
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             const uint8_t *pa = A + (size_t)(y - 1 + j) * rowB + (size_t)(x - 1) * 3;
             const long long bbase = (long long)(y - 1 + j) * rowB + (long long)key * 3;
-            int bb[15];
+#pragma unroll
+            for (int i = 0; i < 9; i++) aw[i * 3 + j] = pa[i];
 #pragma unroll
             for (int i = 0; i < 15; i++) {
                 const long long fi = bbase + i;
-                bb[i] = (fi >= 0 && fi < total) ? (int)B[fi] : 0;
+                bw[j][i] = (fi >= 0 && fi < total) ? (int)B[fi] : 0;
             }
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const int av = pa[i];
-                Sa += av;
-                Saa += av * av;
-#pragma unroll
-                for (int c = 0; c < 3; c++) Sab[c] += av * bb[i + 3 * c];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-#pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    const int bv = bb[i + 3 * c];
-                    Sb[c] += bv;
-                    Sbb[c] += bv * bv;
-                }
         }
-        const int va = 27 * Saa - Sa * Sa;
+        int SL = 0;
+#pragma unroll
+        for (int k = 0; k < 27; k++) SL += aw[k];
+        const double meanL = (double)SL / 27.0; // accumulate() of integers is exact; one rounding in the divide
+        double uL[27];
+        double n1 = 0.0, n2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            uL[k] = (double)aw[k] - meanL;
+            if (k & 1) n2 += uL[k] * uL[k];
+            else n1 += uL[k] * uL[k];
+        }
+        double normL = sqrt(n1 + n2);
+        if (normL == 0) normL = 1; // CManageData.cpp:89
         double xi[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int vb = 27 * Sbb[c] - Sb[c] * Sb[c];
-            const int num = 27 * Sab[c] - Sa * Sb[c];
-            double ncc = 0.0;
-            if (va > 0 && vb > 0) ncc = (double)num / sqrt((double)va * (double)vb);
-            xi[c] = (1 - ncc) / 2; // .cpp:629
+            int SR = 0;
+#pragma unroll
+            for (int k = 0; k < 27; k++) SR += bw[k % 3][k / 3 + 3 * c];
+            const double meanR = (double)SR / 27.0;
+            double m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                const double ur = (double)bw[k % 3][k / 3 + 3 * c] - meanR;
+                if (k & 1) {
+                    m2 += ur * ur;
+                    d2 += uL[k] * ur;
+                } else {
+                    m1 += ur * ur;
+                    d1 += uL[k] * ur;
+                }
+            }
+            double normR = sqrt(m1 + m2);
+            if (normR == 0) normR = 1;
+            xi[c] = (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
         }
         int index = xi[0] >= xi[1]; // .cpp:631-632
         if (xi[index] > xi[2]) index = 2;
@@ -130,8 +155,8 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     } else {
         const double ex = fabs(dE - dC) - fabs(dW - dC);
         const double ey = fabs(dS - dC) - fabs(dN - dC);
-        const double wx = exp(-(ex * ex)); // .cpp:665-666
-        const double wy = exp(-(ey * ey));
+        const double wx = exp_neg(ex * ex); // .cpp:665-666
+        const double wy = exp_neg(ey * ey);
         double ds;
         if (wx + wy == 0) ds = (dE + dW + dS + dN) / 4;
         else ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));

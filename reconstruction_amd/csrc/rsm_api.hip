@@ -580,6 +580,18 @@ extern "C" int rsm_result_device(rsm_ctx *c, const double **d0, const double **d
     return RSM_OK;
 }
 
+extern "C" int rsm_export_cloud_device(rsm_ctx *c, double *d_xyz, uint8_t *d_bgr, int64_t max_points) {
+    if (!c) return RSM_E_INVALID;
+    if (!c->have_result) return set_err(c, RSM_E_STATE, "no result");
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t n = c->n_points < max_points ? c->n_points : max_points;
+    if (n > (int64_t)c->cap_px) n = (int64_t)c->cap_px;
+    if (n > 0 && d_xyz) HIPCHK(c, hipMemcpyAsync(d_xyz, c->xyz, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (n > 0 && d_bgr) HIPCHK(c, hipMemcpyAsync(d_bgr, c->bgr, (size_t)n * 3, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RSM_OK;
+}
+
 extern "C" int rsm_match_pair(rsm_ctx *c, const rsm_pair_in *in, rsm_pair_out *out) {
     int s = rsm_upload_pair(c, in);
     if (s != RSM_OK) return s;
