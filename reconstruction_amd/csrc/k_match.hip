@@ -12,6 +12,8 @@
 // in ascending column order, exactly as the reference.
 #include "rsm_dev.h"
 
+#include <stdlib.h>
+
 // ---------------------------------------------------------------- next valid parent column
 // nv[row][t] = smallest i > t with parent[row][i] != NOMATCH, or INT_MAX. One wave per parent row.
 __global__ void k_next_valid(const double *__restrict__ parent, int Wp, int Hp, int32_t *__restrict__ nv) {
@@ -102,7 +104,8 @@ void launch_hl_interval(const StageArgs &a, hipStream_t st) {
 #define NCC_TX 256  // pixels of one row per block
 #define NCC_CH 512  // candidate columns staged per pass
 
-__global__ __launch_bounds__(NCC_TX) void k_ncc_argmax(StageArgs a, int mode, int strideA, int strideB) {
+// Generic-radius fallback (byte-wise LDS reads); radii 1..7 use k_ncc_dot4 below.
+__global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int strideA, int strideB) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int *s_lohi = (int *)smem;  // [0]=min L, [1]=max R over the block
     uint8_t *sA = smem + 16;
@@ -219,6 +222,185 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_argmax(StageArgs a, int mode, in
     if (active && best != -1) d.d16_out[pix] = (int16_t)(best - x); // .cpp:219-222 / 301-302 / 563-564
 }
 
+// ---------------------------------------------------------------- NCC interval argmax, v_dot4_u32_u8
+// Same decomposition (one row x 256 pixels per workgroup, both views' rows staged in LDS), but:
+//  * the pixel's own (2R+1) x 3(2R+1)-byte window lives in registers as dwords aligned to the window
+//    start (v_alignbyte_b32 once per pixel), bytes past the window masked to 0;
+//  * per candidate and window row the other view's bytes come from LDS as NA+1 aligned dwords,
+//    re-aligned with v_alignbyte_b32 and accumulated 4 MACs at a time with v_dot4_u32_u8;
+//  * mask / S1 / S2 of the candidate columns are staged in LDS next to the rows.
+template <int R>
+__global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode, int strideA, int strideB) {
+    constexpr int WS = 2 * R + 1, WB = 3 * WS, NA = (WB + 3) / 4, LASTV = WB - 4 * (NA - 1);
+    constexpr uint32_t LASTMASK = (LASTV == 4) ? 0xffffffffu : ((1u << (8 * LASTV)) - 1u);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int *s_lohi = (int *)smem;
+    uint32_t *sA = (uint32_t *)(smem + 16);
+    uint32_t *sB = sA + (size_t)WS * (strideA >> 2);
+    int32_t *sS1 = (int32_t *)(sB + (size_t)WS * (strideB >> 2));
+    int32_t *sS2 = sS1 + NCC_CH;
+    uint8_t *sM = (uint8_t *)(sS2 + NCC_CH);
+    const DirArgs &d = a.d[blockIdx.z];
+    const int W = a.W;
+    constexpr int n = WS * WS * 3;
+    const int y = d.own.YL + blockIdx.y;
+    const int x0 = d.own.XL + blockIdx.x * NCC_TX;
+    if (y > d.own.YR || x0 > d.own.XR) return;
+    const int x = x0 + threadIdx.x;
+    const size_t pix = (size_t)y * W + x;
+
+    bool active = (x <= d.own.XR) && (d.mask_own[pix] == 255);
+    if (mode == 2 && active) active = (d.d16_in[pix] == NOMATCH);
+    int L = 0x7fffffff, Rr = -1;
+    if (active) {
+        if (mode == 0) {
+            L = d.oth.XL;
+            Rr = d.oth.XR;
+        } else {
+            L = d.BL[pix];
+            Rr = d.BR[pix];
+        }
+        L = max(L, R);
+        Rr = min(Rr, W - 1 - R);
+        if (L > Rr) active = false;
+    }
+    if (threadIdx.x == 0) {
+        s_lohi[0] = 0x7fffffff;
+        s_lohi[1] = -1;
+    }
+    __syncthreads();
+    {
+        int lo = active ? L : 0x7fffffff, hi = active ? Rr : -1;
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&s_lohi[0], lo);
+            atomicMax(&s_lohi[1], hi);
+        }
+    }
+    __syncthreads();
+    const int cmin = s_lohi[0], cmax = s_lohi[1];
+    if (cmax < cmin) return;
+
+    const int rowBytes = W * 3;
+    // ---- stage own-view rows: LDS byte i of row j <-> image byte column baseA + i
+    const int baseA = (3 * (x0 - R)) & ~3;
+    {
+        const int nd = strideA >> 2;
+        for (int j = 0; j < WS; j++) {
+            const uint8_t *src = d.img_own + (size_t)(y - R + j) * rowBytes;
+            for (int i = threadIdx.x; i < nd; i += NCC_TX) {
+                const int b = baseA + 4 * i;
+                uint32_t v = 0;
+                if (b + 3 < rowBytes) __builtin_memcpy(&v, src + b, 4);
+                else
+                    for (int k = 0; k < 4; k++)
+                        if (b + k < rowBytes) v |= (uint32_t)src[b + k] << (8 * k);
+                sA[j * nd + i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- own window -> registers
+    uint32_t Areg[WS][NA];
+    int Sa = 0, Saa = 0;
+    long long va = 0;
+    if (active) {
+        const int oa = 3 * (x - R) - baseA;
+        const int wa = oa >> 2, sh = oa & 3;
+        const int nd = strideA >> 2;
+#pragma unroll
+        for (int j = 0; j < WS; j++) {
+            uint32_t raw[NA + 1];
+#pragma unroll
+            for (int m = 0; m <= NA; m++) raw[m] = sA[j * nd + wa + m];
+#pragma unroll
+            for (int m = 0; m < NA; m++) Areg[j][m] = __builtin_amdgcn_alignbyte(raw[m + 1], raw[m], sh);
+            Areg[j][NA - 1] &= LASTMASK;
+        }
+        Sa = d.S1_own[pix];
+        Saa = d.S2_own[pix];
+        va = (long long)n * Saa - (long long)Sa * Sa;
+    } else {
+#pragma unroll
+        for (int j = 0; j < WS; j++)
+#pragma unroll
+            for (int m = 0; m < NA; m++) Areg[j][m] = 0;
+    }
+    int best = -1;
+    double bestv = -1.0;
+
+    for (int lo = cmin; lo <= cmax; lo += NCC_CH) {
+        const int hi = min(lo + NCC_CH - 1, cmax);
+        const int baseB = (3 * (lo - R)) & ~3;
+        const int ndB = strideB >> 2;
+        __syncthreads();
+        {
+            const int need = ((3 * (hi + R) + 3 - baseB) + 3 + 8) >> 2; // dwords incl. slack for the NA+1-th read
+            const int ndw = min(need, ndB);
+            for (int j = 0; j < WS; j++) {
+                const uint8_t *src = d.img_oth + (size_t)(y - R + j) * rowBytes;
+                for (int i = threadIdx.x; i < ndw; i += NCC_TX) {
+                    const int b = baseB + 4 * i;
+                    uint32_t v = 0;
+                    if (b + 3 < rowBytes) __builtin_memcpy(&v, src + b, 4);
+                    else
+                        for (int k = 0; k < 4; k++)
+                            if (b + k < rowBytes) v |= (uint32_t)src[b + k] << (8 * k);
+                    sB[j * ndB + i] = v;
+                }
+            }
+            for (int i = threadIdx.x; i <= hi - lo; i += NCC_TX) {
+                const size_t o = (size_t)y * W + lo + i;
+                sM[i] = d.mask_oth[o];
+                sS1[i] = d.S1_oth[o];
+                sS2[i] = d.S2_oth[o];
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const int c0 = max(L, lo), c1 = min(Rr, hi);
+            for (int c = c0; c <= c1; c++) {
+                if (sM[c - lo] != 255) continue;
+                const int ob = 3 * (c - R) - baseB;
+                const int wb = ob >> 2, shb = ob & 3;
+                uint32_t Sab = 0;
+#pragma unroll
+                for (int j = 0; j < WS; j++) {
+                    uint32_t raw[NA + 1];
+#pragma unroll
+                    for (int m = 0; m <= NA; m++) raw[m] = sB[j * ndB + wb + m];
+#pragma unroll
+                    for (int m = 0; m < NA; m++)
+                        Sab = __builtin_amdgcn_udot4(Areg[j][m], __builtin_amdgcn_alignbyte(raw[m + 1], raw[m], shb), Sab, false);
+                }
+                const int Sb = sS1[c - lo];
+                const int Sbb = sS2[c - lo];
+                const long long vb = (long long)n * Sbb - (long long)Sb * Sb;
+                const long long num = (long long)n * (long long)Sab - (long long)Sa * Sb;
+                double score = 0.0;
+                if (va > 0 && vb > 0) score = (double)num / sqrt((double)va * (double)vb);
+                if (score > bestv) {
+                    bestv = score;
+                    best = c;
+                }
+            }
+        }
+    }
+    if (active && best != -1) d.d16_out[pix] = (int16_t)(best - x);
+}
+
+template <int R>
+static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st) {
+    constexpr int WS = 2 * R + 1;
+    const int strideA = (((NCC_TX + 2 * R) * 3 + 3 + 12) + 3) & ~3;
+    const int strideB = (((NCC_CH + 2 * R) * 3 + 3 + 12) + 3) & ~3;
+    const size_t lds = 16 + (size_t)WS * strideA + (size_t)WS * strideB + (size_t)NCC_CH * 9 + 16;
+    hipLaunchKernelGGL(k_ncc_dot4<R>, grid, dim3(NCC_TX), lds, st, a, mode, strideA, strideB);
+}
+
 void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
     int rows = 0, cols = 0;
     for (int v = 0; v < a.ndir; v++) {
@@ -226,10 +408,23 @@ void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
         cols = max(cols, a.d[v].own.XR - a.d[v].own.XL + 1);
     }
     if (rows <= 0 || cols <= 0) return;
+    dim3 grid((cols + NCC_TX - 1) / NCC_TX, rows, a.ndir);
+    static const bool force_bytes = getenv("RSM_NCC_BYTES") != nullptr; // A/B switch for validation
+    if (!force_bytes) {
+        switch (a.r) {
+        case 1: return launch_dot4<1>(a, mode, grid, st);
+        case 2: return launch_dot4<2>(a, mode, grid, st);
+        case 3: return launch_dot4<3>(a, mode, grid, st);
+        case 4: return launch_dot4<4>(a, mode, grid, st);
+        case 5: return launch_dot4<5>(a, mode, grid, st);
+        case 6: return launch_dot4<6>(a, mode, grid, st);
+        case 7: return launch_dot4<7>(a, mode, grid, st);
+        default: break;
+        }
+    }
     const int ws = 2 * a.r + 1;
     const int strideA = (((NCC_TX + 2 * a.r) * 3 + 3) & ~3) + 4;
     const int strideB = (((NCC_CH + 2 * a.r) * 3 + 3) & ~3) + 4;
     const size_t lds = 16 + (size_t)ws * strideA + (size_t)ws * strideB;
-    dim3 grid((cols + NCC_TX - 1) / NCC_TX, rows, a.ndir);
-    hipLaunchKernelGGL(k_ncc_argmax, grid, dim3(NCC_TX), lds, st, a, mode, strideA, strideB);
+    hipLaunchKernelGGL(k_ncc_bytes, grid, dim3(NCC_TX), lds, st, a, mode, strideA, strideB);
 }

@@ -30,11 +30,13 @@ __global__ void k_refine_init(StageArgs a) {
     const size_t n = (size_t)a.W * a.H;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (blockIdx.z == 0 && i < 2 * RF_NSHARD) a.rf_cnt[i] = 0;
     for (; i < n; i += stride) {
         const double v = (double)d.d16_in[i]; // convertTo CV_64F, .cpp:585
         d.f64_a[i] = v;
         d.f64_b[i] = v; // copyTo, .cpp:587
         d.rf_key[i] = INT_MIN;
+        d.rf_key[i + a.rf_stride] = INT_MIN;
     }
 }
 
@@ -42,35 +44,113 @@ void launch_refine_init(const StageArgs &a, hipStream_t st) {
     const size_t n = (size_t)a.W * a.H;
     size_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    if (blocks < (2 * RF_NSHARD + 255) / 256) blocks = (2 * RF_NSHARD + 255) / 256;
     hipLaunchKernelGGL(k_refine_init, dim3((unsigned)blocks, 1, a.ndir), dim3(256), 0, st, a);
 }
 
+// The update of .cpp:652-672 given the data term (pwp, delta = pdp - dCenter).
+__device__ __forceinline__ double refine_update(int mode, double dC, double dE, double dW, double dN, double dS,
+                                                double pwp, double delta, double ws) {
+    // pwp == 0 only happens for index 1 (.cpp:642-643: pdp = 0)
+    const double pdp = (pwp == 0) ? 0.0 : dC + delta;
+    if (mode == 1) return (pdp * pwp + ws * (dE + dW) / 2) / (pwp + ws); // .cpp:658
+    if (mode == 2) return (pdp * pwp + ws * (dN + dS) / 2) / (pwp + ws); // .cpp:661
+    const double ex = fabs(dE - dC) - fabs(dW - dC);
+    const double ey = fabs(dS - dC) - fabs(dN - dC);
+    const double wx = exp_neg(ex * ex); // .cpp:665-666
+    const double wy = exp_neg(ey * ey);
+    double ds;
+    if (wx + wy == 0) ds = (dE + dW + dS + dN) / 4;
+    else ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));
+    return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
+}
+
+// Light sweep kernel: one pixel per thread, every load issued up front. A pixel whose cached data term
+// belongs to another iMatch (cache miss) is appended to the sweep's worklist instead of being updated
+// here; k_refine_miss handles it before the next sweep starts (stream order).
 // TOP only gives the top level's launches (the dominant kernel) their own name in rocprof traces.
 template <int TOP>
 __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     const DirArgs &d = a.d[blockIdx.z];
     const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = d.own.YL + 1 + blockIdx.y;
-    if (x > d.own.XR - 1 || y > d.own.YR - 1) return;
-    const int W = a.W, H = a.H;
-    const double *in = d.f64_a;
-    double *out = d.f64_b;
-    const size_t pix = (size_t)y * W + x;
+    const bool inside = !(x > d.own.XR - 1 || y > d.own.YR - 1);
+    const int W = a.W;
+    const double *__restrict__ in = d.f64_a;
+    double *__restrict__ out = d.f64_b;
+    const size_t pix = inside ? (size_t)y * W + x : (size_t)(d.own.YL + 1) * W + d.own.XL + 1;
     const double dC = in[pix];
-    if (dC == (double)NOMATCH) return; // .cpp:613
     const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
+    const int key = (int)(dC - 1.5) + x; // .cpp:625
+    // 2-way cache indexed by key parity: the iteration settles into flipping between two ADJACENT
+    // iMatch values for most pixels, so both data terms stay resident and misses die out.
+    const size_t cpix = pix + (size_t)(key & 1) * a.rf_stride;
+    const int ckey = d.rf_key[cpix];
+    const double pwp = d.rf_pwp[cpix];
+    const double delta = d.rf_delta[cpix];
+    const bool live = inside && dC != (double)NOMATCH; // .cpp:613
     const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
                      (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
-    if (mode == 0) {
-        out[pix] = dC; // .cpp:655
-        return;
+    const bool miss = live && mode != 0 && ckey != key;
+    // wave-aggregated append of the missing pixels to this sweep's worklist
+    const unsigned long long mm = __ballot(miss);
+    if (mm) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __builtin_ctzll(mm);
+        int base = 0;
+        // sharded: one atomic counter serves ~88 appends/us, ~180k waves per sweep would serialise on it
+        const int shard = (blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & (RF_NSHARD - 1);
+        if (lane == leader) base = atomicAdd(&a.rf_cnt[(a.flag2 & 1) * RF_NSHARD + shard], __popcll(mm));
+        base = __shfl(base, leader);
+        if (miss)
+            a.rf_list[(size_t)shard * a.rf_cap + base + __popcll(mm & ((1ull << lane) - 1ull))] =
+                (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
     }
-    const int key = (int)(dC - 1.5) + x; // .cpp:625
-    double pwp, delta;
-    if (d.rf_key[pix] == key) {
-        pwp = d.rf_pwp[pix];
-        delta = d.rf_delta[pix];
-    } else {
+    if (!live || miss) return;
+    out[pix] = (mode == 0) ? dC /* .cpp:655 */ : refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+}
+
+// Worklist kernel: recomputes the data term of the listed pixels, refreshes their cache and writes
+// their sweep result.
+// FULL = 1 is the first sweep of a level: every cache entry is empty, so instead of a worklist the
+// kernel walks the whole interior (and also does the mode 0 copy-through).
+template <int FULL>
+__global__ __launch_bounds__(256) void k_refine_miss(StageArgs a) {
+    const int W = a.W, H = a.H;
+    // worklist mode: block b serves shard b % RF_NSHARD, RF_SUB blocks per shard
+    const int shard = blockIdx.x & (RF_NSHARD - 1);
+    const int count = FULL ? 0 : a.rf_cnt[(a.flag2 & 1) * RF_NSHARD + shard];
+    if (!FULL && blockIdx.x < RF_NSHARD && threadIdx.x == 0)
+        a.rf_cnt[((a.flag2 + 1) & 1) * RF_NSHARD + shard] = 0; // the next sweep's counter set (idle now)
+    for (int e = (blockIdx.x / RF_NSHARD) * blockDim.x + threadIdx.x; FULL || e < count; e += RF_SUB * blockDim.x) {
+        int x, y, v;
+        if (FULL) {
+            v = blockIdx.z;
+            x = a.d[v].own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+            y = a.d[v].own.YL + 1 + blockIdx.y;
+            if (x > a.d[v].own.XR - 1 || y > a.d[v].own.YR - 1) return;
+        } else {
+            const uint32_t ent = a.rf_list[(size_t)shard * a.rf_cap + e];
+            v = ent >> 31;
+            const uint32_t p = ent & 0x7fffffffu;
+            y = (int)(p / W);
+            x = (int)(p % W);
+        }
+        const DirArgs &d = a.d[v];
+        const size_t pix = (size_t)y * W + x;
+        const double *in = d.f64_a;
+        const double dC = in[pix];
+        if (FULL && dC == (double)NOMATCH) return;
+        const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
+        const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                         (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
+        if (FULL && mode == 0) {
+            d.f64_b[pix] = dC;
+            return;
+        }
+        const int key = (int)(dC - 1.5) + x;
+        double pwp, delta;
+        {
         // Bit-faithful fp64 restatement of CManageData::WindowToVec (CManageData.cpp:81-90) + arma::dot on
         // the 27-element windows, same gather order (byte column outer, row inner) and the same
         // two-accumulator sums as Armadillo (op_dot_meat.hpp:20-55, fn_norm.hpp:99-130): the sweep is
@@ -140,30 +220,17 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
             pwp = 0.5 * (xi[0] + xi[2]) - xi[1];
             delta = (pwp == 0) ? 0.0 : 0.5 * (xi[0] - xi[2]) / (xi[0] + xi[2] - 2 * xi[1]);
         }
-        d.rf_key[pix] = key;
-        d.rf_pwp[pix] = pwp;
-        d.rf_delta[pix] = delta;
+        }
+        const size_t cpix = pix + (size_t)(key & 1) * a.rf_stride;
+        d.rf_key[cpix] = key;
+        d.rf_pwp[cpix] = pwp;
+        d.rf_delta[cpix] = delta;
+        d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+        if (FULL) return;
     }
-    // pwp == 0 only happens for index 1 (.cpp:642-643: pdp = 0)
-    const double pdp = (pwp == 0) ? 0.0 : dC + delta;
-    const double ws = a.ws;
-    double res;
-    if (mode == 1) {
-        res = (pdp * pwp + ws * (dE + dW) / 2) / (pwp + ws); // .cpp:658
-    } else if (mode == 2) {
-        res = (pdp * pwp + ws * (dN + dS) / 2) / (pwp + ws); // .cpp:661
-    } else {
-        const double ex = fabs(dE - dC) - fabs(dW - dC);
-        const double ey = fabs(dS - dC) - fabs(dN - dC);
-        const double wx = exp_neg(ex * ex); // .cpp:665-666
-        const double wy = exp_neg(ey * ey);
-        double ds;
-        if (wx + wy == 0) ds = (dE + dW + dS + dN) / 4;
-        else ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));
-        res = (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
-    }
-    out[pix] = res;
 }
+
+static void launch_refine_sweep_impl(const StageArgs &a, dim3 grid, hipStream_t st);
 
 void launch_refine_sweep(const StageArgs &a, hipStream_t st) {
     int rows = 0, cols = 0;
@@ -173,6 +240,17 @@ void launch_refine_sweep(const StageArgs &a, hipStream_t st) {
     }
     if (rows <= 0 || cols <= 0) return;
     const dim3 grid((cols + 255) / 256, rows, a.ndir);
+    StageArgs b = a;
+    b.rf_cap = (int)((((long long)grid.x * grid.y * grid.z + RF_NSHARD - 1) / RF_NSHARD) * 256);
+    return launch_refine_sweep_impl(b, grid, st);
+}
+
+static void launch_refine_sweep_impl(const StageArgs &a, dim3 grid, hipStream_t st) {
+    if (a.flag2 == 0) { // first sweep: everything misses
+        hipLaunchKernelGGL(k_refine_miss<1>, grid, dim3(256), 0, st, a);
+        return;
+    }
     if (a.flag) hipLaunchKernelGGL(k_refine_sweep<1>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_refine_sweep<0>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_refine_miss<0>, dim3(RF_NSHARD * RF_SUB), dim3(256), 0, st, a);
 }

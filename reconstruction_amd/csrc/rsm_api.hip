@@ -65,6 +65,8 @@ struct rsm_ctx {
     double *f64[3][2]{};
     int32_t *nv[2]{};
     int32_t *rf_key[2]{};
+    int32_t *rf_cnt = nullptr;
+    uint32_t *rf_list = nullptr;
     double *rf_pwp[2]{}, *rf_delta[2]{};
     int32_t *prefix = nullptr;
     int *d_j1 = nullptr, *d_j2 = nullptr;
@@ -231,10 +233,12 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         DALLOC(c, c->BR[v], px);
         for (int i = 0; i < 3; i++) DALLOC(c, c->f64[i][v], px);
         DALLOC(c, c->nv[v], px / 4 + 16);
-        DALLOC(c, c->rf_key[v], px);
-        DALLOC(c, c->rf_pwp[v], px);
-        DALLOC(c, c->rf_delta[v], px);
+        DALLOC(c, c->rf_key[v], 2 * px);
+        DALLOC(c, c->rf_pwp[v], 2 * px);
+        DALLOC(c, c->rf_delta[v], 2 * px);
     }
+    DALLOC(c, c->rf_cnt, 2 * RF_NSHARD);
+    DALLOC(c, c->rf_list, 2 * (size_t)(in->width + 256) * in->height + RF_NSHARD * 256);
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->d_j1, 4096);
     DALLOC(c, c->d_j2, 4096);
@@ -322,6 +326,9 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.r = c->in.radius;
     a.offset = c->in.offset;
     a.ws = c->in.ws;
+    a.rf_cnt = c->rf_cnt;
+    a.rf_list = c->rf_list;
+    a.rf_stride = c->cap_px;
     for (int v = 0; v < 2; v++) {
         DirArgs &d = a.d[v];
         const int o = 1 - v;
@@ -486,12 +493,13 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
                 a.d[v].f64_b = c->f64[nxt][v];
             }
             a.flag = (k == N - 1);
+            a.flag2 = it;
             launch_refine_sweep(a, st);
             const int t = cur;
             cur = nxt;
             nxt = t;
         }
-        prof_end(c, st_sweep, iters, 32.0 * Pk * iters);
+        prof_end(c, st_sweep, iters, 32.0 * Pk * iters); // launches = sweeps (each = light kernel + worklist kernel)
 
         // ---- UniquenessContraint<double> (.cpp:109) on the refined maps (now in f64[cur])
         prof_begin(c, ST_UNIQ64);
@@ -890,14 +898,19 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.img_own = t.up(img_own, px * 3);
     d.img_oth = t.up(img_oth, px * 3);
     double *A = t.alloc<double>(px), *B = t.alloc<double>(px);
-    d.rf_key = t.alloc<int32_t>(px);
-    d.rf_pwp = t.alloc<double>(px);
-    d.rf_delta = t.alloc<double>(px);
+    d.rf_key = t.alloc<int32_t>(2 * px);
+    d.rf_pwp = t.alloc<double>(2 * px);
+    d.rf_delta = t.alloc<double>(2 * px);
+    a.rf_stride = px;
+    a.rf_cnt = t.alloc<int32_t>(2 * RF_NSHARD);
+    a.rf_list = t.alloc<uint32_t>((size_t)(W + 256) * H + RF_NSHARD * 256);
     if (!t.ok) return finish(c, t);
+    if (iterations > RF_MAX_SWEEPS) return set_err(c, RSM_E_INVALID, "iterations");
     d.f64_a = A;
     d.f64_b = B;
     launch_refine_init(a, c->stream);
     for (int it = 0; it < iterations; it++) {
+        a.flag2 = it;
         launch_refine_sweep(a, c->stream);
         double *x = d.f64_a;
         d.f64_a = d.f64_b;

@@ -7,6 +7,9 @@
 
 #define NOMATCH (-10000) // reconstruction/CStereoMatching.h:9
 #define WAVE 64
+#define RF_MAX_SWEEPS 1024
+#define RF_NSHARD 256 // refine worklist shards (power of 2)
+#define RF_SUB 4      // worklist blocks per shard
 
 // Margin of one view at one level (struct Boundary, CManageData.h:10-14, without width/height).
 struct Mg {
@@ -26,7 +29,7 @@ struct DirArgs {
     const double *parent;      // fp64 disparity of level k-1 (this direction)
     const int32_t *parent_nv;  // next-valid-column table of `parent`
     double *f64_a, *f64_b;     // fp64 disparity ping-pong / uniqueness maps
-    int32_t *rf_key;           // refine cache: iMatch key
+    int32_t *rf_key;           // refine cache (2 ways, way = key & 1): iMatch key
     double *rf_pwp, *rf_delta; // refine cache: data-term weight and offset
 };
 
@@ -39,6 +42,11 @@ struct StageArgs {
     int offset;  // m_offset
     double ws;   // m_ws
     int flag;    // stage-specific
+    int flag2;   // refine: sweep index
+    int rf_cap;        // refine: worklist entries per shard
+    size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
+    int32_t *rf_cnt;   // refine: worklist counters [2 sets][RF_NSHARD]
+    uint32_t *rf_list; // refine: worklist of (dir << 31 | pixel index)
 };
 
 // ---- launchers (each enqueues on `st`, no sync) ----------------------------------------------
