@@ -56,7 +56,7 @@ class PairOut(C.Structure):
 EXPORTS = [
     "rsm_create", "rsm_destroy", "rsm_last_error", "rsm_version", "rsm_match_pair", "rsm_upload_pair",
     "rsm_upload_pair_device", "rsm_run_pair", "rsm_download_pair", "rsm_result_device", "rsm_export_cloud_device",
-    "rsm_profile_enable", "rsm_profile_stage_count", "rsm_profile_stage_name", "rsm_profile_get",
+    "rsm_set_option", "rsm_profile_enable", "rsm_profile_stage_count", "rsm_profile_stage_name", "rsm_profile_get",
     "rsm_stage_find_margin", "rsm_stage_pyr_down", "rsm_stage_erode_ellipse", "rsm_stage_initial_match",
     "rsm_stage_smooth", "rsm_stage_order", "rsm_stage_uniqueness_pass_s16", "rsm_stage_uniqueness_pass_f64",
     "rsm_stage_set_boundary", "rsm_stage_rematch", "rsm_stage_median", "rsm_stage_refine", "rsm_stage_cloud",

@@ -161,6 +161,9 @@ class Context:
     def n_points(self):
         return self.result_device()[2]
 
+    def set_option(self, name: str, value: int):
+        self._chk(self._lib.rsm_set_option(self._h, name.encode(), C.c_longlong(value)))
+
     # ---- measurement -----------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self._lib.rsm_profile_enable(self._h, int(bool(on))))

@@ -70,61 +70,59 @@ void launch_smooth(const StageArgs &a, hipStream_t st) {
 // (m = p[x] + x). Crossing count of i = #{j<i : m_j > m_i} + #{j>i : m_j < m_i} -- the row sums of the
 // reference's symmetric matrix A (.cpp:337-353) without ever materialising it. Then the greedy loop of
 // .cpp:354-364: remove the first pixel with the largest count until no crossings remain.
-__global__ __launch_bounds__(256) void k_order(StageArgs a, int maxL) {
+__global__ __launch_bounds__(64) void k_order(StageArgs a, int maxL) {
+    // One wave (= one 64-thread workgroup) per row: no cross-wave barriers in the greedy loop.
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DirArgs &d = a.d[blockIdx.z];
     const int y = d.own.YL + blockIdx.x;
     if (y > d.own.YR) return;
     const int W = a.W, XL = d.own.XL, XR = d.own.XR;
-    int *cnt = (int *)smem;                  // [maxL]
-    int16_t *line = (int16_t *)(cnt + maxL); // [maxL]
-    int16_t *idx = line + maxL;              // [maxL]
-    __shared__ int s_n, s_flag, s_best[4], s_bidx[4], s_wsum[4];
+    int16_t *line = (int16_t *)smem; // [maxL] m = p[x] + x of the valid pixels, ascending x
+    int16_t *idx = line + maxL;      // [maxL] their x
+    int16_t *cnt = idx + maxL;       // [maxL] crossing counts (-1 = removed)
     int16_t *p = d.d16_in + (size_t)y * W;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) {
-        s_n = 0;
-        s_flag = 0;
-    }
-    __syncthreads();
-    // ordered compaction, 256 columns per pass
-    for (int x0 = XL; x0 <= XR; x0 += 256) {
-        const int x = x0 + tid;
+    const int lane = threadIdx.x;
+    int n = 0, pmin = 0x7fffffff, pmax = -0x7fffffff;
+    for (int x0 = XL; x0 <= XR; x0 += 64) {
+        const int x = x0 + lane;
         const int v = (x <= XR) ? (int)p[x] : NOMATCH;
         const bool valid = v != NOMATCH;
         const unsigned long long m = __ballot(valid);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wsum[wid] = __popcll(m);
-        __syncthreads();
-        int base = s_n;
-        for (int w = 0; w < wid; w++) base += s_wsum[w];
         if (valid) {
-            line[base + before] = (int16_t)(v + x);
-            idx[base + before] = (int16_t)x;
+            const int k = n + __popcll(m & ((1ull << lane) - 1ull));
+            line[k] = (int16_t)(v + x);
+            idx[k] = (int16_t)x;
+            pmin = min(pmin, v);
+            pmax = max(pmax, v);
         }
-        __syncthreads();
-        if (tid == 0) s_n += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-        __syncthreads();
+        n += __popcll(m);
     }
-    const int n = s_n;
     if (n < 2) return;
-    // fast path: already non-decreasing -> no crossings
-    for (int i = tid; i + 1 < n; i += 256)
-        if (line[i] > line[i + 1]) s_flag = 1;
     __syncthreads();
-    if (!s_flag) return;
-    for (int i = tid; i < n; i += 256) {
+    // already non-decreasing -> no crossings at all
+    bool inv = false;
+    for (int i = lane; i + 1 < n; i += 64) inv = inv || (line[i] > line[i + 1]);
+    if (!__any(inv)) return;
+    for (int o = 32; o > 0; o >>= 1) {
+        pmin = min(pmin, __shfl_xor(pmin, o));
+        pmax = max(pmax, __shfl_xor(pmax, o));
+    }
+    // j < i crosses i only if x_i - x_j < p_j - p_i <= pmax - pmin, and x_i - x_j >= i - j:
+    // a window of `win` list positions on each side is exhaustive.
+    const int win = pmax - pmin;
+    for (int i = lane; i < n; i += 64) {
         const int mi = line[i];
         int c = 0;
-        for (int j = 0; j < i; j++) c += line[j] > mi;
-        for (int j = i + 1; j < n; j++) c += line[j] < mi;
-        cnt[i] = c;
+        const int j0 = max(0, i - win), j1 = min(n - 1, i + win);
+        for (int j = j0; j < i; j++) c += line[j] > mi;
+        for (int j = i + 1; j <= j1; j++) c += line[j] < mi;
+        cnt[i] = (int16_t)c;
     }
     __syncthreads();
     for (;;) {
-        // first index of the maximum count (op_max: strict '>' scan -> first maximum)
+        // first index of the maximum count (Armadillo's max(idx): strict '>' scan -> first maximum)
         int bv = -1, bi = 0x7fffffff;
-        for (int i = tid; i < n; i += 256) {
+        for (int i = lane; i < n; i += 64) {
             const int c = cnt[i];
             if (c > bv) {
                 bv = c;
@@ -138,30 +136,18 @@ __global__ __launch_bounds__(256) void k_order(StageArgs a, int maxL) {
                 bi = oi;
             }
         }
-        if (lane == 0) {
-            s_best[wid] = bv;
-            s_bidx[wid] = bi;
-        }
-        __syncthreads();
-        bv = s_best[0];
-        bi = s_bidx[0];
-        for (int w = 1; w < 4; w++)
-            if (s_best[w] > bv || (s_best[w] == bv && s_bidx[w] < bi)) {
-                bv = s_best[w];
-                bi = s_bidx[w];
-            }
         if (bv <= 0) break; // ones_count == 0 (.cpp:354)
         const int mb = line[bi];
-        __syncthreads(); // everyone has read s_best / line[bi]
-        for (int j = tid; j < n; j += 256) {
+        const int j0 = max(0, bi - win), j1 = min(n - 1, bi + win);
+        __syncthreads();
+        for (int j = j0 + lane; j <= j1; j += 64) {
             const int c = cnt[j];
             if (c < 0 || j == bi) continue; // removed pixels have no edges left
             const int mj = line[j];
-            if ((j < bi && mj > mb) || (j > bi && mj < mb)) cnt[j] = c - 1;
+            if ((j < bi && mj > mb) || (j > bi && mj < mb)) cnt[j] = (int16_t)(c - 1);
         }
-        __syncthreads();
-        if (tid == 0) {
-            cnt[bi] = -1; // dead: row/col of A zeroed (.cpp:359-361)
+        if (lane == 0) {
+            cnt[bi] = -1; // row/col of A zeroed (.cpp:359-361)
             p[idx[bi]] = (int16_t)NOMATCH;
         }
         __syncthreads();
@@ -176,8 +162,8 @@ void launch_order(const StageArgs &a, hipStream_t st) {
     }
     if (rows <= 0 || maxL <= 0) return;
     maxL = (maxL + 7) & ~7;
-    const size_t lds = (size_t)maxL * (4 + 2 + 2);
-    hipLaunchKernelGGL(k_order, dim3(rows, 1, a.ndir), dim3(256), lds, st, a, maxL);
+    const size_t lds = (size_t)maxL * 6;
+    hipLaunchKernelGGL(k_order, dim3(rows, 1, a.ndir), dim3(64), lds, st, a, maxL);
 }
 
 // ---------------------------------------------------------------- UniquenessContraint_<T>
@@ -251,30 +237,57 @@ void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, h
 
 // ---------------------------------------------------------------- SetBoundary_smooth<short>
 #define MAX_DISPARITY 2 // .cpp:4
-// vertical sweeps (.cpp:842-901): columns are independent -> one thread per column.
+// vertical sweeps (.cpp:842-901): columns are independent -> one thread per column. The only serial
+// dependency is the (bl, br) register pair; loads are batched SB_U rows ahead of it.
+#define SB_U 16
 __global__ void k_setb_vert(StageArgs a) {
     const DirArgs &d = a.d[blockIdx.z];
     const int x = d.own.XL + blockIdx.x * blockDim.x + threadIdx.x;
     if (x > d.own.XR) return;
     const int W = a.W, YL = d.own.YL, YR = d.own.YR;
-    const uint8_t *mk = d.mask_own;
-    const int16_t *src = d.d16_in;
-    int16_t *BL = d.BL, *BR = d.BR;
+    const uint8_t *__restrict__ mk = d.mask_own;
+    const int16_t *__restrict__ src = d.d16_in;
+    int16_t *__restrict__ BL = d.BL;
+    int16_t *__restrict__ BR = d.BR;
     int bl = -10000, br = 10000; // .cpp:832-833
-    for (int y = YL; y <= YR - 1; y++) {
+    int y = YL;
+    for (; y + SB_U <= YR; y += SB_U) { // rows y .. y+SB_U-1 are all <= YR-1
+        int m[SB_U], r[SB_U];
+#pragma unroll
+        for (int i = 0; i < SB_U; i++) {
+            const size_t o = (size_t)(y + i) * W + x;
+            m[i] = mk[o];
+            r[i] = src[o];
+        }
+#pragma unroll
+        for (int i = 0; i < SB_U; i++) {
+            const size_t o = (size_t)(y + i) * W + x;
+            int nbl = -10000, nbr = 10000;
+            if (m[i] == 255) {
+                if (r[i] != NOMATCH) {
+                    bl = r[i];
+                    br = r[i];
+                }
+                nbl = max(bl - MAX_DISPARITY, nbl);
+                nbr = min(br + MAX_DISPARITY, nbr);
+            }
+            BL[o] = (int16_t)bl;
+            BR[o] = (int16_t)br;
+            bl = nbl;
+            br = nbr;
+        }
+    }
+    for (; y <= YR - 1; y++) {
         const size_t o = (size_t)y * W + x;
         int nbl = -10000, nbr = 10000;
         if (mk[o] == 255) {
             const int ref = src[o];
-            if (ref == NOMATCH) {
-                nbl = max(bl - MAX_DISPARITY, nbl);
-                nbr = min(br + MAX_DISPARITY, nbr);
-            } else {
+            if (ref != NOMATCH) {
                 bl = ref;
                 br = ref;
-                nbl = max(ref - MAX_DISPARITY, nbl);
-                nbr = min(ref + MAX_DISPARITY, nbr);
             }
+            nbl = max(bl - MAX_DISPARITY, nbl);
+            nbr = min(br + MAX_DISPARITY, nbr);
         }
         BL[o] = (int16_t)bl;
         BR[o] = (int16_t)br;
@@ -283,20 +296,46 @@ __global__ void k_setb_vert(StageArgs a) {
     }
     BL[(size_t)YR * W + x] = (int16_t)bl;
     BR[(size_t)YR * W + x] = (int16_t)br;
-    for (int y = YR; y >= YL + 1; y--) {
+    y = YR;
+    for (; y - SB_U >= YL; y -= SB_U) { // rows y .. y-SB_U+1 are all >= YL+1
+        int m[SB_U], r[SB_U], ul[SB_U], ur[SB_U];
+#pragma unroll
+        for (int i = 0; i < SB_U; i++) {
+            const size_t o = (size_t)(y - i) * W + x;
+            m[i] = mk[o];
+            r[i] = src[o];
+            ul[i] = BL[o - W];
+            ur[i] = BR[o - W];
+        }
+#pragma unroll
+        for (int i = 0; i < SB_U; i++) {
+            const size_t o = (size_t)(y - i) * W + x;
+            int ubl = ul[i], ubr = ur[i];
+            if (m[i] == 255) {
+                if (r[i] != NOMATCH) {
+                    bl = r[i];
+                    br = r[i];
+                }
+                ubl = max(bl - MAX_DISPARITY, ubl);
+                ubr = min(br + MAX_DISPARITY, ubr);
+            }
+            BL[o] = (int16_t)bl;
+            BR[o] = (int16_t)br;
+            bl = ubl;
+            br = ubr;
+        }
+    }
+    for (; y >= YL + 1; y--) {
         const size_t o = (size_t)y * W + x;
         int ubl = BL[o - W], ubr = BR[o - W];
         if (mk[o] == 255) {
             const int ref = src[o];
-            if (ref == NOMATCH) {
-                ubl = max(bl - MAX_DISPARITY, ubl);
-                ubr = min(br + MAX_DISPARITY, ubr);
-            } else {
+            if (ref != NOMATCH) {
                 bl = ref;
                 br = ref;
-                ubl = max(ref - MAX_DISPARITY, ubl);
-                ubr = min(ref + MAX_DISPARITY, ubr);
             }
+            ubl = max(bl - MAX_DISPARITY, ubl);
+            ubr = min(br + MAX_DISPARITY, ubr);
         }
         BL[o] = (int16_t)bl;
         BR[o] = (int16_t)br;
@@ -307,49 +346,121 @@ __global__ void k_setb_vert(StageArgs a) {
     BR[(size_t)YL * W + x] = (int16_t)br;
 }
 
-// horizontal sweeps (.cpp:903-941): one thread per row, literal.
-__global__ void k_setb_horiz(StageArgs a) {
+// horizontal sweeps (.cpp:903-941): sequential along x inside a row. One wave handles SBH_R rows;
+// SBH_R x SBH_W tiles of BL / BR / mask go through LDS (coalesced row-segment loads and stores), lane t
+// (< SBH_R) walks row t of the tile with the running (bl, br) pair in registers.
+#define SBH_R 16   // rows per wave
+#define SBH_W 256  // tile width (columns)
+#define SBH_LD 258 // LDS row stride in int16 elements
+#define SBH_LM 260 // LDS row stride of the mask tile (bytes)
+__global__ __launch_bounds__(64) void k_setb_horiz(StageArgs a) {
+    __shared__ int16_t tl[SBH_R * SBH_LD], tr[SBH_R * SBH_LD];
+    __shared__ uint8_t tm[SBH_R * SBH_LM];
     const DirArgs &d = a.d[blockIdx.z];
-    const int y = d.own.YL + blockIdx.x * blockDim.x + threadIdx.x;
-    if (y > d.own.YR) return;
-    const int W = a.W, XL = d.own.XL, XR = d.own.XR, XL1 = d.oth.XL, XR1 = d.oth.XR;
-    const uint8_t *mk = d.mask_own + (size_t)y * W;
-    int16_t *bl = d.BL + (size_t)y * W, *br = d.BR + (size_t)y * W;
-    int cbl = bl[XL], cbr = br[XL];
-    for (int x = XL; x <= XR - 1; x++) {
-        int nbl = bl[x + 1], nbr = br[x + 1];
-        if (mk[x] == 255) {
-            nbl = max(cbl - 1, nbl);
-            nbr = min(cbr + MAX_DISPARITY, nbr);
-            bl[x + 1] = (int16_t)nbl;
-            br[x + 1] = (int16_t)nbr;
+    const int y0 = d.own.YL + blockIdx.x * SBH_R;
+    if (y0 > d.own.YR) return;
+    const int W = a.W, XL = d.own.XL, XR = d.own.XR, XL1 = d.oth.XL, XR1 = d.oth.XR, YR = d.own.YR;
+    const int lane = threadIdx.x;
+    const int nrows = min(SBH_R, YR - y0 + 1);
+    const bool rowok = lane < nrows;
+    // ---- left -> right (.cpp:909-916), target-centric: x' = x + 1
+    int cbl = 0, cbr = 0, cm = 0; // running values / mask at x' - 1
+    for (int c0 = XL; c0 <= XR; c0 += SBH_W) {
+        const int nc = min(SBH_W, XR - c0 + 1);
+        for (int r = 0; r < nrows; r++)
+            for (int cc = lane; cc < nc; cc += 64) {
+                const size_t o = (size_t)(y0 + r) * W + c0 + cc;
+                tl[r * SBH_LD + cc] = d.BL[o];
+                tr[r * SBH_LD + cc] = d.BR[o];
+                tm[r * SBH_LM + cc] = d.mask_own[o];
+            }
+        __syncthreads();
+        if (rowok) {
+            for (int i = 0; i < nc; i++) {
+                int vbl = tl[lane * SBH_LD + i], vbr = tr[lane * SBH_LD + i];
+                if (c0 + i > XL && cm == 255) {
+                    vbl = max(cbl - 1, vbl);
+                    vbr = min(cbr + MAX_DISPARITY, vbr);
+                    tl[lane * SBH_LD + i] = (int16_t)vbl;
+                    tr[lane * SBH_LD + i] = (int16_t)vbr;
+                }
+                cbl = vbl;
+                cbr = vbr;
+                cm = tm[lane * SBH_LM + i];
+            }
         }
-        cbl = nbl;
-        cbr = nbr;
+        __syncthreads();
+        for (int r = 0; r < nrows; r++)
+            for (int cc = lane; cc < nc; cc += 64) {
+                const size_t o = (size_t)(y0 + r) * W + c0 + cc;
+                d.BL[o] = tl[r * SBH_LD + cc];
+                d.BR[o] = tr[r * SBH_LD + cc];
+            }
+        __syncthreads();
     }
-    // cbl/cbr now hold the values at XR
-    for (int x = XR; x >= XL + 1; x--) {
-        int lbl = bl[x - 1], lbr = br[x - 1];
-        if (mk[x] == 255) {
-            int A = (int16_t)(cbl + x), B = (int16_t)(cbr + x);
-            if (A < XL1) A = XL1;
-            if (B > XR1) B = XR1;
-            bl[x] = (int16_t)A;
-            br[x] = (int16_t)B;
-            lbl = max(A - x - MAX_DISPARITY, lbl);
-            lbr = min(B - x + 1, lbr);
-            bl[x - 1] = (int16_t)lbl;
-            br[x - 1] = (int16_t)lbr;
+    // ---- right -> left (.cpp:917-940). cbl/cbr hold the values at XR.
+    const int ntile = (XR - XL) / SBH_W + 1;
+    for (int t = ntile - 1; t >= 0; t--) {
+        const int c0 = XL + t * SBH_W;
+        const int nc = min(SBH_W, XR - c0 + 1);
+        for (int r = 0; r < nrows; r++)
+            for (int cc = lane; cc < nc; cc += 64) {
+                const size_t o = (size_t)(y0 + r) * W + c0 + cc;
+                tl[r * SBH_LD + cc] = d.BL[o];
+                tr[r * SBH_LD + cc] = d.BR[o];
+                tm[r * SBH_LM + cc] = d.mask_own[o];
+            }
+        __syncthreads();
+        if (rowok) {
+            for (int i = nc - 1; i >= 0; i--) {
+                const int x = c0 + i;
+                if (x == XL) { // .cpp:932-940 (with the bl/br typo of :938-939)
+                    if (tm[lane * SBH_LM + i] == 255) {
+                        int A = (int16_t)(cbl + XL), B = (int16_t)(cbr + XL);
+                        if (A < XL1) A = XL1;
+                        if (B > XR1) A = XR1;
+                        tl[lane * SBH_LD + i] = (int16_t)A;
+                        tr[lane * SBH_LD + i] = (int16_t)B;
+                    } else {
+                        tl[lane * SBH_LD + i] = (int16_t)cbl;
+                        tr[lane * SBH_LD + i] = (int16_t)cbr;
+                    }
+                    break;
+                }
+                // value at x-1 before this step: from the tile, or from the next tile to the left
+                int lbl, lbr;
+                if (i > 0) {
+                    lbl = tl[lane * SBH_LD + i - 1];
+                    lbr = tr[lane * SBH_LD + i - 1];
+                } else {
+                    const size_t o = (size_t)(y0 + lane) * W + x - 1;
+                    lbl = d.BL[o];
+                    lbr = d.BR[o];
+                }
+                if (tm[lane * SBH_LM + i] == 255) {
+                    int A = (int16_t)(cbl + x), B = (int16_t)(cbr + x);
+                    if (A < XL1) A = XL1;
+                    if (B > XR1) B = XR1;
+                    tl[lane * SBH_LD + i] = (int16_t)A;
+                    tr[lane * SBH_LD + i] = (int16_t)B;
+                    lbl = max(A - x - MAX_DISPARITY, lbl);
+                    lbr = min(B - x + 1, lbr);
+                } else {
+                    tl[lane * SBH_LD + i] = (int16_t)cbl;
+                    tr[lane * SBH_LD + i] = (int16_t)cbr;
+                }
+                cbl = lbl;
+                cbr = lbr;
+            }
         }
-        cbl = lbl;
-        cbr = lbr;
-    }
-    if (mk[XL] == 255) {
-        int A = (int16_t)(cbl + XL), B = (int16_t)(cbr + XL);
-        if (A < XL1) A = XL1;
-        if (B > XR1) A = XR1; // .cpp:938-939: the reference assigns bl here (typo kept)
-        bl[XL] = (int16_t)A;
-        br[XL] = (int16_t)B;
+        __syncthreads();
+        for (int r = 0; r < nrows; r++)
+            for (int cc = lane; cc < nc; cc += 64) {
+                const size_t o = (size_t)(y0 + r) * W + c0 + cc;
+                d.BL[o] = tl[r * SBH_LD + cc];
+                d.BR[o] = tr[r * SBH_LD + cc];
+            }
+        __syncthreads();
     }
 }
 
@@ -361,7 +472,7 @@ void launch_set_boundary(const StageArgs &a, hipStream_t st) {
     }
     if (rows <= 0 || cols <= 0) return;
     hipLaunchKernelGGL(k_setb_vert, dim3((cols + 63) / 64, 1, a.ndir), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_setb_horiz, dim3((rows + 63) / 64, 1, a.ndir), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_setb_horiz, dim3((rows + SBH_R - 1) / SBH_R, 1, a.ndir), dim3(64), 0, st, a);
 }
 
 // ---------------------------------------------------------------- MedianFilter (1 iteration)

@@ -102,7 +102,7 @@ void launch_hl_interval(const StageArgs &a, hipStream_t st) {
 
 // ---------------------------------------------------------------- NCC interval argmax
 #define NCC_TX 256  // pixels of one row per block
-#define NCC_CH 512  // candidate columns staged per pass
+#define NCC_CH 384  // candidate columns staged per pass
 
 // Generic-radius fallback (byte-wise LDS reads); radii 1..7 use k_ncc_dot4 below.
 __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int strideA, int strideB) {
@@ -223,36 +223,193 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int
 }
 
 // ---------------------------------------------------------------- NCC interval argmax, v_dot4_u32_u8
-// Same decomposition (one row x 256 pixels per workgroup, both views' rows staged in LDS), but:
-//  * the pixel's own (2R+1) x 3(2R+1)-byte window lives in registers as dwords aligned to the window
-//    start (v_alignbyte_b32 once per pixel), bytes past the window masked to 0;
-//  * per candidate and window row the other view's bytes come from LDS as NA+1 aligned dwords,
-//    re-aligned with v_alignbyte_b32 and accumulated 4 MACs at a time with v_dot4_u32_u8;
-//  * mask / S1 / S2 of the candidate columns are staged in LDS next to the rows.
+// Both views are read from their BGRX copies (one dword per pixel, X = 0, k_pyramid.hip): a window row is
+// 2R+1 aligned dwords and Sab is a chain of v_dot4_u32_u8 with no byte re-alignment.  Candidates are
+// evaluated in register-blocked groups of NCC_G consecutive columns: per window row 2R+1 own dwords and
+// NCC_G+2R other-view dwords feed NCC_G*(2R+1) dot4s.
+//  k_ncc_dot4 : one row x 256 pixels per workgroup, rows of both views staged in LDS, one pixel per lane.
+//               Pixels whose interval is longer than NCC_WIDE go to a worklist instead.
+//  k_ncc_wide : one workgroup per worklist pixel, its candidates spread over the 256 lanes.  (Whole rows
+//               whose parent row is NOMATCH search the entire other margin, .cpp:260-283: a handful of
+//               rows carrying as many evaluations as the rest of the level.)
+#define NCC_G 5
+#define NCC_WIDE 160
+
+// (score, column) of candidate group c0..c0+G-1 given the G accumulated Sab; strict '>' in ascending order
 template <int R>
-__global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode, int strideA, int strideB) {
-    constexpr int WS = 2 * R + 1, WB = 3 * WS, NA = (WB + 3) / 4, LASTV = WB - 4 * (NA - 1);
-    constexpr uint32_t LASTMASK = (LASTV == 4) ? 0xffffffffu : ((1u << (8 * LASTV)) - 1u);
+__device__ __forceinline__ void ncc_score_group(const uint32_t (&acc)[NCC_G], int c0, int cend, const uint8_t *mk,
+                                                const int32_t *s1, const int32_t *s2, int Sa, long long va,
+                                                double &bv, int &bc) {
+    constexpr int n = (2 * R + 1) * (2 * R + 1) * 3;
+#pragma unroll
+    for (int g = 0; g < NCC_G; g++) {
+        const int c = c0 + g;
+        if (c > cend || mk[g] != 255) continue; // .cpp:209
+        const int Sb = s1[g];
+        const int Sbb = s2[g];
+        const long long vb = (long long)n * Sbb - (long long)Sb * Sb;
+        const long long num = (long long)n * (long long)acc[g] - (long long)Sa * Sb;
+        const double sc = (va > 0 && vb > 0) ? (double)num / sqrt((double)va * (double)vb) : 0.0;
+        if (sc > bv) { // .cpp:213
+            bv = sc;
+            bc = c;
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
+    constexpr int WS = 2 * R + 1, G = NCC_G, NB = G + WS - 1;
+    constexpr int SA = NCC_TX + 2 * R;         // dwords per staged own-view row
+    constexpr int SB = NCC_CH + 2 * R + G + 3; // dwords per staged other-view row
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int *s_lohi = (int *)smem;
+    int *s_ctl = (int *)smem; // [0]=min L, [1]=max R over the narrow pixels of the block
     uint32_t *sA = (uint32_t *)(smem + 16);
-    uint32_t *sB = sA + (size_t)WS * (strideA >> 2);
-    int32_t *sS1 = (int32_t *)(sB + (size_t)WS * (strideB >> 2));
-    int32_t *sS2 = sS1 + NCC_CH;
-    uint8_t *sM = (uint8_t *)(sS2 + NCC_CH);
+    uint32_t *sB = sA + WS * SA;
+    int32_t *sS1 = (int32_t *)(sB + WS * SB);
+    int32_t *sS2 = sS1 + NCC_CH + G;
+    uint8_t *sM = (uint8_t *)(sS2 + NCC_CH + G);
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W;
     constexpr int n = WS * WS * 3;
     const int y = d.own.YL + blockIdx.y;
     const int x0 = d.own.XL + blockIdx.x * NCC_TX;
     if (y > d.own.YR || x0 > d.own.XR) return;
-    const int x = x0 + threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int x = x0 + tid;
     const size_t pix = (size_t)y * W + x;
 
     bool active = (x <= d.own.XR) && (d.mask_own[pix] == 255);
-    if (mode == 2 && active) active = (d.d16_in[pix] == NOMATCH);
+    if (mode == 2 && active) active = (d.d16_in[pix] == NOMATCH); // Rematch: .cpp:538
     int L = 0x7fffffff, Rr = -1;
     if (active) {
+        if (mode == 0) {
+            L = d.oth.XL; // .cpp:207
+            Rr = d.oth.XR;
+        } else {
+            L = d.BL[pix];
+            Rr = d.BR[pix];
+        }
+        L = max(L, R); // windows that would leave the image are skipped (UB in the reference)
+        Rr = min(Rr, W - 1 - R);
+        if (L > Rr) active = false;
+    }
+    const bool wide = active && (Rr - L + 1 > NCC_WIDE);
+    { // wave-aggregated append of the wide pixels to the worklist of k_ncc_wide
+        const unsigned long long mm = __ballot(wide);
+        if (mm) {
+            const int leader = __builtin_ctzll(mm);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(a.ncc_cnt, __popcll(mm));
+            base = __shfl(base, leader);
+            if (wide) a.rf_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
+        }
+    }
+    const bool narrow = active && !wide;
+    if (tid == 0) {
+        s_ctl[0] = 0x7fffffff;
+        s_ctl[1] = -1;
+    }
+    __syncthreads();
+    {
+        int lo = narrow ? L : 0x7fffffff, hi = narrow ? Rr : -1;
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if (lane == 0) {
+            atomicMin(&s_ctl[0], lo);
+            atomicMax(&s_ctl[1], hi);
+        }
+    }
+    __syncthreads();
+    const int cmin = s_ctl[0], cmax = s_ctl[1];
+    if (cmax < cmin) return;
+
+    // ---- stage own-view rows: sA[j][i] <-> image column x0 - R + i of row y - R + j
+    for (int i = tid; i < SA; i += NCC_TX) {
+        const int col = x0 - R + i;
+        uint32_t v[WS];
+#pragma unroll
+        for (int j = 0; j < WS; j++) v[j] = (col >= 0 && col < W) ? d.img4_own[(size_t)(y - R + j) * W + col] : 0u;
+#pragma unroll
+        for (int j = 0; j < WS; j++) sA[j * SA + i] = v[j];
+    }
+    int Sa = 0;
+    long long va = 0;
+    if (narrow) {
+        Sa = d.S1_own[pix];
+        va = (long long)n * d.S2_own[pix] - (long long)Sa * Sa;
+    }
+    int best = -1;
+    double bestv = -1.0;
+    for (int lo = cmin; lo <= cmax; lo += NCC_CH) {
+        const int hi = min(lo + NCC_CH - 1, cmax);
+        __syncthreads();
+        // sB[j][i] <-> image column lo - R + i; mask / window sums of candidate columns lo .. hi (+G slack)
+        {
+            const int ndw = hi - lo + 1 + 2 * R + G;
+            for (int i = tid; i < ndw; i += NCC_TX) {
+                const int col = lo - R + i;
+                uint32_t v[WS];
+#pragma unroll
+                for (int j = 0; j < WS; j++) v[j] = (col >= 0 && col < W) ? d.img4_oth[(size_t)(y - R + j) * W + col] : 0u;
+#pragma unroll
+                for (int j = 0; j < WS; j++) sB[j * SB + i] = v[j];
+            }
+            for (int i = tid; i <= hi - lo + G; i += NCC_TX) {
+                const int col = lo + i;
+                const bool ok = col <= hi; // columns past hi are group padding: never scored
+                const size_t o = (size_t)y * W + (ok ? col : lo);
+                sM[i] = ok ? d.mask_oth[o] : (uint8_t)0;
+                sS1[i] = d.S1_oth[o];
+                sS2[i] = d.S2_oth[o];
+            }
+        }
+        __syncthreads();
+        if (narrow) {
+            const int c1 = min(Rr, hi);
+            for (int c0 = max(L, lo); c0 <= c1; c0 += G) {
+                uint32_t acc[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = 0u;
+                const int bo = c0 - lo;
+#pragma unroll 1 // one window row per iteration keeps the live set at ~2R+1+NB+G dwords (occupancy)
+                for (int j = 0; j < WS; j++) {
+                    uint32_t av[WS], bw[NB];
+#pragma unroll
+                    for (int m = 0; m < WS; m++) av[m] = sA[j * SA + tid + m];
+#pragma unroll
+                    for (int t = 0; t < NB; t++) bw[t] = sB[j * SB + bo + t];
+#pragma unroll
+                    for (int m = 0; m < WS; m++)
+#pragma unroll
+                        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_udot4(av[m], bw[g + m], acc[g], false);
+                }
+                ncc_score_group<R>(acc, c0, c1, sM + bo, sS1 + bo, sS2 + bo, Sa, va, bestv, best);
+            }
+        }
+    }
+    if (narrow && best != -1) d.d16_out[pix] = (int16_t)(best - x); // .cpp:219-222 / 301-302 / 563-564
+}
+
+// One workgroup per wide pixel (worklist of k_ncc_dot4), candidates spread over the 256 lanes.
+template <int R>
+__global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
+    constexpr int WS = 2 * R + 1, G = NCC_G, NB = G + WS - 1;
+    constexpr int n = WS * WS * 3;
+    __shared__ uint32_t sAw[WS * WS];
+    __shared__ double s_v[NCC_TX / 64];
+    __shared__ int s_c[NCC_TX / 64];
+    const int count = *a.ncc_cnt;
+    const int W = a.W;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const uint32_t ent = a.rf_list[item];
+        const DirArgs &d = a.d[ent >> 31];
+        const size_t pix = ent & 0x7fffffffu;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        int L, Rr;
         if (mode == 0) {
             L = d.oth.XL;
             Rr = d.oth.XR;
@@ -262,143 +419,73 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode, int 
         }
         L = max(L, R);
         Rr = min(Rr, W - 1 - R);
-        if (L > Rr) active = false;
-    }
-    if (threadIdx.x == 0) {
-        s_lohi[0] = 0x7fffffff;
-        s_lohi[1] = -1;
-    }
-    __syncthreads();
-    {
-        int lo = active ? L : 0x7fffffff, hi = active ? Rr : -1;
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = min(lo, __shfl_xor(lo, o));
-            hi = max(hi, __shfl_xor(hi, o));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&s_lohi[0], lo);
-            atomicMax(&s_lohi[1], hi);
-        }
-    }
-    __syncthreads();
-    const int cmin = s_lohi[0], cmax = s_lohi[1];
-    if (cmax < cmin) return;
-
-    const int rowBytes = W * 3;
-    // ---- stage own-view rows: LDS byte i of row j <-> image byte column baseA + i
-    const int baseA = (3 * (x0 - R)) & ~3;
-    {
-        const int nd = strideA >> 2;
-        for (int j = 0; j < WS; j++) {
-            const uint8_t *src = d.img_own + (size_t)(y - R + j) * rowBytes;
-            for (int i = threadIdx.x; i < nd; i += NCC_TX) {
-                const int b = baseA + 4 * i;
-                uint32_t v = 0;
-                if (b + 3 < rowBytes) __builtin_memcpy(&v, src + b, 4);
-                else
-                    for (int k = 0; k < 4; k++)
-                        if (b + k < rowBytes) v |= (uint32_t)src[b + k] << (8 * k);
-                sA[j * nd + i] = v;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- own window -> registers
-    uint32_t Areg[WS][NA];
-    int Sa = 0, Saa = 0;
-    long long va = 0;
-    if (active) {
-        const int oa = 3 * (x - R) - baseA;
-        const int wa = oa >> 2, sh = oa & 3;
-        const int nd = strideA >> 2;
-#pragma unroll
-        for (int j = 0; j < WS; j++) {
-            uint32_t raw[NA + 1];
-#pragma unroll
-            for (int m = 0; m <= NA; m++) raw[m] = sA[j * nd + wa + m];
-#pragma unroll
-            for (int m = 0; m < NA; m++) Areg[j][m] = __builtin_amdgcn_alignbyte(raw[m + 1], raw[m], sh);
-            Areg[j][NA - 1] &= LASTMASK;
-        }
-        Sa = d.S1_own[pix];
-        Saa = d.S2_own[pix];
-        va = (long long)n * Saa - (long long)Sa * Sa;
-    } else {
-#pragma unroll
-        for (int j = 0; j < WS; j++)
-#pragma unroll
-            for (int m = 0; m < NA; m++) Areg[j][m] = 0;
-    }
-    int best = -1;
-    double bestv = -1.0;
-
-    for (int lo = cmin; lo <= cmax; lo += NCC_CH) {
-        const int hi = min(lo + NCC_CH - 1, cmax);
-        const int baseB = (3 * (lo - R)) & ~3;
-        const int ndB = strideB >> 2;
+        __syncthreads(); // previous item done with sAw / s_v / s_c
+        if (tid < WS * WS) sAw[tid] = d.img4_own[(size_t)(y - R + tid / WS) * W + x - R + tid % WS];
+        const int Sa = d.S1_own[pix];
+        const long long va = (long long)n * d.S2_own[pix] - (long long)Sa * Sa;
         __syncthreads();
-        {
-            const int need = ((3 * (hi + R) + 3 - baseB) + 3 + 8) >> 2; // dwords incl. slack for the NA+1-th read
-            const int ndw = min(need, ndB);
+        double bv = -1.0;
+        int bc = 0x7fffffff;
+        for (int c0 = L + tid * G; c0 <= Rr; c0 += NCC_TX * G) {
+            uint32_t acc[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) acc[g] = 0u;
+#pragma unroll 1
             for (int j = 0; j < WS; j++) {
-                const uint8_t *src = d.img_oth + (size_t)(y - R + j) * rowBytes;
-                for (int i = threadIdx.x; i < ndw; i += NCC_TX) {
-                    const int b = baseB + 4 * i;
-                    uint32_t v = 0;
-                    if (b + 3 < rowBytes) __builtin_memcpy(&v, src + b, 4);
-                    else
-                        for (int k = 0; k < 4; k++)
-                            if (b + k < rowBytes) v |= (uint32_t)src[b + k] << (8 * k);
-                    sB[j * ndB + i] = v;
-                }
+                const uint32_t *brow = d.img4_oth + (size_t)(y - R + j) * W;
+                uint32_t av[WS], bw[NB];
+#pragma unroll
+                for (int m = 0; m < WS; m++) av[m] = sAw[j * WS + m];
+#pragma unroll
+                for (int t = 0; t < NB; t++) bw[t] = brow[min(c0 - R + t, W - 1)]; // clamped columns belong to c > Rr only
+#pragma unroll
+                for (int m = 0; m < WS; m++)
+#pragma unroll
+                    for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_udot4(av[m], bw[g + m], acc[g], false);
             }
-            for (int i = threadIdx.x; i <= hi - lo; i += NCC_TX) {
-                const size_t o = (size_t)y * W + lo + i;
-                sM[i] = d.mask_oth[o];
-                sS1[i] = d.S1_oth[o];
-                sS2[i] = d.S2_oth[o];
+            uint8_t mk[G];
+            int32_t s1[G], s2[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const size_t o = (size_t)y * W + min(c0 + g, Rr);
+                mk[g] = d.mask_oth[o];
+                s1[g] = d.S1_oth[o];
+                s2[g] = d.S2_oth[o];
             }
+            ncc_score_group<R>(acc, c0, Rr, mk, s1, s2, Sa, va, bv, bc);
+        }
+        // block argmax; equal scores -> the smaller column (the reference scans ascending with '>')
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o);
+            const int oc = __shfl_xor(bc, o);
+            if (ov > bv || (ov == bv && oc < bc)) {
+                bv = ov;
+                bc = oc;
+            }
+        }
+        if (lane == 0) {
+            s_v[wid] = bv;
+            s_c[wid] = bc;
         }
         __syncthreads();
-        if (active) {
-            const int c0 = max(L, lo), c1 = min(Rr, hi);
-            for (int c = c0; c <= c1; c++) {
-                if (sM[c - lo] != 255) continue;
-                const int ob = 3 * (c - R) - baseB;
-                const int wb = ob >> 2, shb = ob & 3;
-                uint32_t Sab = 0;
-#pragma unroll
-                for (int j = 0; j < WS; j++) {
-                    uint32_t raw[NA + 1];
-#pragma unroll
-                    for (int m = 0; m <= NA; m++) raw[m] = sB[j * ndB + wb + m];
-#pragma unroll
-                    for (int m = 0; m < NA; m++)
-                        Sab = __builtin_amdgcn_udot4(Areg[j][m], __builtin_amdgcn_alignbyte(raw[m + 1], raw[m], shb), Sab, false);
+        if (tid == 0) {
+            for (int w = 1; w < NCC_TX / 64; w++)
+                if (s_v[w] > bv || (s_v[w] == bv && s_c[w] < bc)) {
+                    bv = s_v[w];
+                    bc = s_c[w];
                 }
-                const int Sb = sS1[c - lo];
-                const int Sbb = sS2[c - lo];
-                const long long vb = (long long)n * Sbb - (long long)Sb * Sb;
-                const long long num = (long long)n * (long long)Sab - (long long)Sa * Sb;
-                double score = 0.0;
-                if (va > 0 && vb > 0) score = (double)num / sqrt((double)va * (double)vb);
-                if (score > bestv) {
-                    bestv = score;
-                    best = c;
-                }
-            }
+            if (bv > -1.0) d.d16_out[pix] = (int16_t)(bc - x);
         }
     }
-    if (active && best != -1) d.d16_out[pix] = (int16_t)(best - x);
 }
 
 template <int R>
 static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st) {
-    constexpr int WS = 2 * R + 1;
-    const int strideA = (((NCC_TX + 2 * R) * 3 + 3 + 12) + 3) & ~3;
-    const int strideB = (((NCC_CH + 2 * R) * 3 + 3 + 12) + 3) & ~3;
-    const size_t lds = 16 + (size_t)WS * strideA + (size_t)WS * strideB + (size_t)NCC_CH * 9 + 16;
-    hipLaunchKernelGGL(k_ncc_dot4<R>, grid, dim3(NCC_TX), lds, st, a, mode, strideA, strideB);
+    constexpr int WS = 2 * R + 1, SA = NCC_TX + 2 * R, SB = NCC_CH + 2 * R + NCC_G + 3;
+    const size_t lds = 16 + (size_t)WS * (SA + SB) * 4 + (size_t)(NCC_CH + NCC_G) * 9 + 16;
+    (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_ncc_dot4<R>, grid, dim3(NCC_TX), lds, st, a, mode);
+    hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), 0, st, a, mode);
 }
 
 void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
@@ -409,8 +496,7 @@ void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
     }
     if (rows <= 0 || cols <= 0) return;
     dim3 grid((cols + NCC_TX - 1) / NCC_TX, rows, a.ndir);
-    static const bool force_bytes = getenv("RSM_NCC_BYTES") != nullptr; // A/B switch for validation
-    if (!force_bytes) {
+    if (!a.opt_ncc_bytes) {
         switch (a.r) {
         case 1: return launch_dot4<1>(a, mode, grid, st);
         case 2: return launch_dot4<2>(a, mode, grid, st);

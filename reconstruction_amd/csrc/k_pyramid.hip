@@ -178,3 +178,21 @@ void launch_box_sums(const uint8_t *img, int W, int H, int r, int32_t *tmp1, int
     hipLaunchKernelGGL(k_box_h, grid, dim3(256), 0, st, img, W, H, r, tmp1, tmp2);
     hipLaunchKernelGGL(k_box_v, grid, dim3(256), 0, st, tmp1, tmp2, W, H, r, S1, S2);
 }
+
+// ---------------------------------------------------------------- BGR -> BGRX (one dword per pixel)
+// The NCC kernels read both views as dwords: a (2R+1)-pixel window row is 2R+1 aligned dwords and the
+// zero X byte adds nothing to the v_dot4_u32_u8 sums.
+__global__ void k_bgr_to_bgrx(const uint8_t *__restrict__ img, size_t npix, uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < npix; i += stride) {
+        const uint8_t *p = img + 3 * i;
+        out[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    }
+}
+void launch_bgr_to_bgrx(const uint8_t *img, int W, int H, uint32_t *out, hipStream_t st) {
+    const size_t n = (size_t)W * H;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_bgr_to_bgrx, dim3((unsigned)blocks), dim3(256), 0, st, img, n, out);
+}

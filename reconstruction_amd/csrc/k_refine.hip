@@ -65,53 +65,149 @@ __device__ __forceinline__ double refine_update(int mode, double dC, double dE, 
     return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
 }
 
+// Data term (pwp, delta = pdp - dCenter) of pixel (x, y) for iMatch = key: .cpp:624-650.
+__device__ __forceinline__ void refine_data_term(const DirArgs &d, int W, int H, int x, int y, int key, double &pwp,
+                                                 double &delta) {
+    // Bit-faithful fp64 restatement of CManageData::WindowToVec (CManageData.cpp:81-90) + arma::dot on
+    // the 27-element windows, same gather order (byte column outer, row inner) and the same
+    // two-accumulator sums as Armadillo (op_dot_meat.hpp:20-55, fn_norm.hpp:99-130): the sweep is
+    // ill-conditioned at int(d - 1.5) boundaries, so xi must match the reference to the last bit.
+    const uint8_t *A = d.img_own, *B = d.img_oth;
+    const long long total = (long long)W * H * 3;
+    const int rowB = W * 3;
+    int aw[27], bw[3][15];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint8_t *pa = A + (size_t)(y - 1 + j) * rowB + (size_t)(x - 1) * 3;
+        const long long bbase = (long long)(y - 1 + j) * rowB + (long long)key * 3;
+#pragma unroll
+        for (int i = 0; i < 9; i++) aw[i * 3 + j] = pa[i];
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            const long long fi = bbase + i;
+            bw[j][i] = (fi >= 0 && fi < total) ? (int)B[fi] : 0;
+        }
+    }
+    int SL = 0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) SL += aw[k];
+    const double meanL = (double)SL / 27.0; // accumulate() of integers is exact; one rounding in the divide
+    double uL[27];
+    double n1 = 0.0, n2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        uL[k] = (double)aw[k] - meanL;
+        if (k & 1) n2 += uL[k] * uL[k];
+        else n1 += uL[k] * uL[k];
+    }
+    double normL = sqrt(n1 + n2);
+    if (normL == 0) normL = 1; // CManageData.cpp:89
+    double xi[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int SR = 0;
+#pragma unroll
+        for (int k = 0; k < 27; k++) SR += bw[k % 3][k / 3 + 3 * c];
+        const double meanR = (double)SR / 27.0;
+        double m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            const double ur = (double)bw[k % 3][k / 3 + 3 * c] - meanR;
+            if (k & 1) {
+                m2 += ur * ur;
+                d2 += uL[k] * ur;
+            } else {
+                m1 += ur * ur;
+                d1 += uL[k] * ur;
+            }
+        }
+        double normR = sqrt(m1 + m2);
+        if (normR == 0) normR = 1;
+        xi[c] = (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
+    }
+    int index = xi[0] >= xi[1]; // .cpp:631-632
+    if (xi[index] > xi[2]) index = 2;
+    if (index == 0) {
+        pwp = xi[1] - xi[0];
+        delta = -0.5;
+    } else if (index == 2) {
+        pwp = xi[1] - xi[2];
+        delta = 0.5;
+    } else {
+        pwp = 0.5 * (xi[0] + xi[2]) - xi[1];
+        delta = (pwp == 0) ? 0.0 : 0.5 * (xi[0] - xi[2]) / (xi[0] + xi[2] - 2 * xi[1]);
+    }
+}
+
 // Light sweep kernel: one pixel per thread, every load issued up front. A pixel whose cached data term
 // belongs to another iMatch (cache miss) is appended to the sweep's worklist instead of being updated
 // here; k_refine_miss handles it before the next sweep starts (stream order).
 // TOP only gives the top level's launches (the dominant kernel) their own name in rocprof traces.
+// RF_PPT vertically adjacent pixels per thread: more loads in flight per wave (the kernel is latency-bound)
 template <int TOP>
 __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     const DirArgs &d = a.d[blockIdx.z];
     const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = d.own.YL + 1 + blockIdx.y;
-    const bool inside = !(x > d.own.XR - 1 || y > d.own.YR - 1);
+    const int y0 = d.own.YL + 1 + blockIdx.y * RF_PPT;
     const int W = a.W;
+    const bool colok = x <= d.own.XR - 1;
+    const int xs = colok ? x : d.own.XL + 1; // out-of-range lanes shadow a valid column (no stores)
     const double *__restrict__ in = d.f64_a;
     double *__restrict__ out = d.f64_b;
-    const size_t pix = inside ? (size_t)y * W + x : (size_t)(d.own.YL + 1) * W + d.own.XL + 1;
-    const double dC = in[pix];
-    const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
-    const int key = (int)(dC - 1.5) + x; // .cpp:625
-    // 2-way cache indexed by key parity: the iteration settles into flipping between two ADJACENT
-    // iMatch values for most pixels, so both data terms stay resident and misses die out.
-    const size_t cpix = pix + (size_t)(key & 1) * a.rf_stride;
-    const int ckey = d.rf_key[cpix];
-    const double pwp = d.rf_pwp[cpix];
-    const double delta = d.rf_delta[cpix];
-    const bool live = inside && dC != (double)NOMATCH; // .cpp:613
-    const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
-                     (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
-    const bool miss = live && mode != 0 && ckey != key;
-    // wave-aggregated append of the missing pixels to this sweep's worklist
-    const unsigned long long mm = __ballot(miss);
-    if (mm) {
-        const int lane = threadIdx.x & 63;
-        const int leader = __builtin_ctzll(mm);
-        int base = 0;
-        // sharded: one atomic counter serves ~88 appends/us, ~180k waves per sweep would serialise on it
-        const int shard = (blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & (RF_NSHARD - 1);
-        if (lane == leader) base = atomicAdd(&a.rf_cnt[(a.flag2 & 1) * RF_NSHARD + shard], __popcll(mm));
-        base = __shfl(base, leader);
-        if (miss)
-            a.rf_list[(size_t)shard * a.rf_cap + base + __popcll(mm & ((1ull << lane) - 1ull))] =
-                (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
+    const int ylast = d.own.YR - 1;
+    // phase 1: every state load of the RF_PPT pixels
+    double col[RF_PPT + 2], dE[RF_PPT], dW[RF_PPT];
+#pragma unroll
+    for (int i = 0; i < RF_PPT + 2; i++) {
+        const int yy = min(y0 - 1 + i, ylast + 1);
+        col[i] = in[(size_t)yy * W + xs];
     }
-    if (!live || miss) return;
-    out[pix] = (mode == 0) ? dC /* .cpp:655 */ : refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+#pragma unroll
+    for (int i = 0; i < RF_PPT; i++) {
+        const int yy = min(y0 + i, ylast);
+        dE[i] = in[(size_t)yy * W + xs + 1];
+        dW[i] = in[(size_t)yy * W + xs - 1];
+    }
+    // phase 2: the cache way each pixel needs (2-way cache indexed by the parity of int(d - 1.5) (so neighbouring pixels share cache lines): the iteration settles
+    // into flipping between two ADJACENT iMatch values, so both data terms stay resident)
+    int key[RF_PPT], ckey[RF_PPT];
+    double pwp[RF_PPT], delta[RF_PPT];
+    size_t pix[RF_PPT];
+#pragma unroll
+    for (int i = 0; i < RF_PPT; i++) {
+        const int yy = min(y0 + i, ylast);
+        pix[i] = (size_t)yy * W + xs;
+        key[i] = (int)(col[i + 1] - 1.5) + xs; // .cpp:625
+        const size_t cpix = pix[i] + (size_t)((key[i] - xs) & 1) * a.rf_stride;
+        ckey[i] = d.rf_key[cpix];
+        pwp[i] = d.rf_pwp[cpix];
+        delta[i] = d.rf_delta[cpix];
+    }
+    const int lane = threadIdx.x & 63;
+    const int shard = (blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & (RF_NSHARD - 1);
+#pragma unroll
+    for (int i = 0; i < RF_PPT; i++) {
+        const double dC = col[i + 1], dN = col[i], dS = col[i + 2];
+        const bool live = colok && (y0 + i <= ylast) && dC != (double)NOMATCH; // .cpp:613
+        const int mode = (int)(dE[i] != (double)NOMATCH && dW[i] != (double)NOMATCH) +
+                         (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
+        const bool miss = live && mode != 0 && ckey[i] != key[i];
+        // wave-aggregated append of the missing pixels to this sweep's (sharded) worklist
+        const unsigned long long mm = __ballot(miss);
+        if (mm) {
+            const int leader = __builtin_ctzll(mm);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&a.rf_cnt[(a.flag2 & 1) * RF_NSHARD + shard], __popcll(mm));
+            base = __shfl(base, leader);
+            if (miss)
+                a.rf_list[(size_t)shard * a.rf_cap + base + __popcll(mm & ((1ull << lane) - 1ull))] =
+                    (uint32_t)pix[i] | ((uint32_t)blockIdx.z << 31);
+        }
+        if (live && !miss)
+            out[pix[i]] = (mode == 0) ? dC /* .cpp:655 */ : refine_update(mode, dC, dE[i], dW[i], dN, dS, pwp[i], delta[i], a.ws);
+    }
 }
 
-// Worklist kernel: recomputes the data term of the listed pixels, refreshes their cache and writes
-// their sweep result.
 // FULL = 1 is the first sweep of a level: every cache entry is empty, so instead of a worklist the
 // kernel walks the whole interior (and also does the mode 0 copy-through).
 template <int FULL>
@@ -150,84 +246,47 @@ __global__ __launch_bounds__(256) void k_refine_miss(StageArgs a) {
         }
         const int key = (int)(dC - 1.5) + x;
         double pwp, delta;
-        {
-        // Bit-faithful fp64 restatement of CManageData::WindowToVec (CManageData.cpp:81-90) + arma::dot on
-        // the 27-element windows, same gather order (byte column outer, row inner) and the same
-        // two-accumulator sums as Armadillo (op_dot_meat.hpp:20-55, fn_norm.hpp:99-130): the sweep is
-        // ill-conditioned at int(d - 1.5) boundaries, so xi must match the reference to the last bit.
-        const uint8_t *A = d.img_own, *B = d.img_oth;
-        const long long total = (long long)W * H * 3;
-        const int rowB = W * 3;
-        int aw[27], bw[3][15];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint8_t *pa = A + (size_t)(y - 1 + j) * rowB + (size_t)(x - 1) * 3;
-            const long long bbase = (long long)(y - 1 + j) * rowB + (long long)key * 3;
-#pragma unroll
-            for (int i = 0; i < 9; i++) aw[i * 3 + j] = pa[i];
-#pragma unroll
-            for (int i = 0; i < 15; i++) {
-                const long long fi = bbase + i;
-                bw[j][i] = (fi >= 0 && fi < total) ? (int)B[fi] : 0;
-            }
-        }
-        int SL = 0;
-#pragma unroll
-        for (int k = 0; k < 27; k++) SL += aw[k];
-        const double meanL = (double)SL / 27.0; // accumulate() of integers is exact; one rounding in the divide
-        double uL[27];
-        double n1 = 0.0, n2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 27; k++) {
-            uL[k] = (double)aw[k] - meanL;
-            if (k & 1) n2 += uL[k] * uL[k];
-            else n1 += uL[k] * uL[k];
-        }
-        double normL = sqrt(n1 + n2);
-        if (normL == 0) normL = 1; // CManageData.cpp:89
-        double xi[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            int SR = 0;
-#pragma unroll
-            for (int k = 0; k < 27; k++) SR += bw[k % 3][k / 3 + 3 * c];
-            const double meanR = (double)SR / 27.0;
-            double m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 27; k++) {
-                const double ur = (double)bw[k % 3][k / 3 + 3 * c] - meanR;
-                if (k & 1) {
-                    m2 += ur * ur;
-                    d2 += uL[k] * ur;
-                } else {
-                    m1 += ur * ur;
-                    d1 += uL[k] * ur;
-                }
-            }
-            double normR = sqrt(m1 + m2);
-            if (normR == 0) normR = 1;
-            xi[c] = (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
-        }
-        int index = xi[0] >= xi[1]; // .cpp:631-632
-        if (xi[index] > xi[2]) index = 2;
-        if (index == 0) {
-            pwp = xi[1] - xi[0];
-            delta = -0.5;
-        } else if (index == 2) {
-            pwp = xi[1] - xi[2];
-            delta = 0.5;
-        } else {
-            pwp = 0.5 * (xi[0] + xi[2]) - xi[1];
-            delta = (pwp == 0) ? 0.0 : 0.5 * (xi[0] - xi[2]) / (xi[0] + xi[2] - 2 * xi[1]);
-        }
-        }
-        const size_t cpix = pix + (size_t)(key & 1) * a.rf_stride;
+        refine_data_term(d, W, H, x, y, key, pwp, delta);
+        const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
         d.rf_key[cpix] = key;
         d.rf_pwp[cpix] = pwp;
         d.rf_delta[cpix] = delta;
         d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
         if (FULL) return;
     }
+}
+
+// Small levels are launch-latency bound: one fused kernel (data term inline on a miss) per sweep.
+__global__ __launch_bounds__(256) void k_refine_fused(StageArgs a) {
+    const DirArgs &d = a.d[blockIdx.z];
+    const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = d.own.YL + 1 + blockIdx.y;
+    if (x > d.own.XR - 1 || y > d.own.YR - 1) return;
+    const int W = a.W, H = a.H;
+    const double *__restrict__ in = d.f64_a;
+    const size_t pix = (size_t)y * W + x;
+    const double dC = in[pix];
+    if (dC == (double)NOMATCH) return;
+    const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
+    const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                     (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
+    if (mode == 0) {
+        d.f64_b[pix] = dC;
+        return;
+    }
+    const int key = (int)(dC - 1.5) + x;
+    const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
+    double pwp, delta;
+    if (d.rf_key[cpix] == key) {
+        pwp = d.rf_pwp[cpix];
+        delta = d.rf_delta[cpix];
+    } else {
+        refine_data_term(d, W, H, x, y, key, pwp, delta);
+        d.rf_key[cpix] = key;
+        d.rf_pwp[cpix] = pwp;
+        d.rf_delta[cpix] = delta;
+    }
+    d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
 }
 
 static void launch_refine_sweep_impl(const StageArgs &a, dim3 grid, hipStream_t st);
@@ -241,16 +300,23 @@ void launch_refine_sweep(const StageArgs &a, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return;
     const dim3 grid((cols + 255) / 256, rows, a.ndir);
     StageArgs b = a;
-    b.rf_cap = (int)((((long long)grid.x * grid.y * grid.z + RF_NSHARD - 1) / RF_NSHARD) * 256);
+    // worklist shard capacity: every light-kernel workgroup of a shard could append all its pixels
+    const long long lblocks = (long long)grid.x * ((grid.y + RF_PPT - 1) / RF_PPT) * grid.z;
+    b.rf_cap = (int)(((lblocks + RF_NSHARD - 1) / RF_NSHARD) * 256 * RF_PPT);
     return launch_refine_sweep_impl(b, grid, st);
 }
 
 static void launch_refine_sweep_impl(const StageArgs &a, dim3 grid, hipStream_t st) {
+    if ((long long)grid.x * grid.y * grid.z * 256 < a.opt_refine_fused_max) { // small level
+        hipLaunchKernelGGL(k_refine_fused, grid, dim3(256), 0, st, a);
+        return;
+    }
     if (a.flag2 == 0) { // first sweep: everything misses
         hipLaunchKernelGGL(k_refine_miss<1>, grid, dim3(256), 0, st, a);
         return;
     }
-    if (a.flag) hipLaunchKernelGGL(k_refine_sweep<1>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_refine_sweep<0>, grid, dim3(256), 0, st, a);
+    const dim3 lgrid(grid.x, (grid.y + RF_PPT - 1) / RF_PPT, grid.z);
+    if (a.flag) hipLaunchKernelGGL(k_refine_sweep<1>, lgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_refine_sweep<0>, lgrid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_refine_miss<0>, dim3(RF_NSHARD * RF_SUB), dim3(256), 0, st, a);
 }

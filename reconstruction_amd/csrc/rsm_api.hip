@@ -61,6 +61,7 @@ struct rsm_ctx {
     std::vector<void *> allocs;
     int *d_margins = nullptr; // N*2*4 ints
     int32_t *S1[2]{}, *S2[2]{}, *tmp1 = nullptr, *tmp2 = nullptr;
+    uint32_t *img4[2]{};
     int16_t *d16a[2]{}, *d16b[2]{}, *BL[2]{}, *BR[2]{};
     double *f64[3][2]{};
     int32_t *nv[2]{};
@@ -82,6 +83,10 @@ struct rsm_ctx {
     double *res_disp[2]{};
     int64_t n_points = 0;
     int64_t v_top = 0;
+
+    // options (rsm_set_option)
+    long long opt_refine_fused_max = 1ll << 20;
+    int opt_ncc_bytes = 0;
 
     // profiling
     bool profile = false;
@@ -226,6 +231,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->tmp2, px);
     for (int v = 0; v < 2; v++) {
         DALLOC(c, c->S1[v], px);
+        DALLOC(c, c->img4[v], px);
         DALLOC(c, c->S2[v], px);
         DALLOC(c, c->d16a[v], px);
         DALLOC(c, c->d16b[v], px);
@@ -237,8 +243,8 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         DALLOC(c, c->rf_pwp[v], 2 * px);
         DALLOC(c, c->rf_delta[v], 2 * px);
     }
-    DALLOC(c, c->rf_cnt, 2 * RF_NSHARD);
-    DALLOC(c, c->rf_list, 2 * (size_t)(in->width + 256) * in->height + RF_NSHARD * 256);
+    DALLOC(c, c->rf_cnt, 2 * RF_NSHARD + 16);
+    DALLOC(c, c->rf_list, RF_LIST_ENTRIES(in->width, in->height, 2));
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->d_j1, 4096);
     DALLOC(c, c->d_j2, 4096);
@@ -298,6 +304,14 @@ static void prof_end(rsm_ctx *c, int stage, int launches, double bytes) {
     c->prof_bytes[stage] += bytes;
 }
 
+extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
+    if (!c || !name) return RSM_E_INVALID;
+    if (!strcmp(name, "refine_fused_max")) c->opt_refine_fused_max = value;
+    else if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
+    else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
+    return RSM_OK;
+}
+
 extern "C" int rsm_profile_enable(rsm_ctx *c, int on) {
     if (!c) return RSM_E_INVALID;
     c->profile = on != 0;
@@ -328,12 +342,17 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.ws = c->in.ws;
     a.rf_cnt = c->rf_cnt;
     a.rf_list = c->rf_list;
+    a.ncc_cnt = c->rf_cnt + 2 * RF_NSHARD;
     a.rf_stride = c->cap_px;
+    a.opt_refine_fused_max = c->opt_refine_fused_max;
+    a.opt_ncc_bytes = c->opt_ncc_bytes;
     for (int v = 0; v < 2; v++) {
         DirArgs &d = a.d[v];
         const int o = 1 - v;
         d.img_own = c->img[k][v];
         d.img_oth = c->img[k][o];
+        d.img4_own = c->img4[v];
+        d.img4_oth = c->img4[o];
         d.mask_own = c->msk[k][v];
         d.mask_oth = c->msk[k][o];
         d.S1_own = c->S1[v];
@@ -406,8 +425,11 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             return set_err(c, RSM_E_DEGENERATE_MARGIN, "level %d: YL>=YR || XL>=XR", k);
 
         prof_begin(c, ST_BOXSUM);
-        for (int v = 0; v < 2; v++) launch_box_sums(c->img[k][v], W, H, r, c->tmp1, c->tmp2, c->S1[v], c->S2[v], st);
-        prof_end(c, ST_BOXSUM, 4, 0);
+        for (int v = 0; v < 2; v++) {
+            launch_box_sums(c->img[k][v], W, H, r, c->tmp1, c->tmp2, c->S1[v], c->S2[v], st);
+            launch_bgr_to_bgrx(c->img[k][v], W, H, c->img4[v], st);
+        }
+        prof_end(c, ST_BOXSUM, 6, 0);
 
         // ---- initial match (.cpp:53-62) -> d16a
         prof_begin(c, ST_INITIAL_MATCH);
@@ -700,6 +722,9 @@ namespace {
 // uploads the images/masks of one direction and builds the window-sum tables
 struct MatchBufs {
     uint8_t *io, *it, *mo, *mt;
+    uint32_t *i4o, *i4t;
+    uint32_t *wl; // wide-pixel worklist + counter of the NCC kernels
+    int32_t *wc;
     int32_t *S1o, *S2o, *S1t, *S2t;
 };
 bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_oth, const uint8_t *mask_own,
@@ -709,6 +734,10 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     b.it = t.up(img_oth, px * 3);
     b.mo = t.up(mask_own, px);
     b.mt = t.up(mask_oth, px);
+    b.wl = t.alloc<uint32_t>(px + 64);
+    b.wc = t.alloc<int32_t>(16);
+    b.i4o = t.alloc<uint32_t>(px);
+    b.i4t = t.alloc<uint32_t>(px);
     b.S1o = t.alloc<int32_t>(px);
     b.S2o = t.alloc<int32_t>(px);
     b.S1t = t.alloc<int32_t>(px);
@@ -717,10 +746,14 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     if (!t.ok) return false;
     launch_box_sums(b.io, W, H, r, t1, t2, b.S1o, b.S2o, c->stream);
     launch_box_sums(b.it, W, H, r, t1, t2, b.S1t, b.S2t, c->stream);
+    launch_bgr_to_bgrx(b.io, W, H, b.i4o, c->stream);
+    launch_bgr_to_bgrx(b.it, W, H, b.i4t, c->stream);
     return true;
 }
-StageArgs one_dir(int W, int H, int r, const rsm_boundary *own, const rsm_boundary *oth) {
+StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, const rsm_boundary *oth) {
     StageArgs a{};
+    a.opt_refine_fused_max = c->opt_refine_fused_max;
+    a.opt_ncc_bytes = c->opt_ncc_bytes;
     a.ndir = 1;
     a.W = W;
     a.H = H;
@@ -730,9 +763,13 @@ StageArgs one_dir(int W, int H, int r, const rsm_boundary *own, const rsm_bounda
     return a;
 }
 void bind_match(StageArgs &a, const MatchBufs &b) {
+    a.rf_list = b.wl;
+    a.ncc_cnt = b.wc;
     DirArgs &d = a.d[0];
     d.img_own = b.io;
     d.img_oth = b.it;
+    d.img4_own = b.i4o;
+    d.img4_oth = b.i4t;
     d.mask_own = b.mo;
     d.mask_oth = b.mt;
     d.S1_own = b.S1o;
@@ -751,7 +788,7 @@ extern "C" int rsm_stage_initial_match(rsm_ctx *c, const uint8_t *img_own, const
     const size_t px = (size_t)W * H;
     MatchBufs b{};
     if (!setup_match(c, t, img_own, img_oth, mask_own, mask_oth, W, H, r, b)) return finish(c, t);
-    StageArgs a = one_dir(W, H, r, own, oth);
+    StageArgs a = one_dir(c, W, H, r, own, oth);
     bind_match(a, b);
     a.offset = offset;
     a.Wp = Wp;
@@ -782,7 +819,7 @@ extern "C" int rsm_stage_smooth(rsm_ctx *c, int16_t *disp, int W, int H, const r
     if (!stage_ok(c, W, H) || !disp || !own) return RSM_E_INVALID;
     Tmp t(c);
     const size_t px = (size_t)W * H;
-    StageArgs a = one_dir(W, H, 0, own, nullptr);
+    StageArgs a = one_dir(c, W, H, 0, own, nullptr);
     a.d[0].d16_in = t.up(disp, px);
     a.d[0].d16_out = t.alloc<int16_t>(px);
     if (!t.ok) return finish(c, t);
@@ -795,7 +832,7 @@ extern "C" int rsm_stage_order(rsm_ctx *c, int16_t *disp, int W, int H, const rs
     if (!stage_ok(c, W, H) || !disp || !own) return RSM_E_INVALID;
     Tmp t(c);
     const size_t px = (size_t)W * H;
-    StageArgs a = one_dir(W, H, 0, own, nullptr);
+    StageArgs a = one_dir(c, W, H, 0, own, nullptr);
     a.d[0].d16_in = a.d[0].d16_out = t.up(disp, px);
     if (!t.ok) return finish(c, t);
     launch_order(a, c->stream);
@@ -835,7 +872,7 @@ extern "C" int rsm_stage_set_boundary(rsm_ctx *c, const int16_t *disp, const uin
     if (degenerate(to_mg(*own))) return set_err(c, RSM_E_DEGENERATE_MARGIN, "YL>=YR || XL>=XR");
     Tmp t(c);
     const size_t px = (size_t)W * H;
-    StageArgs a = one_dir(W, H, 0, own, oth);
+    StageArgs a = one_dir(c, W, H, 0, own, oth);
     a.d[0].d16_in = t.up(disp, px);
     a.d[0].mask_own = t.up(mask_own, px);
     a.d[0].BL = t.alloc<int16_t>(px);
@@ -858,7 +895,7 @@ extern "C" int rsm_stage_rematch(rsm_ctx *c, const uint8_t *img_own, const uint8
     const size_t px = (size_t)W * H;
     MatchBufs b{};
     if (!setup_match(c, t, img_own, img_oth, mask_own, mask_oth, W, H, r, b)) return finish(c, t);
-    StageArgs a = one_dir(W, H, r, own, oth);
+    StageArgs a = one_dir(c, W, H, r, own, oth);
     bind_match(a, b);
     a.d[0].d16_in = a.d[0].d16_out = t.up(disp, px);
     a.d[0].BL = t.alloc<int16_t>(px);
@@ -875,7 +912,7 @@ extern "C" int rsm_stage_median(rsm_ctx *c, int16_t *disp, const uint8_t *mask_o
     if (!stage_ok(c, W, H) || !disp || !mask_own || !own) return RSM_E_INVALID;
     Tmp t(c);
     const size_t px = (size_t)W * H;
-    StageArgs a = one_dir(W, H, 0, own, nullptr);
+    StageArgs a = one_dir(c, W, H, 0, own, nullptr);
     a.d[0].d16_in = t.up(disp, px);
     a.d[0].mask_own = t.up(mask_own, px);
     a.d[0].d16_out = t.alloc<int16_t>(px);
@@ -891,7 +928,7 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     if (!stage_ok(c, W, H) || !disp_in || !img_own || !img_oth || !own || !disp_out || iterations < 0) return RSM_E_INVALID;
     Tmp t(c);
     const size_t px = (size_t)W * H;
-    StageArgs a = one_dir(W, H, 0, own, nullptr);
+    StageArgs a = one_dir(c, W, H, 0, own, nullptr);
     a.ws = ws;
     DirArgs &d = a.d[0];
     d.d16_in = t.up(disp_in, px);
@@ -903,7 +940,7 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.rf_delta = t.alloc<double>(2 * px);
     a.rf_stride = px;
     a.rf_cnt = t.alloc<int32_t>(2 * RF_NSHARD);
-    a.rf_list = t.alloc<uint32_t>((size_t)(W + 256) * H + RF_NSHARD * 256);
+    a.rf_list = t.alloc<uint32_t>(RF_LIST_ENTRIES(W, H, 1));
     if (!t.ok) return finish(c, t);
     if (iterations > RF_MAX_SWEEPS) return set_err(c, RSM_E_INVALID, "iterations");
     d.f64_a = A;
@@ -974,7 +1011,7 @@ extern "C" int rsm_bench_ncc(rsm_ctx *c, int W, int H, int r, int cands, int ite
     MatchBufs b{};
     if (!setup_match(c, t, hi.data(), hi.data(), hm.data(), hm.data(), W, H, r, b)) return finish(c, t);
     rsm_boundary m{r, H - 1 - r, r, W - 1 - r, W - 2 * r, H - 2 * r};
-    StageArgs a = one_dir(W, H, r, &m, &m);
+    StageArgs a = one_dir(c, W, H, r, &m, &m);
     bind_match(a, b);
     std::vector<int16_t> hl(px), hr(px);
     for (int y = 0; y < H; y++)

@@ -10,6 +10,9 @@
 #define RF_MAX_SWEEPS 1024
 #define RF_NSHARD 256 // refine worklist shards (power of 2)
 #define RF_SUB 4      // worklist blocks per shard
+#define RF_PPT 4      // pixels per thread of the light sweep kernel
+// worklist capacity (entries) for ndir directions of a WxH level
+#define RF_LIST_ENTRIES(W, H, ndir) ((size_t)(ndir) * ((size_t)(W) + 256) * ((size_t)(H) + RF_PPT) + (size_t)RF_NSHARD * 256 * RF_PPT)
 
 // Margin of one view at one level (struct Boundary, CManageData.h:10-14, without width/height).
 struct Mg {
@@ -20,6 +23,7 @@ struct Mg {
 // (IsZeroOne = (v == 0) in the reference's signatures).
 struct DirArgs {
     const uint8_t *img_own, *img_oth;   // BGR interleaved, stride 3*W
+    const uint32_t *img4_own, *img4_oth; // BGRX copies (one dword per pixel), stride W
     const uint8_t *mask_own, *mask_oth; // stride W
     const int32_t *S1_own, *S2_own;     // (2r+1)^2*3 window sums of bytes / squared bytes, centre-indexed
     const int32_t *S1_oth, *S2_oth;
@@ -45,8 +49,11 @@ struct StageArgs {
     int flag2;   // refine: sweep index
     int rf_cap;        // refine: worklist entries per shard
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
+    long long opt_refine_fused_max; // refine: levels with fewer pixel-threads use the fused kernel
+    int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int32_t *rf_cnt;   // refine: worklist counters [2 sets][RF_NSHARD]
-    uint32_t *rf_list; // refine: worklist of (dir << 31 | pixel index)
+    uint32_t *rf_list; // refine / NCC: worklist of (dir << 31 | pixel index)
+    int32_t *ncc_cnt;  // NCC: number of wide pixels in rf_list
 };
 
 // ---- launchers (each enqueues on `st`, no sync) ----------------------------------------------
@@ -56,6 +63,7 @@ void launch_fill_i32(int32_t *p, size_t n, int32_t v, hipStream_t st);
 void launch_pyr_down(const uint8_t *src, int W, int H, int C, uint8_t *dst, hipStream_t st);
 // out4 = {XL, XR, YL, YR} initialised by the kernel launcher (inverted defaults, .cpp:1014-1017)
 void launch_find_margin(const uint8_t *mask, int W, int H, int r, int *out4, hipStream_t st);
+void launch_bgr_to_bgrx(const uint8_t *img, int W, int H, uint32_t *out, hipStream_t st);
 void launch_box_sums(const uint8_t *img, int W, int H, int r, int32_t *tmp1, int32_t *tmp2,
                      int32_t *S1, int32_t *S2, hipStream_t st);
 

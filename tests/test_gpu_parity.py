@@ -124,9 +124,11 @@ def test_integer_stages_bit_exact(ctx, name):
     assert not fails, "\n".join(fails[:12])
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("name", list(CASES))
-def test_fp64_stages(ctx, name):
+def test_fp64_stages(ctx, name, split):
     cfg, rec, fin = stages(name)
+    ctx.set_option("refine_fused_max", 0 if split else 1 << 20)
     imgs, msks = fin["imgs"], fin["msks"]
     worst = 0.0
     for q in rec:
@@ -140,6 +142,7 @@ def test_fp64_stages(ctx, name):
             g0, g1 = ctx.uniqueness(q["inp"][0], q["inp"][1], mg[0], mg[1])
             assert np.array_equal(g0, q["out"][0]), diff_report("uniq64 d0 L%d" % k, g0, q["out"][0])
             assert np.array_equal(g1, q["out"][1]), diff_report("uniq64 d1 L%d" % k, g1, q["out"][1])
+    ctx.set_option("refine_fused_max", 1 << 20)
     print("worst refine rel err", worst)
 
 
@@ -258,3 +261,20 @@ def test_order_constraint_heavy_crossings(ctx):
     own = (2, H - 3, 2, W - 3, W - 4, H - 4)
     a, b = ctx.order_constraint(d, own), orc.order_constraint(d, own)
     assert np.array_equal(a, b), diff_report("order heavy", a, b)
+
+
+@pytest.mark.parametrize("opt", [("refine_fused_max", 0), ("refine_fused_max", 1 << 40), ("ncc_bytes", 1)])
+def test_kernel_variants_give_identical_results(ctx, opt):
+    """The split (light + worklist) and fused refine kernels, and the dot4 / byte-wise NCC kernels, are
+    interchangeable bit for bit."""
+    cfg = synth.config_small(**CASES["s320x160_occluded_neg_r4"])
+    base = ctx.match_pair(cfg)
+    ctx.set_option(*opt)
+    try:
+        alt = ctx.match_pair(cfg)
+    finally:
+        ctx.set_option("refine_fused_max", 1 << 20)
+        ctx.set_option("ncc_bytes", 0)
+    for v in range(2):
+        assert np.array_equal(base.disparity[v], alt.disparity[v]), opt
+    assert np.array_equal(base.xyz, alt.xyz, equal_nan=True)
