@@ -1,0 +1,63 @@
+"""The C-ABI library: loads on a CPU-only box, exports exactly what include/rsm.h declares, and refuses to
+run without a GPU (no CPU fallback anywhere in the product path)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rsm.h")
+
+
+def declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_what_the_binding_lists():
+    from reconstruction_amd import _lib
+    assert declared() == sorted(_lib.EXPORTS)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from reconstruction_amd import _lib
+    lib = _lib.load()
+    for name in declared():
+        assert hasattr(lib, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (rsm_[a-z0-9_]+)", out))
+    assert exported == set(declared()), exported ^ set(declared())
+    assert lib.rsm_version().startswith(b"rsm-mi355")
+    assert lib.rsm_profile_stage_count() >= 10
+
+
+def test_struct_layouts_match_the_header():
+    from reconstruction_amd import _lib
+    # rsm_boundary = 6 ints; rsm_pair_in: 4 ptr + 4 int + (pad) double + 2 int + 28 double + int
+    assert C.sizeof(_lib.Boundary) == 24
+    assert C.sizeof(_lib.PairIn) == 4 * 8 + 4 * 4 + 8 + 2 * 4 + 28 * 8 + 8
+    assert C.sizeof(_lib.PairOut) == 2 * 8 + 2 * 24 + 8 + 8 + 8 + 8 + 8
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from reconstruction_amd import Context, RsmError
+    with pytest.raises(RsmError):
+        Context(0)
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "reconstruction_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                # comments may mention the oracle; nothing may import, include, link or load it
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+                assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", txt), f
+                assert "liborc" not in txt and "orc_match_pair" not in txt, f

@@ -1,0 +1,83 @@
+"""Multi-rank path on CPU: pairs shard statically across ranks, clouds are gathered to rank 0 in pair order
+(world_size 2 and 3, gloo).  Same code path bench.py / a multi-GPU driver uses with backend nccl (= RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cloud(pair):
+    rng = np.random.default_rng(pair)
+    n = 5 + 3 * pair if pair != 2 else 0          # pair 2 has an empty cloud
+    return rng.normal(size=(n, 3)), rng.integers(0, 256, (n, 3)).astype(np.uint8)
+
+
+def _worker(rank, world, port, n_pairs, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from reconstruction_amd.dist import gather_clouds, shard_pairs
+    mine = shard_pairs(n_pairs, world, rank)
+    local = []
+    for p in mine:
+        xyz, bgr = _cloud(p)
+        local.append((p, torch.from_numpy(xyz), torch.from_numpy(bgr)))
+    res = gather_clouds(local, dst=0)
+    if rank == 0:
+        q.put([(pid, x.numpy().copy(), b.numpy().copy()) for pid, x, b in res])
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_pairs", [(2, 5), (3, 4), (2, 1)])
+def test_shard_and_gather(world, n_pairs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [pid for pid, _, _ in res] == list(range(n_pairs))   # pair order, independent of the sharding
+    for pid, xyz, bgr in res:
+        ex, eb = _cloud(pid)
+        assert np.array_equal(xyz, ex) and np.array_equal(bgr, eb)
+
+
+def test_shard_pairs_is_a_partition():
+    from reconstruction_amd.dist import shard_pairs
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 10, 16):
+            got = sorted(p for r in range(world) for p in shard_pairs(n, world, r))
+            assert got == list(range(n))
+    # the 10-camera rig on 8 GPUs: 2,2,1,1,1,1,1,1 pairs
+    assert [len(shard_pairs(10, 8, r)) for r in range(8)] == [2, 2, 1, 1, 1, 1, 1, 1]
+
+
+def test_single_process_gather_is_identity():
+    from reconstruction_amd.dist import gather_clouds
+    loc = [(3, torch.zeros(2, 3, dtype=torch.float64), torch.zeros(2, 3, dtype=torch.uint8)),
+           (1, torch.ones(1, 3, dtype=torch.float64), torch.ones(1, 3, dtype=torch.uint8))]
+    out = gather_clouds(loc)
+    assert [p for p, _, _ in out] == [1, 3]
