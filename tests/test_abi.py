@@ -61,3 +61,20 @@ def test_product_path_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
                 assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", txt), f
                 assert "liborc" not in txt and "orc_match_pair" not in txt, f
+
+
+def test_header_is_plain_c():
+    r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", HEADER], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/reconstruction"), reason="reference headers only exist in the build container")
+def test_cpp_adapter_compiles_against_the_reference_headers(tmp_path):
+    src = tmp_path / "adapter_check.cpp"
+    src.write_text('#define __declspec(x)\n#define _Longlong long long\n#include "SharedInclude.h"\n'
+                   '#include "CStereoMatching.h"\n#include "CStereoMatchingMI355.hpp"\n'
+                   'bool f(CStereoMatching &sm) { RsmStereoMI355 g(0); return g.MatchPair(sm, 0); }\n')
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-I/root/reference/include",
+                        "-I/root/reference/reconstruction", "-I" + os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -286,3 +286,37 @@ def test_kernel_variants_give_identical_results(ctx, opt):
     for v in range(2):
         assert np.array_equal(base.disparity[v], alt.disparity[v]), opt
     assert np.array_equal(base.xyz, alt.xyz, equal_nan=True)
+
+
+def test_reference_shaped_mirror_drives_the_pipeline(ctx):
+    """StereoMatching.Init / MatchAllLayer (CStereoMatching.h:47-48) over the C ABI: same results as Context,
+    bounds stored on the cameras (.cpp:27-28), InsertPoint called once per point in order, then filter."""
+    from reconstruction_amd import Camera, ManageData, StereoMatching
+    cfg = synth.config_small(**CASES["s128x96_r2_neg_holes"])
+    top = 1 << (cfg.pyr_levels - 1)
+
+    class Sink:
+        def __init__(self):
+            self.points, self.filtered = [], []
+
+        def InsertPoint(self, p):
+            self.points.append(np.array(p))
+
+        def filter(self, idx):
+            self.filtered.append(idx)
+
+    data = ManageData(cam=[[Camera(camID=0, image=cfg.image[0], mask=cfg.mask[0]),
+                            Camera(camID=1, image=cfg.image[1], mask=cfg.mask[1])]],
+                      m_PyrmNum=cfg.pyr_levels, m_LowestLevelSize=(cfg.width // top, cfg.height // top),
+                      m_OriginSize=(cfg.width, cfg.height),
+                      rectified=[dict(Q=cfg.Q, R_final=cfg.R_final, T_final=cfg.T_final)])
+    sink = Sink()
+    sm = StereoMatching(0)
+    sm.Init(data, sink, 2, 0.03)
+    sm.Verbose = 0
+    sm.MatchAllLayer()
+    ref = ctx.match_pair(cfg)
+    assert sm.margin == ref.margin and data.cam[0][0].bound == ref.margin[0] and data.cam[0][1].bound == ref.margin[1]
+    assert np.array_equal(sm.disparity[0], ref.disparity[0])
+    assert len(sink.points) == ref.n_points and sink.filtered == [0]
+    assert np.array_equal(np.array(sink.points), ref.xyz, equal_nan=True)
