@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=["c2", "c2s", "c1", "c3", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="rsm_set_option name=value (tuning knobs)")
     ap.add_argument("--ncc-bench", action="store_true", help="also report the NCC kernel MDE/s microbenchmark")
     args = ap.parse_args()
 
@@ -60,6 +61,9 @@ def main():
             "c3": synth.config_c3, "c5": synth.config_c5}[args.config]
     cfg = make(pair=rank)  # a differently-seeded pair per rank
     ctx = Context(local_rank)
+    for o in args.opt:
+        k, v = o.split("=")
+        ctx.set_option(k, int(v))
     # inputs -> HBM once, outside the timed region (torch owns the staging tensors: plumbing)
     dev = torch.device("cuda", local_rank)
     t_img = [torch.from_numpy(np.ascontiguousarray(cfg.image[v])).to(dev) for v in range(2)]

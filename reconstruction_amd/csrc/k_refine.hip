@@ -289,223 +289,6 @@ __global__ __launch_bounds__(256) void k_refine_fused(StageArgs a) {
     d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
 }
 
-// ---------------------------------------------------------------- temporally blocked sweeps
-// The per-sweep kernels above are HBM-bound (state 16 B + one cache way 20 B per pixel and sweep, and since
-// neighbouring pixels sit in different ways both ways' lines are fetched: ~56 B measured).  k_refine_tile
-// runs up to RT_T Jacobi sweeps per launch on a 64 x RT_RH pixel region kept on chip: each lane owns a
-// vertical strip of RT_RPW pixels (state + BOTH cache ways in registers), east/west neighbours come from
-// wave shuffles, the strip-boundary rows are exchanged through LDS.  A halo of RT_T pixels is recomputed
-// redundantly (the outermost ring is never updated, so after s sweeps everything >= s pixels from the edge
-// is exact); only the interior is stored.  A cache miss inside the tile (rare once the iteration has
-// settled into its 2-cycle) is served in place by the loop-based data-term routine below.
-#define RT_T 4                    // max sweeps per launch = halo width
-#define RT_RPW 6                  // rows per wave (pixels per lane)
-#define RT_NW 8                   // waves per workgroup
-#define RT_RH (RT_RPW * RT_NW)    // region rows (48)
-#define RT_IW (64 - 2 * RT_T)     // interior columns (56)
-#define RT_IH (RT_RH - 2 * RT_T)  // interior rows (40)
-
-// Same arithmetic as refine_data_term (bit for bit: same operation order), written with rolled loops that
-// re-read the image bytes so that it needs only a handful of registers.
-__device__ __forceinline__ void refine_data_term_small(const DirArgs &d, int W, int H, int x, int y, int key,
-                                                       double &pwp, double &delta) {
-    const uint8_t *A = d.img_own, *B = d.img_oth;
-    const long long total = (long long)W * H * 3;
-    const long long rowB = (long long)W * 3;
-    const long long abase = (long long)(y - 1) * rowB + (long long)(x - 1) * 3;
-    auto aval = [&](int k) -> double { return (double)A[abase + (k % 3) * rowB + k / 3]; };
-    int SL = 0;
-#pragma unroll 1
-    for (int k = 0; k < 27; k++) SL += (int)A[abase + (k % 3) * rowB + k / 3];
-    const double meanL = (double)SL / 27.0;
-    double n1 = 0.0, n2 = 0.0;
-#pragma unroll 1
-    for (int k = 0; k < 27; k++) {
-        const double u = aval(k) - meanL;
-        if (k & 1) n2 += u * u;
-        else n1 += u * u;
-    }
-    double normL = sqrt(n1 + n2);
-    if (normL == 0) normL = 1;
-    double xi[3];
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
-        const long long bbase = (long long)(y - 1) * rowB + (long long)(key + c) * 3;
-        auto bval = [&](int k) -> double {
-            const long long fi = bbase + (k % 3) * rowB + k / 3;
-            return (fi >= 0 && fi < total) ? (double)B[fi] : 0.0;
-        };
-        double SR = 0.0; // integers: exact in fp64
-#pragma unroll 1
-        for (int k = 0; k < 27; k++) SR += bval(k);
-        const double meanR = SR / 27.0;
-        double m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
-#pragma unroll 1
-        for (int k = 0; k < 27; k++) {
-            const double ur = bval(k) - meanR;
-            const double ul = aval(k) - meanL;
-            if (k & 1) {
-                m2 += ur * ur;
-                d2 += ul * ur;
-            } else {
-                m1 += ur * ur;
-                d1 += ul * ur;
-            }
-        }
-        double normR = sqrt(m1 + m2);
-        if (normR == 0) normR = 1;
-        xi[c] = (1 - (d1 + d2) / (normL * normR)) / 2;
-    }
-    const double x0 = xi[0], x1 = xi[1], x2 = xi[2];
-    int index = x0 >= x1;
-    if ((index ? x1 : x0) > x2) index = 2;
-    if (index == 0) {
-        pwp = x1 - x0;
-        delta = -0.5;
-    } else if (index == 2) {
-        pwp = x1 - x2;
-        delta = 0.5;
-    } else {
-        pwp = 0.5 * (x0 + x2) - x1;
-        delta = (pwp == 0) ? 0.0 : 0.5 * (x0 - x2) / (x0 + x2 - 2 * x1);
-    }
-}
-
-template <int TOP>
-__global__ __launch_bounds__(64 * RT_NW) void k_refine_tile(StageArgs a) {
-    __shared__ double sEx[2][RT_NW][2][64]; // [parity][wave][0 = top row, 1 = bottom row][lane]
-    const DirArgs &d = a.d[blockIdx.z];
-    const int W = a.W, H = a.H, nsweeps = a.flag2;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int XL = d.own.XL, XR = d.own.XR, YL = d.own.YL, YR = d.own.YR;
-    const int x = XL + 1 - RT_T + blockIdx.x * RT_IW + lane;
-    const int ry0 = YL + 1 - RT_T + blockIdx.y * RT_IH + wv * RT_RPW; // image row of this lane's first pixel
-    if (XL + 1 + (int)blockIdx.x * RT_IW > XR - 1 || YL + 1 + (int)blockIdx.y * RT_IH > YR - 1) return; // uniform
-    const bool xin = x >= 0 && x < W;
-    const bool xupd = x >= XL + 1 && x <= XR - 1 && lane != 0 && lane != 63;
-    const double *__restrict__ in = d.f64_a;
-    double *__restrict__ out = d.f64_b;
-
-    double dv[RT_RPW], pw[2][RT_RPW], dl[2][RT_RPW];
-    int ky[2][RT_RPW];
-    unsigned upd = 0, dirty = 0; // bit i: pixel i is updated by the sweeps; bits 2i, 2i+1: way dirty
-#pragma unroll
-    for (int i = 0; i < RT_RPW; i++) {
-        const int yy = ry0 + i;
-        const bool ok = xin && yy >= 0 && yy < H;
-        const size_t pix = ok ? (size_t)yy * W + x : 0;
-        dv[i] = ok ? in[pix] : (double)NOMATCH;
-#pragma unroll
-        for (int w = 0; w < 2; w++) {
-            ky[w][i] = ok ? d.rf_key[pix + w * a.rf_stride] : INT_MIN;
-            pw[w][i] = ok ? d.rf_pwp[pix + w * a.rf_stride] : 0.0;
-            dl[w][i] = ok ? d.rf_delta[pix + w * a.rf_stride] : 0.0;
-        }
-        const int r = wv * RT_RPW + i; // region row
-        if (ok && xupd && yy >= YL + 1 && yy <= YR - 1 && r != 0 && r != RT_RH - 1 && dv[i] != (double)NOMATCH)
-            upd |= 1u << i;
-    }
-    for (int s = 0; s < nsweeps; s++) {
-        const int par = s & 1;
-        sEx[par][wv][0][lane] = dv[0];
-        sEx[par][wv][1][lane] = dv[RT_RPW - 1];
-        __syncthreads();
-        const double north = (wv > 0) ? sEx[par][wv - 1][1][lane] : (double)NOMATCH;
-        const double south = (wv < RT_NW - 1) ? sEx[par][wv + 1][0][lane] : (double)NOMATCH;
-        double nd[RT_RPW];
-#pragma unroll
-        for (int i = 0; i < RT_RPW; i++) {
-            const double dC = dv[i];
-            const double dE = __shfl_down(dC, 1), dW = __shfl_up(dC, 1);
-            const double dN = (i > 0) ? dv[i - 1] : north;
-            const double dS = (i < RT_RPW - 1) ? dv[i + 1] : south;
-            nd[i] = dC;
-            if (upd & (1u << i)) {
-                const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
-                                 (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
-                if (mode != 0) {
-                    const int key = (int)(dC - 1.5) + x; // .cpp:625
-                    const int w = (key - x) & 1;
-                    const bool hit = (w ? ky[1][i] : ky[0][i]) == key;
-                    double pwp = w ? pw[1][i] : pw[0][i];
-                    double delta = w ? dl[1][i] : dl[0][i];
-                    if (!hit) {
-                        refine_data_term_small(d, W, H, x, ry0 + i, key, pwp, delta);
-                        if (w) {
-                            ky[1][i] = key;
-                            pw[1][i] = pwp;
-                            dl[1][i] = delta;
-                        } else {
-                            ky[0][i] = key;
-                            pw[0][i] = pwp;
-                            dl[0][i] = delta;
-                        }
-                        dirty |= 1u << (2 * i + w);
-                    }
-                    nd[i] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RT_RPW; i++) dv[i] = nd[i];
-    }
-    // ---- store the interior of the region (exact after <= RT_T sweeps)
-    if (lane >= RT_T && lane < 64 - RT_T) {
-#pragma unroll
-        for (int i = 0; i < RT_RPW; i++) {
-            const int r = wv * RT_RPW + i;
-            if (r < RT_T || r >= RT_RH - RT_T || !(upd & (1u << i))) continue;
-            const size_t pix = (size_t)(ry0 + i) * W + x;
-            out[pix] = dv[i];
-#pragma unroll
-            for (int w = 0; w < 2; w++)
-                if (dirty & (1u << (2 * i + w))) {
-                    d.rf_key[pix + w * a.rf_stride] = ky[w][i];
-                    d.rf_pwp[pix + w * a.rf_stride] = pw[w][i];
-                    d.rf_delta[pix + w * a.rf_stride] = dl[w][i];
-                }
-        }
-    }
-}
-
-// Enqueues `count` sweeps starting at sweep index `first` with the tile kernel; returns the number of
-// buffer swaps performed (one per launch). `a` carries f64_a = current state, f64_b = scratch.
-int launch_refine_tiles(StageArgs a, int first, int count, hipStream_t st) {
-    int rows = 0, cols = 0;
-    for (int v = 0; v < a.ndir; v++) {
-        rows = max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
-        cols = max(cols, a.d[v].own.XR - a.d[v].own.XL - 1);
-    }
-    if (rows <= 0 || cols <= 0 || count <= 0) return 0;
-    (void)first;
-    const dim3 grid((cols + RT_IW - 1) / RT_IW, (rows + RT_IH - 1) / RT_IH, a.ndir);
-    int launches = 0;
-    while (count > 0) {
-        a.flag2 = count < RT_T ? count : RT_T;
-        if (a.flag) hipLaunchKernelGGL(k_refine_tile<1>, grid, dim3(64 * RT_NW), 0, st, a);
-        else hipLaunchKernelGGL(k_refine_tile<0>, grid, dim3(64 * RT_NW), 0, st, a);
-        count -= a.flag2;
-        for (int v = 0; v < a.ndir; v++) {
-            double *t = a.d[v].f64_a;
-            a.d[v].f64_a = a.d[v].f64_b;
-            a.d[v].f64_b = t;
-        }
-        launches++;
-    }
-    return launches;
-}
-
-bool refine_uses_tiles(const StageArgs &a) {
-    int rows = 0, cols = 0;
-    for (int v = 0; v < a.ndir; v++) {
-        rows = max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
-        cols = max(cols, a.d[v].own.XR - a.d[v].own.XL - 1);
-    }
-    if (rows <= 0 || cols <= 0) return false;
-    const long long px = (long long)((cols + 255) / 256) * rows * a.ndir * 256;
-    return a.opt_refine_tile && px >= a.opt_refine_fused_max;
-}
-
 static void launch_refine_sweep_impl(const StageArgs &a, dim3 grid, hipStream_t st);
 
 void launch_refine_sweep(const StageArgs &a, hipStream_t st) {

@@ -87,7 +87,6 @@ struct rsm_ctx {
     // options (rsm_set_option)
     long long opt_refine_fused_max = 1ll << 20;
     int opt_ncc_bytes = 0;
-    int opt_refine_tile = 0; // experimental: bit-identical, not yet faster than the split kernels
 
     // profiling
     bool profile = false;
@@ -309,7 +308,6 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "refine_fused_max")) c->opt_refine_fused_max = value;
     else if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
-    else if (!strcmp(name, "refine_tile")) c->opt_refine_tile = value != 0;
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
     return RSM_OK;
 }
@@ -348,7 +346,6 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.rf_stride = c->cap_px;
     a.opt_refine_fused_max = c->opt_refine_fused_max;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
-    a.opt_refine_tile = c->opt_refine_tile;
     for (int v = 0; v < 2; v++) {
         DirArgs &d = a.d[v];
         const int o = 1 - v;
@@ -517,22 +514,12 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             a.d[v].f64_a = c->f64[cur][v];
             a.d[v].f64_b = c->f64[nxt][v];
         }
-        const bool tiles = refine_uses_tiles(a);
         for (int it = 0; it < iters; it++) {
             for (int v = 0; v < 2; v++) {
                 a.d[v].f64_a = c->f64[cur][v];
                 a.d[v].f64_b = c->f64[nxt][v];
             }
             a.flag2 = it;
-            if (tiles && it > 0) { // sweep 0 fills the cache (k_refine_miss<1>), the rest run temporally blocked
-                const int swaps = launch_refine_tiles(a, it, iters - it, st);
-                if (swaps & 1) {
-                    const int t = cur;
-                    cur = nxt;
-                    nxt = t;
-                }
-                break;
-            }
             launch_refine_sweep(a, st);
             const int t = cur;
             cur = nxt;
@@ -771,7 +758,6 @@ StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, cons
     StageArgs a{};
     a.opt_refine_fused_max = c->opt_refine_fused_max;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
-    a.opt_refine_tile = c->opt_refine_tile;
     a.ndir = 1;
     a.W = W;
     a.H = H;
@@ -964,17 +950,8 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.f64_a = A;
     d.f64_b = B;
     launch_refine_init(a, c->stream);
-    const bool tiles = refine_uses_tiles(a);
     for (int it = 0; it < iterations; it++) {
         a.flag2 = it;
-        if (tiles && it > 0) {
-            if (launch_refine_tiles(a, it, iterations - it, c->stream) & 1) {
-                double *x = d.f64_a;
-                d.f64_a = d.f64_b;
-                d.f64_b = x;
-            }
-            break;
-        }
         launch_refine_sweep(a, c->stream);
         double *x = d.f64_a;
         d.f64_a = d.f64_b;

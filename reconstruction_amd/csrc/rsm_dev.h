@@ -51,7 +51,6 @@ struct StageArgs {
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
     long long opt_refine_fused_max; // refine: levels with fewer pixel-threads use the fused kernel
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
-    int opt_refine_tile;            // use the temporally blocked refine kernel on large levels
     int32_t *rf_cnt;   // refine: worklist counters [2 sets][RF_NSHARD]
     uint32_t *rf_list; // refine / NCC: worklist of (dir << 31 | pixel index)
     int32_t *ncc_cnt;  // NCC: number of wide pixels in rf_list
@@ -82,9 +81,6 @@ void launch_set_boundary(const StageArgs &a, hipStream_t st);  // d16_in, mask_o
 void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out (pre-filled NOMATCH)
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 void launch_refine_sweep(const StageArgs &a, hipStream_t st);  // f64_a -> f64_b
-// temporally blocked sweeps (k_refine_tile): `count` sweeps, returns the number of launches = buffer swaps
-int launch_refine_tiles(StageArgs a, int first, int count, hipStream_t st);
-bool refine_uses_tiles(const StageArgs &a);
 
 // cloud: returns nothing; *d_npoints (device int64) receives the point count
 void launch_bad_prefix(const uint8_t *mask, int W, int H, int32_t *prefix, hipStream_t st);

@@ -129,7 +129,6 @@ def test_integer_stages_bit_exact(ctx, name):
 def test_fp64_stages(ctx, name, split):
     cfg, rec, fin = stages(name)
     ctx.set_option("refine_fused_max", 0 if split else 1 << 20)
-    ctx.set_option("refine_tile", 1 if (split and name.endswith("r4")) else 0)
     imgs, msks = fin["imgs"], fin["msks"]
     worst = 0.0
     for q in rec:
@@ -144,7 +143,6 @@ def test_fp64_stages(ctx, name, split):
             assert np.array_equal(g0, q["out"][0]), diff_report("uniq64 d0 L%d" % k, g0, q["out"][0])
             assert np.array_equal(g1, q["out"][1]), diff_report("uniq64 d1 L%d" % k, g1, q["out"][1])
     ctx.set_option("refine_fused_max", 1 << 20)
-    ctx.set_option("refine_tile", 0)
     print("worst refine rel err", worst)
 
 
@@ -265,24 +263,19 @@ def test_order_constraint_heavy_crossings(ctx):
     assert np.array_equal(a, b), diff_report("order heavy", a, b)
 
 
-@pytest.mark.parametrize("opt", [("refine_fused_max", 0), ("refine_fused_max", 1 << 40), ("ncc_bytes", 1),
-                                 ("refine_tile", 0)])
+@pytest.mark.parametrize("opt", [("refine_fused_max", 1 << 40), ("ncc_bytes", 1)])
 def test_kernel_variants_give_identical_results(ctx, opt):
     """The split (light + worklist) and fused refine kernels, and the dot4 / byte-wise NCC kernels, are
     interchangeable bit for bit."""
     cfg = synth.config_small(**CASES["s320x160_occluded_neg_r4"])
-    ctx.set_option("refine_fused_max", 0)   # base = temporally blocked tiles on every level
-    ctx.set_option("refine_tile", 1)
+    ctx.set_option("refine_fused_max", 0)   # base = split light + worklist kernels on every level
     base = ctx.match_pair(cfg)
-    if opt[0] != "refine_fused_max":
-        ctx.set_option("refine_fused_max", 0)
     ctx.set_option(*opt)
     try:
         alt = ctx.match_pair(cfg)
     finally:
         ctx.set_option("refine_fused_max", 1 << 20)
         ctx.set_option("ncc_bytes", 0)
-        ctx.set_option("refine_tile", 0)
     for v in range(2):
         assert np.array_equal(base.disparity[v], alt.disparity[v]), opt
     assert np.array_equal(base.xyz, alt.xyz, equal_nan=True)
