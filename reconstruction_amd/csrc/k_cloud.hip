@@ -82,6 +82,7 @@ struct CloudArgs {
     const double *q; // 16 doubles, column 3 already scaled (.cpp:698)
     const double *R, *T;
     Mg own;
+    uint8_t *flags; // W*H scratch: pass 0 stores cloud_flag, pass 1 reads it back
     int32_t *row_count;
     int64_t *row_offset;
     int64_t *npoints;
@@ -116,7 +117,13 @@ __global__ __launch_bounds__(256) void k_cloud(CloudArgs c) {
     }
     for (int x0 = c.own.XL; x0 <= c.own.XR; x0 += 256) {
         const int x = x0 + tid;
-        const bool f = cloud_flag(c, x, y);
+        bool f;
+        if (PASS == 0) {
+            f = cloud_flag(c, x, y);
+            if (x <= c.own.XR) c.flags[(size_t)y * c.W + x] = f;
+        } else {
+            f = (x <= c.own.XR) && c.flags[(size_t)y * c.W + x];
+        }
         const unsigned long long b = __ballot(f);
         if (lane == 0) s_w[wid] = __popcll(b);
         __syncthreads();
@@ -179,14 +186,14 @@ __global__ __launch_bounds__(256) void k_row_scan(const int32_t *__restrict__ cn
 
 void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *img, int W, int H, int ksize,
                   const int *d_j1, const int *d_j2, const double *q16_scaled, const double *R, const double *T,
-                  Mg own, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints, double *xyz,
+                  Mg own, uint8_t *flags, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints, double *xyz,
                   uint8_t *bgr, int64_t max_points, hipStream_t st) {
     const int rows = own.YR - own.YL + 1;
     if (rows <= 0 || own.XR < own.XL) {
         (void)hipMemsetAsync(d_npoints, 0, sizeof(int64_t), st);
         return;
     }
-    CloudArgs c{disp, bad_prefix, img, W, H, ksize, d_j1, d_j2, q16_scaled, R, T, own,
+    CloudArgs c{disp, bad_prefix, img, W, H, ksize, d_j1, d_j2, q16_scaled, R, T, own, flags,
                 row_count, row_offset, d_npoints, xyz, bgr, max_points};
     hipLaunchKernelGGL(k_cloud<0>, dim3(rows), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(256), 0, st, row_count, rows, row_offset, d_npoints);

@@ -346,14 +346,14 @@ __global__ void k_setb_vert(StageArgs a) {
     BR[(size_t)YL * W + x] = (int16_t)br;
 }
 
-// horizontal sweeps (.cpp:903-941): sequential along x inside a row. One wave handles SBH_R rows;
+// horizontal sweeps (.cpp:903-941): sequential along x inside a row. One workgroup handles SBH_R rows;
 // SBH_R x SBH_W tiles of BL / BR / mask go through LDS (coalesced row-segment loads and stores), lane t
 // (< SBH_R) walks row t of the tile with the running (bl, br) pair in registers.
 #define SBH_R 16   // rows per wave
 #define SBH_W 256  // tile width (columns)
 #define SBH_LD 258 // LDS row stride in int16 elements
 #define SBH_LM 260 // LDS row stride of the mask tile (bytes)
-__global__ __launch_bounds__(64) void k_setb_horiz(StageArgs a) {
+__global__ __launch_bounds__(256) void k_setb_horiz(StageArgs a) {
     __shared__ int16_t tl[SBH_R * SBH_LD], tr[SBH_R * SBH_LD];
     __shared__ uint8_t tm[SBH_R * SBH_LM];
     const DirArgs &d = a.d[blockIdx.z];
@@ -362,18 +362,30 @@ __global__ __launch_bounds__(64) void k_setb_horiz(StageArgs a) {
     const int W = a.W, XL = d.own.XL, XR = d.own.XR, XL1 = d.oth.XL, XR1 = d.oth.XR, YR = d.own.YR;
     const int lane = threadIdx.x;
     const int nrows = min(SBH_R, YR - y0 + 1);
-    const bool rowok = lane < nrows;
+    const bool rowok = lane < nrows; // the first SBH_R lanes of wave 0 walk the rows
     // ---- left -> right (.cpp:909-916), target-centric: x' = x + 1
     int cbl = 0, cbr = 0, cm = 0; // running values / mask at x' - 1
     for (int c0 = XL; c0 <= XR; c0 += SBH_W) {
         const int nc = min(SBH_W, XR - c0 + 1);
-        for (int r = 0; r < nrows; r++)
-            for (int cc = lane; cc < nc; cc += 64) {
-                const size_t o = (size_t)(y0 + r) * W + c0 + cc;
-                tl[r * SBH_LD + cc] = d.BL[o];
-                tr[r * SBH_LD + cc] = d.BR[o];
-                tm[r * SBH_LM + cc] = d.mask_own[o];
+        { // the 256 threads fetch the SBH_R x SBH_W tile: thread = column, all rows' loads in flight at once
+            const int cc = threadIdx.x;
+            int16_t vl[SBH_R], vr[SBH_R];
+            uint8_t vm[SBH_R];
+#pragma unroll
+            for (int r = 0; r < SBH_R; r++) {
+                const bool ok = r < nrows && cc < nc;
+                const size_t o = ok ? (size_t)(y0 + r) * W + c0 + cc : (size_t)y0 * W + c0;
+                vl[r] = d.BL[o];
+                vr[r] = d.BR[o];
+                vm[r] = d.mask_own[o];
             }
+#pragma unroll
+            for (int r = 0; r < SBH_R; r++) {
+                tl[r * SBH_LD + cc] = vl[r];
+                tr[r * SBH_LD + cc] = vr[r];
+                tm[r * SBH_LM + cc] = vm[r];
+            }
+        }
         __syncthreads();
         if (rowok) {
             for (int i = 0; i < nc; i++) {
@@ -390,12 +402,17 @@ __global__ __launch_bounds__(64) void k_setb_horiz(StageArgs a) {
             }
         }
         __syncthreads();
-        for (int r = 0; r < nrows; r++)
-            for (int cc = lane; cc < nc; cc += 64) {
-                const size_t o = (size_t)(y0 + r) * W + c0 + cc;
-                d.BL[o] = tl[r * SBH_LD + cc];
-                d.BR[o] = tr[r * SBH_LD + cc];
-            }
+        {
+            const int cc = threadIdx.x;
+            if (cc < nc)
+#pragma unroll
+                for (int r = 0; r < SBH_R; r++)
+                    if (r < nrows) {
+                        const size_t o = (size_t)(y0 + r) * W + c0 + cc;
+                        d.BL[o] = tl[r * SBH_LD + cc];
+                        d.BR[o] = tr[r * SBH_LD + cc];
+                    }
+        }
         __syncthreads();
     }
     // ---- right -> left (.cpp:917-940). cbl/cbr hold the values at XR.
@@ -403,13 +420,25 @@ __global__ __launch_bounds__(64) void k_setb_horiz(StageArgs a) {
     for (int t = ntile - 1; t >= 0; t--) {
         const int c0 = XL + t * SBH_W;
         const int nc = min(SBH_W, XR - c0 + 1);
-        for (int r = 0; r < nrows; r++)
-            for (int cc = lane; cc < nc; cc += 64) {
-                const size_t o = (size_t)(y0 + r) * W + c0 + cc;
-                tl[r * SBH_LD + cc] = d.BL[o];
-                tr[r * SBH_LD + cc] = d.BR[o];
-                tm[r * SBH_LM + cc] = d.mask_own[o];
+        { // the 256 threads fetch the SBH_R x SBH_W tile: thread = column, all rows' loads in flight at once
+            const int cc = threadIdx.x;
+            int16_t vl[SBH_R], vr[SBH_R];
+            uint8_t vm[SBH_R];
+#pragma unroll
+            for (int r = 0; r < SBH_R; r++) {
+                const bool ok = r < nrows && cc < nc;
+                const size_t o = ok ? (size_t)(y0 + r) * W + c0 + cc : (size_t)y0 * W + c0;
+                vl[r] = d.BL[o];
+                vr[r] = d.BR[o];
+                vm[r] = d.mask_own[o];
             }
+#pragma unroll
+            for (int r = 0; r < SBH_R; r++) {
+                tl[r * SBH_LD + cc] = vl[r];
+                tr[r * SBH_LD + cc] = vr[r];
+                tm[r * SBH_LM + cc] = vm[r];
+            }
+        }
         __syncthreads();
         if (rowok) {
             for (int i = nc - 1; i >= 0; i--) {
@@ -454,12 +483,17 @@ __global__ __launch_bounds__(64) void k_setb_horiz(StageArgs a) {
             }
         }
         __syncthreads();
-        for (int r = 0; r < nrows; r++)
-            for (int cc = lane; cc < nc; cc += 64) {
-                const size_t o = (size_t)(y0 + r) * W + c0 + cc;
-                d.BL[o] = tl[r * SBH_LD + cc];
-                d.BR[o] = tr[r * SBH_LD + cc];
-            }
+        {
+            const int cc = threadIdx.x;
+            if (cc < nc)
+#pragma unroll
+                for (int r = 0; r < SBH_R; r++)
+                    if (r < nrows) {
+                        const size_t o = (size_t)(y0 + r) * W + c0 + cc;
+                        d.BL[o] = tl[r * SBH_LD + cc];
+                        d.BR[o] = tr[r * SBH_LD + cc];
+                    }
+        }
         __syncthreads();
     }
 }
@@ -472,7 +506,7 @@ void launch_set_boundary(const StageArgs &a, hipStream_t st) {
     }
     if (rows <= 0 || cols <= 0) return;
     hipLaunchKernelGGL(k_setb_vert, dim3((cols + 63) / 64, 1, a.ndir), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_setb_horiz, dim3((rows + SBH_R - 1) / SBH_R, 1, a.ndir), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_setb_horiz, dim3((rows + SBH_R - 1) / SBH_R, 1, a.ndir), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------- MedianFilter (1 iteration)

@@ -80,10 +80,23 @@ __global__ void k_find_margin(const uint8_t *__restrict__ mask, int W, int H, in
     if (y >= H - r) return;
     const uint8_t *p = mask + (size_t)y * W;
     int lo = 0x7fffffff, hi = -1;
-    for (int x = r + threadIdx.x; x < W - r; x += blockDim.x) {
-        if (p[x] == 255) {
-            lo = min(lo, x);
-            hi = max(hi, x);
+    // 16 bytes per thread and load (row bases are only byte aligned: unaligned dwordx4 loads)
+    for (int x0 = r + 16 * threadIdx.x; x0 < W - r; x0 += 16 * blockDim.x) {
+        if (x0 + 16 <= W - r) {
+            uint32_t v[4];
+            __builtin_memcpy(v, p + x0, 16);
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (((v[k >> 2] >> (8 * (k & 3))) & 255u) == 255u) {
+                    lo = min(lo, x0 + k);
+                    hi = max(hi, x0 + k);
+                }
+        } else {
+            for (int x = x0; x < W - r; x++)
+                if (p[x] == 255) {
+                    lo = min(lo, x);
+                    hi = max(hi, x);
+                }
         }
     }
     // wave reduce
@@ -103,11 +116,12 @@ __global__ void k_find_margin(const uint8_t *__restrict__ mask, int W, int H, in
             lo = min(lo, slo[i]);
             hi = max(hi, shi[i]);
         }
-        if (hi >= 0) {
-            atomicMin(&out4[0], lo);
-            atomicMax(&out4[1], hi);
-            atomicMin(&out4[2], y);
-            atomicMax(&out4[3], y);
+        if (hi >= 0) { // a stale read only costs a redundant atomic: ~12k same-address atomics would serialise
+            volatile int *o = out4;
+            if (lo < o[0]) atomicMin(&out4[0], lo);
+            if (hi > o[1]) atomicMax(&out4[1], hi);
+            if (y < o[2]) atomicMin(&out4[2], y);
+            if (y > o[3]) atomicMax(&out4[3], y);
         }
     }
 }

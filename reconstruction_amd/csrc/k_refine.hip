@@ -35,8 +35,8 @@ __global__ void k_refine_init(StageArgs a) {
         const double v = (double)d.d16_in[i]; // convertTo CV_64F, .cpp:585
         d.f64_a[i] = v;
         d.f64_b[i] = v; // copyTo, .cpp:587
-        d.rf_key[i] = INT_MIN;
-        d.rf_key[i + a.rf_stride] = INT_MIN;
+        d.rf_key[i] = RF_NOKEY;
+        d.rf_key[i + a.rf_stride] = RF_NOKEY;
     }
 }
 
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         pix[i] = (size_t)yy * W + xs;
         key[i] = (int)(col[i + 1] - 1.5) + xs; // .cpp:625
         const size_t cpix = pix[i] + (size_t)((key[i] - xs) & 1) * a.rf_stride;
-        ckey[i] = d.rf_key[cpix];
+        ckey[i] = (int)d.rf_key[cpix] + xs; // stored relative to the column (int16)
         pwp[i] = d.rf_pwp[cpix];
         delta[i] = d.rf_delta[cpix];
     }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_refine_miss(StageArgs a) {
         double pwp, delta;
         refine_data_term(d, W, H, x, y, key, pwp, delta);
         const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
-        d.rf_key[cpix] = key;
+        d.rf_key[cpix] = (int16_t)(key - x);
         d.rf_pwp[cpix] = pwp;
         d.rf_delta[cpix] = delta;
         d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
@@ -277,12 +277,12 @@ __global__ __launch_bounds__(256) void k_refine_fused(StageArgs a) {
     const int key = (int)(dC - 1.5) + x;
     const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
     double pwp, delta;
-    if (d.rf_key[cpix] == key) {
+    if ((int)d.rf_key[cpix] + x == key) {
         pwp = d.rf_pwp[cpix];
         delta = d.rf_delta[cpix];
     } else {
         refine_data_term(d, W, H, x, y, key, pwp, delta);
-        d.rf_key[cpix] = key;
+        d.rf_key[cpix] = (int16_t)(key - x);
         d.rf_pwp[cpix] = pwp;
         d.rf_delta[cpix] = delta;
     }

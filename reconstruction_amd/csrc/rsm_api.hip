@@ -65,7 +65,7 @@ struct rsm_ctx {
     int16_t *d16a[2]{}, *d16b[2]{}, *BL[2]{}, *BR[2]{};
     double *f64[3][2]{};
     int32_t *nv[2]{};
-    int32_t *rf_key[2]{};
+    int16_t *rf_key[2]{};
     int32_t *rf_cnt = nullptr;
     uint32_t *rf_list = nullptr;
     double *rf_pwp[2]{}, *rf_delta[2]{};
@@ -556,7 +556,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         HIPCHK(c, hipStreamSynchronize(st)); // j1/j2/q are stack/vector storage
         launch_bad_prefix(c->msk[k][0], W, H, c->prefix, st);
         launch_cloud(c->f64[par][0], c->prefix, c->img[k][0], W, H, ksize, c->d_j1, c->d_j2, c->d_q, c->d_R, c->d_T,
-                     c->mg[k][0], c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
+                     c->mg[k][0], (uint8_t *)c->d16a[0], c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
         const Mg &m = c->mg[k][0];
         prof_end(c, ST_CLOUD, 4, 28.0 * (double)(m.XR - m.XL + 1) * (m.YR - m.YL + 1));
     }
@@ -939,7 +939,7 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.img_own = t.up(img_own, px * 3);
     d.img_oth = t.up(img_oth, px * 3);
     double *A = t.alloc<double>(px), *B = t.alloc<double>(px);
-    d.rf_key = t.alloc<int32_t>(2 * px);
+    d.rf_key = t.alloc<int16_t>(2 * px);
     d.rf_pwp = t.alloc<double>(2 * px);
     d.rf_delta = t.alloc<double>(2 * px);
     a.rf_stride = px;
@@ -990,7 +990,9 @@ extern "C" int rsm_stage_cloud(rsm_ctx *c, const double *disp, const uint8_t *ma
     uint8_t *db = (bgr && cap) ? t.alloc<uint8_t>((size_t)cap * 3) : nullptr;
     if (!t.ok) return finish(c, t);
     launch_bad_prefix(dm, W, H, pre, c->stream);
-    launch_cloud(dd, pre, di, W, H, ksize, d1, d2, dq, dR, dT, to_mg(*own), rc, ro, dn, dx, db, cap, c->stream);
+    uint8_t *fl = t.alloc<uint8_t>(px);
+    if (!t.ok) return finish(c, t);
+    launch_cloud(dd, pre, di, W, H, ksize, d1, d2, dq, dR, dT, to_mg(*own), fl, rc, ro, dn, dx, db, cap, c->stream);
     int64_t n = 0;
     t.down(&n, (const int64_t *)dn, 1);
     *n_points = n;

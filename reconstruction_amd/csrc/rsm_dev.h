@@ -8,8 +8,9 @@
 #define NOMATCH (-10000) // reconstruction/CStereoMatching.h:9
 #define WAVE 64
 #define RF_MAX_SWEEPS 1024
+#define RF_NOKEY ((int16_t)-32768)
 #define RF_NSHARD 256 // refine worklist shards (power of 2)
-#define RF_SUB 4      // worklist blocks per shard
+#define RF_SUB 1      // worklist blocks per shard
 #define RF_PPT 4      // pixels per thread of the light sweep kernel
 // worklist capacity (entries) for ndir directions of a WxH level
 #define RF_LIST_ENTRIES(W, H, ndir) ((size_t)(ndir) * ((size_t)(W) + 256) * ((size_t)(H) + RF_PPT) + (size_t)RF_NSHARD * 256 * RF_PPT)
@@ -33,7 +34,7 @@ struct DirArgs {
     const double *parent;      // fp64 disparity of level k-1 (this direction)
     const int32_t *parent_nv;  // next-valid-column table of `parent`
     double *f64_a, *f64_b;     // fp64 disparity ping-pong / uniqueness maps
-    int32_t *rf_key;           // refine cache (2 ways, way = key & 1): iMatch key
+    int16_t *rf_key;           // refine cache (2 ways): iMatch - x = int(d - 1.5) of the cached entry, RF_NOKEY = empty
     double *rf_pwp, *rf_delta; // refine cache: data-term weight and offset
 };
 
@@ -88,6 +89,6 @@ void launch_erode_binary(const int32_t *prefix, int W, int H, int ksize, const i
                          uint8_t *dst255, hipStream_t st);
 void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *img, int W, int H, int ksize,
                   const int *d_j1, const int *d_j2, const double *q16_scaled, const double *R,
-                  const double *T, Mg own, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints,
+                  const double *T, Mg own, uint8_t *flags, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints,
                   double *xyz, uint8_t *bgr, int64_t max_points, hipStream_t st);
 void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long long *d_count, hipStream_t st);
