@@ -29,14 +29,15 @@ enum Stage {
     ST_MEDIAN,
     ST_REFINE_INIT,
     ST_REFINE_SWEEP,     // all levels below the top
-    ST_REFINE_SWEEP_TOP, // the top level's sweeps (the dominant kernel)
+    ST_REFINE_SWEEP_TOP, // the top level's sweeps (light + worklist kernels)
+    ST_REFINE_LIGHT_TOP, // only the k_refine_sweep<1> launches of the top level (the dominant kernel)
     ST_UNIQ64,
     ST_CLOUD,
     ST_COUNT
 };
 static const char *kStageNames[ST_COUNT] = {"pyramid", "margin", "boxsum", "initial_match", "smooth", "order",
                                             "uniqueness_s16", "rematch", "median", "refine_init",
-                                            "refine_sweep", "refine_sweep_top", "uniqueness_f64", "cloud"};
+                                            "refine_sweep", "refine_sweep_top", "refine_light_top", "uniqueness_f64", "cloud"};
 
 struct EvPair {
     hipEvent_t a, b;
@@ -285,8 +286,7 @@ extern "C" int rsm_upload_pair_device(rsm_ctx *c, const rsm_pair_in *in) {
 }
 
 // ---- profiling helpers --------------------------------------------------------------------------
-static void prof_begin(rsm_ctx *c, int stage) {
-    if (!c->profile) return;
+static int prof_slot(rsm_ctx *c, int stage) { // next event pair of the pool
     if (c->ev_used == c->evpool.size()) {
         EvPair e{};
         (void)hipEventCreate(&e.a);
@@ -294,12 +294,17 @@ static void prof_begin(rsm_ctx *c, int stage) {
         c->evpool.push_back(e);
     }
     c->evpool[c->ev_used].stage = stage;
-    (void)hipEventRecord(c->evpool[c->ev_used].a, c->stream);
+    return (int)c->ev_used++;
 }
-static void prof_end(rsm_ctx *c, int stage, int launches, double bytes) {
-    if (!c->profile) return;
-    (void)hipEventRecord(c->evpool[c->ev_used].b, c->stream);
-    c->ev_used++;
+static int prof_begin(rsm_ctx *c, int stage) {
+    if (!c->profile) return -1;
+    const int s = prof_slot(c, stage);
+    (void)hipEventRecord(c->evpool[s].a, c->stream);
+    return s;
+}
+static void prof_end(rsm_ctx *c, int slot, int stage, int launches, double bytes) {
+    if (slot < 0) return;
+    (void)hipEventRecord(c->evpool[slot].b, c->stream);
     c->prof_launches[stage] += launches;
     c->prof_bytes[stage] += bytes;
 }
@@ -389,20 +394,20 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     const double P_top_full = (double)c->Wk[N - 1] * c->Hk[N - 1];
 
     // ConstructPyrm, .cpp:1040-1053 (top level = uploaded images)
-    prof_begin(c, ST_PYRAMID);
+    const int ps1 = prof_begin(c, ST_PYRAMID);
     for (int k = N - 2; k >= 0; k--)
         for (int v = 0; v < 2; v++) {
             launch_pyr_down(c->img[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 3, c->img[k][v], st);
             launch_pyr_down(c->msk[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 1, c->msk[k][v], st);
         }
-    prof_end(c, ST_PYRAMID, 4 * (N - 1), 14.0 * P_top_full);
+    prof_end(c, ps1, ST_PYRAMID, 4 * (N - 1), 14.0 * P_top_full);
 
     // FindMargin for every level and view (.cpp:51-52): depends on the masks only
-    prof_begin(c, ST_MARGIN);
+    const int ps2 = prof_begin(c, ST_MARGIN);
     for (int k = 0; k < N; k++)
         for (int v = 0; v < 2; v++)
             launch_find_margin(c->msk[k][v], c->Wk[k], c->Hk[k], r, c->d_margins + (k * 2 + v) * 4, st);
-    prof_end(c, ST_MARGIN, 4 * N, 0);
+    prof_end(c, ps2, ST_MARGIN, 4 * N, 0);
     int hm[RSM_MAX_LEVELS * 2 * 4];
     HIPCHK(c, hipMemcpyAsync(hm, c->d_margins, sizeof(int) * N * 2 * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -424,15 +429,15 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         if (degenerate(c->mg[k][0]) || degenerate(c->mg[k][1]))
             return set_err(c, RSM_E_DEGENERATE_MARGIN, "level %d: YL>=YR || XL>=XR", k);
 
-        prof_begin(c, ST_BOXSUM);
+        const int ps3 = prof_begin(c, ST_BOXSUM);
         for (int v = 0; v < 2; v++) {
             launch_box_sums(c->img[k][v], W, H, r, c->tmp1, c->tmp2, c->S1[v], c->S2[v], st);
             launch_bgr_to_bgrx(c->img[k][v], W, H, c->img4[v], st);
         }
-        prof_end(c, ST_BOXSUM, 6, 0);
+        prof_end(c, ps3, ST_BOXSUM, 6, 0);
 
         // ---- initial match (.cpp:53-62) -> d16a
-        prof_begin(c, ST_INITIAL_MATCH);
+        const int ps4 = prof_begin(c, ST_INITIAL_MATCH);
         for (int v = 0; v < 2; v++) {
             launch_fill_i16(c->d16a[v], px, (int16_t)NOMATCH, st);
             a.d[v].d16_in = c->d16a[v];
@@ -448,66 +453,66 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             launch_hl_interval(a, st);
             launch_ncc_argmax(a, 1, st);
         }
-        prof_end(c, ST_INITIAL_MATCH, k == 0 ? 3 : 6, 24.0 * Pk);
+        prof_end(c, ps4, ST_INITIAL_MATCH, k == 0 ? 3 : 6, 24.0 * Pk);
 
         // ---- SmoothConstraint (.cpp:66-67): d16a -> d16b
-        prof_begin(c, ST_SMOOTH);
+        const int ps5 = prof_begin(c, ST_SMOOTH);
         for (int v = 0; v < 2; v++) {
             a.d[v].d16_in = c->d16a[v];
             a.d[v].d16_out = c->d16b[v];
         }
         launch_smooth(a, st);
-        prof_end(c, ST_SMOOTH, 1, 8.0 * Pk);
+        prof_end(c, ps5, ST_SMOOTH, 1, 8.0 * Pk);
 
         // ---- OrderConstraint (.cpp:71-72): d16b in place
-        prof_begin(c, ST_ORDER);
+        const int ps6 = prof_begin(c, ST_ORDER);
         for (int v = 0; v < 2; v++) a.d[v].d16_in = a.d[v].d16_out = c->d16b[v];
         launch_order(a, st);
-        prof_end(c, ST_ORDER, 1, 8.0 * Pk);
+        prof_end(c, ps6, ST_ORDER, 1, 8.0 * Pk);
 
         // ---- UniquenessContraint<short> (.cpp:75)
-        prof_begin(c, ST_UNIQ16);
+        const int ps7 = prof_begin(c, ST_UNIQ16);
         launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
         launch_uniq_s16(c->d16b[1], c->d16b[0], W, H, c->mg[k][1], c->mg[k][0], st);
         launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
-        prof_end(c, ST_UNIQ16, 3, 18.0 * Pk);
+        prof_end(c, ps7, ST_UNIQ16, 3, 18.0 * Pk);
 
         // ---- Rematch (.cpp:80-81): SetBoundary_smooth + NCC on still-unmatched pixels, in place
-        prof_begin(c, ST_REMATCH);
+        const int ps8 = prof_begin(c, ST_REMATCH);
         launch_set_boundary(a, st);
         launch_ncc_argmax(a, 2, st);
-        prof_end(c, ST_REMATCH, 3, 46.0 * Pk);
+        prof_end(c, ps8, ST_REMATCH, 3, 46.0 * Pk);
 
         // ---- UniquenessContraint<short> (.cpp:86)
-        prof_begin(c, ST_UNIQ16);
+        const int ps9 = prof_begin(c, ST_UNIQ16);
         launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
         launch_uniq_s16(c->d16b[1], c->d16b[0], W, H, c->mg[k][1], c->mg[k][0], st);
         launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
-        prof_end(c, ST_UNIQ16, 3, 18.0 * Pk);
+        prof_end(c, ps9, ST_UNIQ16, 3, 18.0 * Pk);
 
         // ---- MedianFilter (.cpp:89-90): d16b -> d16a (pre-filled NOMATCH, .cpp:772)
-        prof_begin(c, ST_MEDIAN);
+        const int ps10 = prof_begin(c, ST_MEDIAN);
         for (int v = 0; v < 2; v++) {
             launch_fill_i16(c->d16a[v], px, (int16_t)NOMATCH, st);
             a.d[v].d16_in = c->d16b[v];
             a.d[v].d16_out = c->d16a[v];
         }
         launch_median(a, st);
-        prof_end(c, ST_MEDIAN, 3, 10.0 * Pk);
+        prof_end(c, ps10, ST_MEDIAN, 3, 10.0 * Pk);
 
         // ---- DisparityRefine (.cpp:95-98): int16 d16a -> fp64, 30 + 30k Jacobi sweeps
         const int iters = 30 + k * 30;
         const int ia = (par + 1) % 3, ib = (par + 2) % 3;
-        prof_begin(c, ST_REFINE_INIT);
+        const int ps11 = prof_begin(c, ST_REFINE_INIT);
         for (int v = 0; v < 2; v++) {
             a.d[v].d16_in = c->d16a[v];
             a.d[v].f64_a = c->f64[ia][v];
             a.d[v].f64_b = c->f64[ib][v];
         }
         launch_refine_init(a, st);
-        prof_end(c, ST_REFINE_INIT, 1, 12.0 * Pk);
+        prof_end(c, ps11, ST_REFINE_INIT, 1, 12.0 * Pk);
         const int st_sweep = (k == N - 1) ? ST_REFINE_SWEEP_TOP : ST_REFINE_SWEEP;
-        prof_begin(c, st_sweep);
+        const int ps12 = prof_begin(c, st_sweep);
         int cur = ia, nxt = ib;
         a.flag = (k == N - 1);
         for (int v = 0; v < 2; v++) {
@@ -520,26 +525,33 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
                 a.d[v].f64_b = c->f64[nxt][v];
             }
             a.flag2 = it;
-            launch_refine_sweep(a, st);
+            if (c->profile && k == N - 1 && it > 0) { // per-launch events on the dominant kernel only
+                const int es = prof_slot(c, ST_REFINE_LIGHT_TOP);
+                launch_refine_sweep(a, st, c->evpool[es].a, c->evpool[es].b);
+                c->prof_launches[ST_REFINE_LIGHT_TOP] += 1;
+                c->prof_bytes[ST_REFINE_LIGHT_TOP] += 32.0 * Pk;
+            } else {
+                launch_refine_sweep(a, st);
+            }
             const int t = cur;
             cur = nxt;
             nxt = t;
         }
-        prof_end(c, st_sweep, iters, 32.0 * Pk * iters); // launches = sweeps (each = light kernel + worklist kernel)
+        prof_end(c, ps12, st_sweep, iters, 32.0 * Pk * iters); // launches = sweeps (each = light kernel + worklist kernel)
 
         // ---- UniquenessContraint<double> (.cpp:109) on the refined maps (now in f64[cur])
-        prof_begin(c, ST_UNIQ64);
+        const int ps13 = prof_begin(c, ST_UNIQ64);
         launch_uniq_f64(c->f64[cur][0], c->f64[cur][1], W, H, c->mg[k][0], c->mg[k][1], st);
         launch_uniq_f64(c->f64[cur][1], c->f64[cur][0], W, H, c->mg[k][1], c->mg[k][0], st);
         launch_uniq_f64(c->f64[cur][0], c->f64[cur][1], W, H, c->mg[k][0], c->mg[k][1], st);
-        prof_end(c, ST_UNIQ64, 3, 72.0 * Pk);
+        prof_end(c, ps13, ST_UNIQ64, 3, 72.0 * Pk);
         par = cur;
     }
 
     // ---- DisparityToCloud<double>(disparity[0], maskPyrm[top][0], Q, top, true) (.cpp:29)
     {
         const int k = N - 1, W = c->Wk[k], H = c->Hk[k];
-        prof_begin(c, ST_CLOUD);
+        const int ps14 = prof_begin(c, ST_CLOUD);
         const int ksize = (int)ceil(0.02 * H); // .cpp:703
         if (ksize > 4096) return set_err(c, RSM_E_INVALID, "erode size");
         std::vector<int> j1, j2;
@@ -558,7 +570,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         launch_cloud(c->f64[par][0], c->prefix, c->img[k][0], W, H, ksize, c->d_j1, c->d_j2, c->d_q, c->d_R, c->d_T,
                      c->mg[k][0], (uint8_t *)c->d16a[0], c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
         const Mg &m = c->mg[k][0];
-        prof_end(c, ST_CLOUD, 4, 28.0 * (double)(m.XR - m.XL + 1) * (m.YR - m.YL + 1));
+        prof_end(c, ps14, ST_CLOUD, 4, 28.0 * (double)(m.XR - m.XL + 1) * (m.YR - m.YL + 1));
     }
     int64_t np = 0;
     unsigned long long vt = 0;

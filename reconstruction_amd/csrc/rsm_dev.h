@@ -81,7 +81,8 @@ void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, h
 void launch_set_boundary(const StageArgs &a, hipStream_t st);  // d16_in, mask_own -> BL, BR
 void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out (pre-filled NOMATCH)
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
-void launch_refine_sweep(const StageArgs &a, hipStream_t st);  // f64_a -> f64_b
+// f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
+void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // cloud: returns nothing; *d_npoints (device int64) receives the point count
 void launch_bad_prefix(const uint8_t *mask, int W, int H, int32_t *prefix, hipStream_t st);
