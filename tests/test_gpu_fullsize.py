@@ -1,0 +1,100 @@
+"""Full-size (BASELINE.json C2: 4096x3072, 5 levels, 11x11 NCC) checks on the GPU path through properties that
+need no CPU oracle run (the oracle would take ~20 minutes at this size): a pure integer-shift scene, exact
+repeatability, margin / count invariants, cloud geometry."""
+import numpy as np
+import pytest
+
+from reconstruction_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+NOMATCH = -10000
+W, H, N, R = 4096, 3072, 5, 5
+SHIFT = 48  # divisible by 2^(N-1): an integer disparity at every pyramid level
+
+
+@pytest.fixture(scope="module")
+def shift_pair():
+    img0 = synth.make_texture(W, H, 77)
+    img1 = np.roll(img0, SHIFT, axis=1)
+    m0 = np.zeros((H, W), np.uint8)
+    m0[128:H - 128, 1024:3072] = 255
+    m1 = np.roll(m0, SHIFT, axis=1)
+    Q, Rm, T = synth.pinhole_calibration(W, H, 0)
+    return synth.PairConfig(width=W, height=H, pyr_levels=N, radius=R, ws=0.03, offset=2, origin_width=W,
+                            image=[img0, img1], mask=[m0, m1], Q=Q, R_final=Rm, T_final=T, name="shift48")
+
+
+@pytest.fixture(scope="module")
+def shift_result(ctx, shift_pair):
+    return ctx.match_pair(shift_pair)
+
+
+def test_fullsize_shift_scene_recovers_the_shift(shift_pair, shift_result):
+    res = shift_result
+    m0 = shift_pair.mask[0] == 255
+    for v, s in ((0, SHIFT), (1, -SHIFT)):
+        d = res.disparity[v]
+        inside = shift_pair.mask[v] == 255
+        valid = inside & (d != NOMATCH)
+        assert valid.sum() > 0.97 * inside.sum()
+        # the NCC match is exact at every level; the refinement moves it by at most its half-pixel steps, and for
+        # negative disparities the reference's int(d - 1.5) truncation (.cpp:625) centres the three taps one pixel
+        # low: the whole map sits ~1 px below the true value (kept on purpose)
+        err = np.abs(d[valid] - (s if s > 0 else s - 1))
+        assert np.percentile(err, 99) < 0.75 and err.max() <= 1.0 + 1e-9, (np.percentile(err, 99), err.max())
+        assert (d[~inside] == NOMATCH).all()
+    assert res.v_top == int(m0.sum())
+
+
+def test_fullsize_margins_and_counts(shift_pair, shift_result):
+    res = shift_result
+    for v in range(2):
+        ys, xs = np.nonzero(shift_pair.mask[v][R:H - R, R:W - R] == 255)
+        YL, YR, XL, XR, w, h = res.margin[v]
+        assert (YL, YR, XL, XR) == (ys.min() + R, ys.max() + R, xs.min() + R, xs.max() + R)
+        assert (w, h) == (XR - XL + 1, YR - YL + 1)
+    assert 0 < res.n_points <= res.v_top
+    assert res.xyz.shape == (res.n_points, 3) and res.bgr.shape == (res.n_points, 3)
+
+
+def test_fullsize_cloud_of_constant_disparity_is_a_plane(shift_pair, shift_result):
+    res = shift_result
+    z = res.xyz[:, 2]
+    f, B = 1.2 * W, 100.0
+    z_expected = f / (-(1.0 / B) * SHIFT)          # Z = q23 / (q32 * d), Q as Rectify leaves it (.cpp:138,745-748)
+    assert np.isfinite(z).all()
+    assert np.percentile(np.abs(z / z_expected - 1.0), 99) < 0.75 / SHIFT
+
+
+def test_fullsize_run_is_bit_repeatable(ctx, shift_pair, shift_result):
+    again = ctx.match_pair(shift_pair)
+    for v in range(2):
+        assert np.array_equal(again.disparity[v], shift_result.disparity[v])
+    assert np.array_equal(again.xyz, shift_result.xyz) and np.array_equal(again.bgr, shift_result.bgr)
+
+
+def test_fullsize_c2_workload_invariants(ctx):
+    cfg = synth.config_c2()
+    res = ctx.match_pair(cfg, want_cloud=False)
+    assert res.v_top == int((cfg.mask[0] == 255).sum()) == 5767168
+    d0, d1 = res.disparity
+    inside = cfg.mask[0] == 255
+    valid = inside & (d0 != NOMATCH)
+    assert valid.sum() > 0.9 * inside.sum()
+    # left-right consistency of the two refined maps (UniquenessContraint<double>, .cpp:463-497, leaves only
+    # pixels whose partner agrees within 2 px or that were rescued by a neighbour)
+    ys, xs = np.nonzero(valid)
+    sel = slice(None, None, 97)
+    t = np.clip(np.rint(xs[sel] + d0[ys[sel], xs[sel]]).astype(np.int64), 0, W - 1)
+    back = d1[ys[sel], t]
+    ok = back != NOMATCH
+    assert ok.mean() > 0.9
+    assert np.percentile(np.abs(back[ok] + d0[ys[sel], xs[sel]][ok]), 95) < 2.0
+    # accuracy against the generating field: view1(x1) = view0(x1 - disp1(x1)), so d(x0) solves x1 = x0 + disp1(x1)
+    x0 = xs[sel].astype(np.float64)
+    x1 = x0.copy()
+    for _ in range(12):
+        x1 = x0 + cfg.true_disparity[ys[sel], np.clip(np.rint(x1).astype(np.int64), 0, W - 1)]
+    err = np.abs(d0[ys[sel], xs[sel]] - (x1 - x0))
+    assert np.median(err) < 0.5 and np.percentile(err, 95) < 1.5, (np.median(err), np.percentile(err, 95))
