@@ -525,7 +525,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
                 a.d[v].f64_b = c->f64[nxt][v];
             }
             a.flag2 = it;
-            if (c->profile && k == N - 1 && it > 0) { // per-launch events on the dominant kernel only
+            if (c->profile && k == N - 1 && (it & 7) == 4) { // events around every 8th launch of the dominant kernel
                 const int es = prof_slot(c, ST_REFINE_LIGHT_TOP);
                 launch_refine_sweep(a, st, c->evpool[es].a, c->evpool[es].b);
                 c->prof_launches[ST_REFINE_LIGHT_TOP] += 1;
