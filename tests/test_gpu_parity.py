@@ -27,6 +27,11 @@ CASES = {
                               mask_l0_width=48, border_l0=5),
     "s320x160_occluded_neg_r4": dict(width=320, height=160, levels=2, radius=4, offset=3, pair=7, occlude=True,
                                      holes=True, mask_l0_width=120, border_l0=6),
+    "s200x120_r7_single_level": dict(width=200, height=120, levels=1, radius=7, offset=2, pair=8, mask_l0_width=150,
+                                     border_l0=12, d0_l0=5.0),
+    "s144x96_r1_r6": dict(width=144, height=96, levels=2, radius=1, offset=5, pair=9, occlude=True, mask_l0_width=50,
+                          border_l0=4),
+    "s288x160_r6": dict(width=288, height=160, levels=3, radius=6, offset=2, pair=10, mask_l0_width=40, border_l0=9),
 }
 
 _cache = {}
