@@ -51,10 +51,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    # RSM_BENCH_BACKEND=gloo lets the N > 1 control flow be exercised on a single-GPU box (ranks share device 0,
+    # clouds go through host memory); the real multi-GPU run uses nccl = RCCL over xGMI.
+    backend = os.environ.get("RSM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     make = {"c2": synth.config_c2, "c2s": synth.config_c2_sample, "c1": synth.config_c1,
@@ -78,6 +86,8 @@ def main():
             xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
             bgr = torch.empty((n, 3), dtype=torch.uint8, device=dev)
             ctx.export_cloud_device(xyz.data_ptr(), bgr.data_ptr(), n)
+            if backend != "nccl":
+                xyz, bgr = xyz.cpu(), bgr.cpu()
             return gather_clouds([(rank, xyz, bgr)], dst=0)
         return None
 
@@ -105,7 +115,7 @@ def main():
     res = ctx.download_pair(want_cloud=False, want_disparity=False)
     v_top = res.v_top
     if world > 1:
-        t = torch.tensor([dt, float(v_top)], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, float(v_top)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -176,7 +186,7 @@ def cpu_baseline(synth):
     r = orc.match_pair(cfg, want_cloud=True, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": round(r["v_top"] / dt / 1e6, 5), "unit": "Mdisparities/s", "cores": cores, "kind": "port",
-            "sample": "%s: one pair, 5 levels, 11x11 NCC, offset 2, 9/64 of C2's area, %d masked pixels, %.1f s "
+            "sample": "%s: one pair, 5 levels, 11x11 NCC, offset 2, 1/4 of C2's area, %d masked pixels, %.1f s "
                       "(refine %.1f s, NCC match %.1f s)" % (cfg.name, r["v_top"], dt, r["refine_seconds"], r["match_seconds"])}
 
 

@@ -171,9 +171,9 @@ def config_c2(pair: int = 0) -> PairConfig:
 
 
 def config_c2_sample(pair: int = 0) -> PairConfig:
-    """Bounded CPU sample of C2: same 5 levels / 11x11 / offset 2, 9/64 of the area (1536x1152)."""
-    return make_pair(1536, 1152, 5, radius=5, offset=2, pair=pair, mask_kind="rect", mask_l0_width=48,
-                     border_l0=6, d0_l0=2.0, amp_l0=1.0, name="C2s_1536x1152_r5_d48")
+    """Bounded CPU sample of C2: same 5 levels / 11x11 / offset 2, 1/4 of the area (2048x1536)."""
+    return make_pair(2048, 1536, 5, radius=5, offset=2, pair=pair, mask_kind="rect", mask_l0_width=64,
+                     border_l0=6, d0_l0=2.0, amp_l0=1.0, name="C2s_2048x1536_r5_d64")
 
 
 def config_c3(pair: int = 0) -> PairConfig:
