@@ -150,6 +150,12 @@ int rsm_stage_cloud(rsm_ctx *ctx, const double *disp, const uint8_t *mask_org, c
                     const double *T_final, const rsm_boundary *own, double *xyz, uint8_t *bgr,
                     int64_t max_points, int64_t *n_points);
 
+/* ---- cloud interchange ----------------------------------------------------- */
+/* Writes the debug / interchange PLY of CStereoMatching::DisparityToCloud (.cpp:723-729 header, :754-756
+ * records): binary_little_endian, per vertex float x,y,z (the fp64 point cast to float, .cpp:754) and uchar
+ * blue,green,red.  Host-only (no GPU needed). Returns 0 or RSM_E_INVALID. */
+int rsm_write_ply(const char *path, const double *xyz, const uint8_t *bgr, int64_t n_points);
+
 /* ---- kernel microbenchmark (MDE/s: pixel x candidate NCC evaluations) -------------------- */
 /* Runs the NCC interval-argmax kernel `iters` times on a resident level-sized problem with
  * `cands` candidates per pixel and returns average milliseconds per launch. */

@@ -4,5 +4,6 @@ Only what the path needs: csrc/ (HIP kernels + the C ABI of include/rsm.h), a ct
 host-side mirror of the reference's CStereoMatching call surface, synthetic inputs, and the
 pair-sharding / RCCL cloud gather for multi-GPU runs.
 """
-from .api import Context, StereoMatching, ManageData, Camera, PairResult, Boundary, NOMATCH, RsmError  # noqa: F401
+from .api import (Context, StereoMatching, ManageData, Camera, PairResult, Boundary, NOMATCH, RsmError,  # noqa: F401
+                  write_ply)
 from . import synth  # noqa: F401

@@ -60,7 +60,7 @@ EXPORTS = [
     "rsm_stage_find_margin", "rsm_stage_pyr_down", "rsm_stage_erode_ellipse", "rsm_stage_initial_match",
     "rsm_stage_smooth", "rsm_stage_order", "rsm_stage_uniqueness_pass_s16", "rsm_stage_uniqueness_pass_f64",
     "rsm_stage_set_boundary", "rsm_stage_rematch", "rsm_stage_median", "rsm_stage_refine", "rsm_stage_cloud",
-    "rsm_bench_ncc",
+    "rsm_bench_ncc", "rsm_write_ply",
 ]
 
 _lib = None

@@ -36,6 +36,16 @@ def _bd(t) -> Boundary:
     return Boundary(*t)
 
 
+def write_ply(path, xyz, bgr):
+    """cloud%d.ply of DisparityToCloud (.cpp:723-729,754-756) through the C ABI (host-only, no GPU needed)."""
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    bgr = _u8(bgr).reshape(-1, 3)
+    assert len(xyz) == len(bgr)
+    st = _lib.load().rsm_write_ply(str(path).encode(), _p(xyz), _p(bgr), C.c_int64(len(xyz)))
+    if st != 0:
+        raise RsmError(st, "rsm_write_ply(%s)" % path)
+
+
 @dataclass
 class PairResult:
     disparity: list            # [2] float64 HxW (NOMATCH = -10000)
@@ -386,6 +396,8 @@ class StereoMatching:
             self.disparity = res.disparity
             if self.Verbose >= 1:
                 print("\tconverting disparity to cloud %d..." % CamPair)
+            if getattr(data, "isoutput", 0):   # .cpp:707-730,753-757: cloud%d.ply in the working directory
+                write_ply("cloud%d.ply" % CamPair, res.xyz, res.bgr)
             sink = self.m_CloudOptimization
             if sink is not None:
                 if hasattr(sink, "InsertPoints"):

@@ -1014,6 +1014,26 @@ extern "C" int rsm_stage_cloud(rsm_ctx *c, const double *disp, const uint8_t *ma
     return finish(c, t);
 }
 
+// ---- PLY writer (CStereoMatching.cpp:723-729, 754-756) ----------------------------------------------
+extern "C" int rsm_write_ply(const char *path, const double *xyz, const uint8_t *bgr, int64_t n) {
+    if (!path || n < 0 || (n > 0 && (!xyz || !bgr))) return RSM_E_INVALID;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return RSM_E_INVALID;
+    fprintf(fp, "ply\n");
+    fprintf(fp, "format binary_little_endian 1.0\n");
+    fprintf(fp, "element vertex %d\n", (int)n);
+    fprintf(fp, "property float x\nproperty float y\nproperty float z\nproperty uchar blue\nproperty uchar green\nproperty uchar red\n");
+    fprintf(fp, "end_header\n");
+    for (int64_t i = 0; i < n; i++) {
+        const float p[3] = {(float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]}; // convertTo CV_32F, .cpp:754
+        fwrite(p, sizeof(float), 3, fp);
+        fwrite(bgr + 3 * i, 1, 3, fp);
+    }
+    const int ok = ferror(fp) == 0;
+    fclose(fp);
+    return ok ? RSM_OK : RSM_E_INVALID;
+}
+
 // ---- NCC kernel microbenchmark --------------------------------------------------------------------
 extern "C" int rsm_bench_ncc(rsm_ctx *c, int W, int H, int r, int cands, int iters, double *ms_per_launch) {
     if (!stage_ok(c, W, H) || r < 1 || r > 15 || cands < 1 || iters < 1 || !ms_per_launch) return RSM_E_INVALID;
