@@ -60,7 +60,7 @@ def dump_opencv_yaml(path: str, data: dict) -> None:
             elif isinstance(v, (list, tuple)):
                 f.write("%s:\n" % k)
                 for s in v:
-                    f.write('   - "%s"\n' % s)
+                    f.write('   - "%s"\n' % str(s).replace("\\", "\\\\"))
             elif isinstance(v, str):
                 f.write('%s: "%s"\n' % (k, v.replace("\\", "\\\\")))
             else:
