@@ -150,6 +150,41 @@ int rsm_stage_cloud(rsm_ctx *ctx, const double *disp, const uint8_t *mask_org, c
                     const double *T_final, const rsm_boundary *own, double *xyz, uint8_t *bgr,
                     int64_t max_points, int64_t *n_points);
 
+/* ---- Rectify (CStereoMatching::Rectify, reconstruction/CStereoMatching.cpp:117-168) -------- */
+typedef struct rsm_rectify_in {
+    double K[2][9];                   /* cam[pair][v].MatIntrinsics, row-major 3x3 (CManageData.cpp:59)   */
+    double E[2][12];                  /* cam[pair][v].MatExtrinsics, row-major 3x4 (CManageData.cpp:60)   */
+    int origin_width, origin_height;  /* m_OriginSize: size of the raw images (CManageData.cpp:68-69)     */
+    int lowest_width, lowest_height;  /* m_LowestLevelSize                                                */
+    int pyr_levels;                   /* m_PyrmNum                                                        */
+    const uint8_t *image[2];          /* raw BGR images (cv::imread, .cpp:146), origin size, host memory  */
+    const uint8_t *mask[2];           /* raw grey masks (.cpp:155), origin size, host memory              */
+} rsm_rectify_in;
+
+typedef struct rsm_rectify_out {
+    double Q[16];                     /* after the sign flip of .cpp:138                                  */
+    double R_final[9], T_final[3];    /* .cpp:132-133                                                     */
+    double P[2][12];                  /* cam[pair][v].P after .cpp:143-145                                */
+    int width, height;                /* largestSize (.cpp:120)                                           */
+    uint8_t *image[2];                /* optional host copies of cam[pair][v].image, width*height*3       */
+    uint8_t *mask[2];                 /* optional host copies of cam[pair][v].mask (eroded), width*height */
+} rsm_rectify_out;
+
+/* Rectifies one pair on the GPU (host fp64 stereoRectify, device maps / remap / mask erosion) and leaves the
+ * rectified images resident exactly as rsm_upload_pair would, with Q / R_final / T_final set: rsm_run_pair
+ * can follow directly.  radius / ws / offset / verbose are CStereoMatching::Init's parameters. */
+int rsm_rectify_pair(rsm_ctx *ctx, const rsm_rectify_in *in, int radius, double ws, int offset, int verbose,
+                     rsm_rectify_out *out);
+/* cv::stereoRectify(K1, 0, K2, 0, (nx, ny), R, T, R1, R2, P1, P2, Q, flags = 0, alpha = -1) -- host only. */
+int rsm_stereo_rectify(const double *K1, const double *K2, int nx, int ny, const double *R, const double *T,
+                       double *R1, double *R2, double *P1, double *P2, double *Q);
+/* stage entry points for the parity tests */
+int rsm_stage_rect_map(rsm_ctx *ctx, const double *A, const double *R, const double *newA, int W, int H,
+                       int16_t *map1, uint16_t *map2);
+int rsm_stage_remap(rsm_ctx *ctx, const uint8_t *src, int Ws, int Hs, int channels, const int16_t *map1,
+                    const uint16_t *map2, int W, int H, uint8_t *dst);
+int rsm_stage_erode_gray(rsm_ctx *ctx, const uint8_t *src, int W, int H, int ksize, uint8_t *dst);
+
 /* ---- cloud interchange ----------------------------------------------------- */
 /* Writes the debug / interchange PLY of CStereoMatching::DisparityToCloud (.cpp:723-729 header, :754-756
  * records): binary_little_endian, per vertex float x,y,z (the fp64 point cast to float, .cpp:754) and uchar

@@ -44,8 +44,8 @@ class PairOut(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(HERE, "liborc.so")
-    src = os.path.join(HERE, "stereo_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("stereo_oracle.c", "rectify_oracle.c", "stereo_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     return so
 
@@ -294,3 +294,50 @@ def match_pair(cfg, want_cloud=True, threads=None):
             "n_points": n, "xyz": xyz[:min(n, cap)].copy(), "bgr": bgr[:min(n, cap)].copy(),
             "level_seconds": list(pout.level_seconds)[:cfg.pyr_levels], "refine_seconds": pout.refine_seconds,
             "match_seconds": pout.match_seconds, "v_top": int(pout.v_top), "threads": L.orc_num_threads()}
+
+
+# ---- Rectify (rectify_oracle.c) ------------------------------------------------------------------
+def stereo_rectify(K1, K2, size, R, T):
+    """cv::stereoRectify(K1, 0, K2, 0, size, R, T, flags=0, alpha=-1). Returns R1, R2, P1, P2, Q."""
+    a = [np.ascontiguousarray(x, np.float64) for x in (K1, K2, R, T)]
+    R1 = np.zeros((3, 3)); R2 = np.zeros((3, 3)); P1 = np.zeros((3, 4)); P2 = np.zeros((3, 4)); Q = np.zeros((4, 4))
+    lib().orc_stereo_rectify(_p(a[0]), _p(a[1]), int(size[0]), int(size[1]), _p(a[2]), _p(a[3]),
+                             _p(R1), _p(R2), _p(P1), _p(P2), _p(Q))
+    return R1, R2, P1, P2, Q
+
+
+def rodrigues(x):
+    x = np.ascontiguousarray(x, np.float64)
+    if x.size == 3:
+        R = np.zeros((3, 3)); lib().orc_rodrigues_v2m(_p(x), _p(R)); return R
+    r = np.zeros(3); lib().orc_rodrigues_m2v(_p(x), _p(r)); return r
+
+
+def init_rectify_map(A, R, newA, W, H):
+    A, R, newA = (np.ascontiguousarray(x, np.float64) for x in (A, R, newA))
+    m1 = np.zeros((H, W, 2), np.int16); m2 = np.zeros((H, W), np.uint16)
+    lib().orc_init_rectify_map(_p(A), _p(R), _p(newA), W, H, _p(m1), _p(m2))
+    return m1, m2
+
+
+def remap_linear(src, map1, map2):
+    src = _u8(src); Hs, Ws = src.shape[:2]; Cn = 1 if src.ndim == 2 else src.shape[2]
+    H, W = map2.shape
+    dst = np.zeros((H, W) + (() if src.ndim == 2 else (Cn,)), np.uint8)
+    m1 = np.ascontiguousarray(map1, np.int16); m2 = np.ascontiguousarray(map2, np.uint16)
+    lib().orc_remap_linear_u8(_p(src), Ws, Hs, Cn, _p(m1), _p(m2), W, H, _p(dst))
+    return dst
+
+
+def rectify_pair(K, E, origin_size, lowest_size, N, imgs, msks):
+    """CStereoMatching::Rectify for one pair. K, E: [2] 3x3 / 3x4. Returns dict(image, mask, Q, R_final, T_final, P)."""
+    K = [np.ascontiguousarray(k, np.float64) for k in K]; E = [np.ascontiguousarray(e, np.float64) for e in E]
+    imgs = [_u8(i) for i in imgs]; msks = [_u8(m) for m in msks]
+    W, H = lowest_size[0] << (N - 1), lowest_size[1] << (N - 1)
+    rimg = [np.zeros((H, W, 3), np.uint8) for _ in range(2)]; rmsk = [np.zeros((H, W), np.uint8) for _ in range(2)]
+    Q = np.zeros((4, 4)); Rf = np.zeros((3, 3)); Tf = np.zeros(3); P = [np.zeros((3, 4)) for _ in range(2)]
+    arr = lambda xs: (C.c_void_p * 2)(*[x.ctypes.data for x in xs])
+    lib().orc_rectify_pair(_p(K[0]), _p(K[1]), _p(E[0]), _p(E[1]), int(origin_size[0]), int(origin_size[1]),
+                           int(lowest_size[0]), int(lowest_size[1]), int(N), arr(imgs), arr(msks), arr(rimg), arr(rmsk),
+                           _p(Q), _p(Rf), _p(Tf), arr(P))
+    return dict(image=rimg, mask=rmsk, Q=Q, R_final=Rf, T_final=Tf, P=P)

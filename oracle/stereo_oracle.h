@@ -125,6 +125,19 @@ int64_t orc_disparity_to_cloud(const double *disp, const uint8_t *mask_org,
  * the reference's exit(0) at :827-830). */
 int orc_match_pair(const orc_pair_in *in, orc_pair_out *out);
 
+/* ---- Rectify (rectify_oracle.c; OpenCV 2.4 operations restated, parity unpinned) ---- */
+void orc_rodrigues_v2m(const double *r, double *R);
+void orc_rodrigues_m2v(const double *R, double *r);
+void orc_stereo_rectify(const double *K1, const double *K2, int nx, int ny, const double *R, const double *T,
+                        double *R1, double *R2, double *P1, double *P2, double *Q);
+void orc_init_rectify_map(const double *A, const double *R, const double *newA, int W, int H, int16_t *map1,
+                          uint16_t *map2);
+void orc_remap_linear_u8(const uint8_t *src, int Ws, int Hs, int C, const int16_t *map1, const uint16_t *map2,
+                         int W, int H, uint8_t *dst);
+void orc_rectify_pair(const double *K0, const double *K1, const double *E0, const double *E1, int originW, int originH,
+                      int lowW, int lowH, int N, const uint8_t *const img[2], const uint8_t *const msk[2],
+                      uint8_t *rimg[2], uint8_t *rmsk[2], double *Q, double *R_final, double *T_final, double *Pout[2]);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

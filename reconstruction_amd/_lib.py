@@ -52,6 +52,19 @@ class PairOut(C.Structure):
                 ("xyz", C.c_void_p), ("bgr", C.c_void_p), ("v_top", C.c_int64)]
 
 
+class RectifyIn(C.Structure):
+    _fields_ = [("K", (C.c_double * 9) * 2), ("E", (C.c_double * 12) * 2),
+                ("origin_width", C.c_int), ("origin_height", C.c_int), ("lowest_width", C.c_int),
+                ("lowest_height", C.c_int), ("pyr_levels", C.c_int),
+                ("image", C.c_void_p * 2), ("mask", C.c_void_p * 2)]
+
+
+class RectifyOut(C.Structure):
+    _fields_ = [("Q", C.c_double * 16), ("R_final", C.c_double * 9), ("T_final", C.c_double * 3),
+                ("P", (C.c_double * 12) * 2), ("width", C.c_int), ("height", C.c_int),
+                ("image", C.c_void_p * 2), ("mask", C.c_void_p * 2)]
+
+
 # every symbol include/rsm.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
     "rsm_create", "rsm_destroy", "rsm_last_error", "rsm_version", "rsm_match_pair", "rsm_upload_pair",
@@ -60,7 +73,8 @@ EXPORTS = [
     "rsm_stage_find_margin", "rsm_stage_pyr_down", "rsm_stage_erode_ellipse", "rsm_stage_initial_match",
     "rsm_stage_smooth", "rsm_stage_order", "rsm_stage_uniqueness_pass_s16", "rsm_stage_uniqueness_pass_f64",
     "rsm_stage_set_boundary", "rsm_stage_rematch", "rsm_stage_median", "rsm_stage_refine", "rsm_stage_cloud",
-    "rsm_bench_ncc", "rsm_write_ply",
+    "rsm_bench_ncc", "rsm_write_ply", "rsm_rectify_pair", "rsm_stereo_rectify", "rsm_stage_rect_map",
+    "rsm_stage_remap", "rsm_stage_erode_gray",
 ]
 
 _lib = None

@@ -6,10 +6,10 @@ margin, MatchBlockRadius, m_ws, m_offset, Verbose); `ManageData` / `Camera` carr
 CManageData.h:16-40 this path reads and writes.  All compute goes through the C ABI of
 include/rsm.h (librsm_mi355.so, hand-written HIP for gfx950) -- there is no CPU path here.
 
-Scope note: CStereoMatching::Rectify (.cpp:117-168, OpenCV stereoRectify/remap) is a "next" row
-(SURVEY.md 8(f1)); MatchAllLayer here starts from rectified top-level images, i.e. each
-`ManageData.cam[pair][v]` must already hold `.image` / `.mask` (what Rectify leaves there, .cpp:154-158)
-and `ManageData.rectified[pair]` the Q / R_final / T_final Rectify computes (.cpp:128-138).
+MatAllLayer either rectifies on the GPU (cameras carry calibration + raw image / mask
+files or arrays, `ManageData.rectified[pair]` is absent) or starts from rectified inputs (each
+`ManageData.cam[pair][v]` holds what Rectify leaves in `.image` / `.mask`, .cpp:154-158, and
+`ManageData.rectified[pair]` the Q / R_final / T_final it computes, .cpp:128-138).
 """
 from __future__ import annotations
 
@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import Boundary, NOMATCH, PairIn, PairOut, RsmError  # noqa: F401
+from ._lib import Boundary, NOMATCH, PairIn, PairOut, RectifyIn, RectifyOut, RsmError  # noqa: F401
 
 
 def _u8(a):
@@ -34,6 +34,17 @@ def _bd(t) -> Boundary:
     if isinstance(t, Boundary):
         return t
     return Boundary(*t)
+
+
+def stereo_rectify(K1, K2, size, R, T):
+    """cv::stereoRectify(K1, 0, K2, 0, size, R, T, flags=0, alpha=-1) through the C ABI (host fp64, no GPU needed)."""
+    a = [np.ascontiguousarray(x, np.float64) for x in (K1, K2, R, T)]
+    R1 = np.zeros((3, 3)); R2 = np.zeros((3, 3)); P1 = np.zeros((3, 4)); P2 = np.zeros((3, 4)); Q = np.zeros((4, 4))
+    st = _lib.load().rsm_stereo_rectify(_p(a[0]), _p(a[1]), int(size[0]), int(size[1]), _p(a[2]), _p(a[3]),
+                                        _p(R1), _p(R2), _p(P1), _p(P2), _p(Q))
+    if st != 0:
+        raise RsmError(st, "rsm_stereo_rectify")
+    return R1, R2, P1, P2, Q
 
 
 def write_ply(path, xyz, bgr):
@@ -124,6 +135,56 @@ class Context:
             pin.mask[v] = int(mask_ptrs[v])
         self._chk(self._lib.rsm_upload_pair_device(self._h, C.byref(pin)))
         self._shape = (cfg.height, cfg.width)
+
+    def rectify_pair(self, K, E, origin_size, lowest_size, pyr_levels, images, masks, radius=2, ws=0.03, offset=2,
+                     verbose=0, want_images=True):
+        """CStereoMatching::Rectify for one pair on the GPU (.cpp:117-168); the rectified pair stays resident, so
+        run_pair() can follow.  K / E: [2] 3x3 / 3x4, images / masks: raw BGR / grey arrays of origin size
+        (width, height).  Returns dict(image, mask, Q, R_final, T_final, P, size)."""
+        rin, rout = RectifyIn(), RectifyOut()
+        imgs = [_u8(i) for i in images]
+        msks = [_u8(m) for m in masks]
+        ow, oh = int(origin_size[0]), int(origin_size[1])
+        for v in range(2):
+            assert imgs[v].shape == (oh, ow, 3) and msks[v].shape == (oh, ow)
+            rin.K[v][:] = list(np.asarray(K[v], np.float64).ravel())
+            rin.E[v][:] = list(np.asarray(E[v], np.float64).ravel())
+            rin.image[v] = imgs[v].ctypes.data
+            rin.mask[v] = msks[v].ctypes.data
+        rin.origin_width, rin.origin_height = ow, oh
+        rin.lowest_width, rin.lowest_height, rin.pyr_levels = int(lowest_size[0]), int(lowest_size[1]), int(pyr_levels)
+        W, H = rin.lowest_width << (pyr_levels - 1), rin.lowest_height << (pyr_levels - 1)
+        rimg = [np.zeros((H, W, 3), np.uint8) for _ in range(2)] if want_images else [None, None]
+        rmsk = [np.zeros((H, W), np.uint8) for _ in range(2)] if want_images else [None, None]
+        if want_images:
+            for v in range(2):
+                rout.image[v] = rimg[v].ctypes.data
+                rout.mask[v] = rmsk[v].ctypes.data
+        self._chk(self._lib.rsm_rectify_pair(self._h, C.byref(rin), int(radius), C.c_double(ws), int(offset), int(verbose),
+                                             C.byref(rout)))
+        self._shape = (H, W)
+        return dict(image=rimg, mask=rmsk, Q=np.array(rout.Q).reshape(4, 4), R_final=np.array(rout.R_final).reshape(3, 3),
+                    T_final=np.array(rout.T_final), P=[np.array(rout.P[v]).reshape(3, 4) for v in range(2)], size=(W, H))
+
+    def rect_map(self, A, R, newA, W, H):
+        A, R, newA = (np.ascontiguousarray(x, np.float64) for x in (A, R, newA))
+        m1 = np.zeros((H, W, 2), np.int16); m2 = np.zeros((H, W), np.uint16)
+        self._chk(self._lib.rsm_stage_rect_map(self._h, _p(A), _p(R), _p(newA), W, H, _p(m1), _p(m2)))
+        return m1, m2
+
+    def remap_linear(self, src, map1, map2):
+        src = _u8(src); Hs, Ws = src.shape[:2]; ch = 1 if src.ndim == 2 else src.shape[2]
+        H, W = map2.shape
+        m1 = np.ascontiguousarray(map1, np.int16); m2 = np.ascontiguousarray(map2, np.uint16)
+        dst = np.zeros((H, W) + (() if src.ndim == 2 else (ch,)), np.uint8)
+        self._chk(self._lib.rsm_stage_remap(self._h, _p(src), Ws, Hs, ch, _p(m1), _p(m2), W, H, _p(dst)))
+        return dst
+
+    def erode_ellipse_gray(self, mask, ksize):
+        mask = _u8(mask); H, W = mask.shape
+        dst = np.zeros_like(mask)
+        self._chk(self._lib.rsm_stage_erode_gray(self._h, _p(mask), W, H, ksize, _p(dst)))
+        return dst
 
     def run_pair(self):
         self._chk(self._lib.rsm_run_pair(self._h))
@@ -313,6 +374,9 @@ class Camera:
     bound: tuple | None = None        # written by MatchAllLayer (.cpp:27-28)
     image_name: str = ""
     mask_name: str = ""
+    MatIntrinsics: np.ndarray | None = None   # 3x3 (CManageData.cpp:59)
+    MatExtrinsics: np.ndarray | None = None   # 3x4 (CManageData.cpp:60)
+    CamCenter: np.ndarray | None = None       # -R^T t as float32 (CManageData.cpp:61-62)
 
 
 @dataclass
@@ -373,11 +437,38 @@ class StereoMatching:
             cams = data.cam[CamPair]
             if self.Verbose >= 1:
                 print("processing pair %d: cam %d and cam %d..." % (CamPair + 1, cams[0].camID, cams[1].camID))
-            if cams[0].image is None or cams[1].image is None:
-                # reference: "read image ... error" then silent return from Rectify (.cpp:147-151)
-                print("read image %s error" % (cams[0].image_name or cams[1].image_name))
-                return
-            rect = data.rectified[CamPair]
+            pre_rectified = CamPair < len(data.rectified) and data.rectified[CamPair] is not None
+            if not pre_rectified:
+                # Rectify(CamPair, Q), .cpp:20 / :117-168: raw images + calibration -> rectified pair on the GPU
+                from . import config as _cfg
+                if self.Verbose >= 1:
+                    print("\trectifying...")
+                raw, rawm = [], []
+                for j in range(2):
+                    img = getattr(cams[j], "raw_image", None)
+                    if img is None:
+                        img = _cfg.imread_bgr(cams[j].image_name)
+                    if img is None:
+                        print("read image %s error" % cams[j].image_name)   # .cpp:147-151: silent return
+                        return
+                    msk = getattr(cams[j], "raw_mask", None)
+                    if msk is None:
+                        msk = _cfg.imread_gray(cams[j].mask_name)
+                    if msk is None:
+                        print("read image %s error" % cams[j].mask_name)
+                        return
+                    raw.append(img)
+                    rawm.append(msk)
+                rect = self._ctx.rectify_pair([cams[0].MatIntrinsics, cams[1].MatIntrinsics],
+                                              [cams[0].MatExtrinsics, cams[1].MatExtrinsics], data.m_OriginSize,
+                                              data.m_LowestLevelSize, data.m_PyrmNum, raw, rawm)
+                for j in range(2):
+                    cams[j].image, cams[j].mask, cams[j].P = rect["image"][j], rect["mask"][j], rect["P"][j]
+            else:
+                if cams[0].image is None or cams[1].image is None:
+                    print("read image %s error" % (cams[0].image_name or cams[1].image_name))
+                    return
+                rect = data.rectified[CamPair]
             self.Q = np.asarray(rect["Q"], np.float64)
             self.R_final = np.asarray(rect["R_final"], np.float64)
             self.T_final = np.asarray(rect["T_final"], np.float64)

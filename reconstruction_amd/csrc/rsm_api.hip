@@ -5,6 +5,7 @@
 // kept exactly) -> DisparityToCloud<double> (:682-761).  Everything stays resident in HBM between the one
 // upload and the one download; both matching directions run in the same launches (gridDim.z).
 #include "../../include/rsm.h"
+#include "rectify_host.h"
 #include "rsm_dev.h"
 
 #include <math.h>
@@ -1011,6 +1012,143 @@ extern "C" int rsm_stage_cloud(rsm_ctx *c, const double *disp, const uint8_t *ma
     const int64_t m = n < cap ? n : cap;
     if (m > 0 && dx) t.down(xyz, (const double *)dx, (size_t)m * 3);
     if (m > 0 && db) t.down(bgr, (const uint8_t *)db, (size_t)m * 3);
+    return finish(c, t);
+}
+
+
+// =================================================================================================
+// Rectify (CStereoMatching.cpp:117-168): host fp64 plan + device maps / remap / grey erosion.
+// =================================================================================================
+extern "C" int rsm_stereo_rectify(const double *K1, const double *K2, int nx, int ny, const double *R, const double *T,
+                                  double *R1, double *R2, double *P1, double *P2, double *Q) {
+    if (!K1 || !K2 || !R || !T || !R1 || !R2 || !P1 || !P2 || !Q || nx <= 0 || ny <= 0) return RSM_E_INVALID;
+    stereo_rectify_host(K1, K2, nx, ny, R, T, R1, R2, P1, P2, Q);
+    return RSM_OK;
+}
+
+extern "C" int rsm_rectify_pair(rsm_ctx *c, const rsm_rectify_in *in, int radius, double ws, int offset, int verbose,
+                                rsm_rectify_out *out) {
+    if (!c || !in || !out) return RSM_E_INVALID;
+    if (in->origin_width <= 0 || in->origin_height <= 0 || in->lowest_width <= 0 || in->lowest_height <= 0 ||
+        in->pyr_levels < 1 || in->pyr_levels > RSM_MAX_LEVELS)
+        return set_err(c, RSM_E_INVALID, "rectify: sizes");
+    for (int v = 0; v < 2; v++)
+        if (!in->image[v] || !in->mask[v]) return set_err(c, RSM_E_INVALID, "read image error"); // .cpp:147-151
+    HIPCHK(c, hipSetDevice(c->device));
+    RectifyPlan plan;
+    rectify_plan(in->K[0], in->K[1], in->E[0], in->E[1], in->origin_width, in->origin_height, in->lowest_width,
+                 in->lowest_height, in->pyr_levels, &plan);
+    rsm_pair_in pin{};
+    pin.width = plan.W;
+    pin.height = plan.H;
+    pin.pyr_levels = in->pyr_levels;
+    pin.radius = radius;
+    pin.ws = ws;
+    pin.offset = offset;
+    pin.origin_width = in->origin_width;
+    pin.verbose = verbose;
+    memcpy(pin.Q, plan.Q, sizeof pin.Q);
+    memcpy(pin.R_final, plan.R_final, sizeof pin.R_final);
+    memcpy(pin.T_final, plan.T_final, sizeof pin.T_final);
+    for (int v = 0; v < 2; v++) { // only to satisfy validate(); the rectified images are produced on the device
+        pin.image[v] = in->image[v];
+        pin.mask[v] = in->mask[v];
+    }
+    int s = validate(c, &pin);
+    if (s != RSM_OK) return s;
+    s = ensure_workspace(c, &pin);
+    if (s != RSM_OK) return s;
+    hipStream_t st = c->stream;
+    const int top = c->N - 1, W = plan.W, H = plan.H;
+    const size_t opx = (size_t)in->origin_width * in->origin_height, px = (size_t)W * H;
+    Tmp t(c);
+    uint8_t *raw_img = t.alloc<uint8_t>(opx * 3), *raw_msk = t.alloc<uint8_t>(opx);
+    if (!t.ok) return set_err(c, RSM_E_NOMEM, "rectify: raw buffers");
+    std::vector<int> j1, j2;
+    if (plan.ksize > 4096) return set_err(c, RSM_E_INVALID, "erode size");
+    ellipse_spans(plan.ksize, j1, j2);
+    HIPCHK(c, hipMemcpyAsync(c->d_j1, j1.data(), sizeof(int) * plan.ksize, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_j2, j2.data(), sizeof(int) * plan.ksize, hipMemcpyHostToDevice, st));
+    int16_t *map1 = (int16_t *)c->tmp1;   // 4 B / pixel
+    uint16_t *map2 = (uint16_t *)c->tmp2; // 2 B / pixel
+    uint8_t *mtmp = (uint8_t *)c->d16a[0];
+    uint8_t *stbuf = (uint8_t *)c->f64[0][0]; // sparse-table planes: <= 8 B / pixel
+    int levels = 1;
+    while ((1 << levels) <= plan.ksize) levels++;
+    if (levels > 8) return set_err(c, RSM_E_INVALID, "erode size");
+    for (int v = 0; v < 2; v++) {
+        HIPCHK(c, hipMemcpyAsync(raw_img, in->image[v], opx * 3, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(raw_msk, in->mask[v], opx, hipMemcpyHostToDevice, st));
+        const double *K = in->K[v];
+        launch_rect_map(plan.ir[v], K[0], K[4], K[2], K[5], W, H, map1, map2, st);                 // :144
+        launch_remap(raw_img, in->origin_width, in->origin_height, 3, map1, map2, W, H, c->img[top][v], st); // :154
+        launch_remap(raw_msk, in->origin_width, in->origin_height, 1, map1, map2, W, H, mtmp, st);          // :156
+        launch_erode_gray(mtmp, W, H, plan.ksize, c->d_j1, c->d_j2, stbuf, c->msk[top][v], st);             // :157-158
+        HIPCHK(c, hipStreamSynchronize(st)); // raw buffers are reused by the next view
+    }
+    HIPCHK(c, hipGetLastError());
+    memcpy(out->Q, plan.Q, sizeof plan.Q);
+    memcpy(out->R_final, plan.R_final, sizeof plan.R_final);
+    memcpy(out->T_final, plan.T_final, sizeof plan.T_final);
+    for (int v = 0; v < 2; v++) {
+        memcpy(out->P[v], plan.Pext[v], sizeof plan.Pext[v]);
+        if (out->image[v]) HIPCHK(c, hipMemcpyAsync(out->image[v], c->img[top][v], px * 3, hipMemcpyDeviceToHost, st));
+        if (out->mask[v]) HIPCHK(c, hipMemcpyAsync(out->mask[v], c->msk[top][v], px, hipMemcpyDeviceToHost, st));
+    }
+    out->width = W;
+    out->height = H;
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->have_pair = true;
+    c->have_result = false;
+    return RSM_OK;
+}
+
+extern "C" int rsm_stage_rect_map(rsm_ctx *c, const double *A, const double *R, const double *newA, int W, int H,
+                                  int16_t *map1, uint16_t *map2) {
+    if (!stage_ok(c, W, H) || !A || !R || !newA || !map1 || !map2) return RSM_E_INVALID;
+    // (newA * R)^-1 through the same host routine the pipeline uses
+    double AR[9], ir[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) AR[3 * i + j] = newA[3 * i] * R[j] + newA[3 * i + 1] * R[3 + j] + newA[3 * i + 2] * R[6 + j];
+    rectify_inv3(AR, ir);
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    int16_t *d1 = t.alloc<int16_t>(px * 2);
+    uint16_t *d2 = t.alloc<uint16_t>(px);
+    if (!t.ok) return finish(c, t);
+    launch_rect_map(ir, A[0], A[4], A[2], A[5], W, H, d1, d2, c->stream);
+    t.down(map1, (const int16_t *)d1, px * 2);
+    t.down(map2, (const uint16_t *)d2, px);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_remap(rsm_ctx *c, const uint8_t *src, int Ws, int Hs, int ch, const int16_t *map1,
+                               const uint16_t *map2, int W, int H, uint8_t *dst) {
+    if (!stage_ok(c, W, H) || !src || !map1 || !map2 || !dst || Ws <= 0 || Hs <= 0 || (ch != 1 && ch != 3)) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    uint8_t *ds = t.up(src, (size_t)Ws * Hs * ch);
+    int16_t *d1 = t.up(map1, px * 2);
+    uint16_t *d2 = t.up(map2, px);
+    uint8_t *dd = t.alloc<uint8_t>(px * ch);
+    if (!t.ok) return finish(c, t);
+    launch_remap(ds, Ws, Hs, ch, d1, d2, W, H, dd, c->stream);
+    t.down(dst, (const uint8_t *)dd, px * ch);
+    return finish(c, t);
+}
+
+extern "C" int rsm_stage_erode_gray(rsm_ctx *c, const uint8_t *src, int W, int H, int ksize, uint8_t *dst) {
+    if (!stage_ok(c, W, H) || !src || !dst || ksize < 1 || ksize > 255) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H;
+    std::vector<int> j1, j2;
+    ellipse_spans(ksize, j1, j2);
+    uint8_t *ds = t.up(src, px);
+    int *d1 = t.up(j1.data(), (size_t)ksize), *d2 = t.up(j2.data(), (size_t)ksize);
+    uint8_t *stb = t.alloc<uint8_t>(px * 9), *dd = t.alloc<uint8_t>(px);
+    if (!t.ok) return finish(c, t);
+    launch_erode_gray(ds, W, H, ksize, d1, d2, stb, dd, c->stream);
+    t.down(dst, (const uint8_t *)dd, px);
     return finish(c, t);
 }
 

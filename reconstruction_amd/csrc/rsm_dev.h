@@ -93,3 +93,12 @@ void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *
                   const double *T, Mg own, uint8_t *flags, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints,
                   double *xyz, uint8_t *bgr, int64_t max_points, hipStream_t st);
 void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long long *d_count, hipStream_t st);
+
+// Rectify (k_rectify.hip)
+void launch_rect_map(const double *ir, double fx, double fy, double u0, double v0, int W, int H, int16_t *map1,
+                     uint16_t *map2, hipStream_t st);
+void launch_remap(const uint8_t *src, int Ws, int Hs, int C, const int16_t *map1, const uint16_t *map2, int W, int H,
+                  uint8_t *dst, hipStream_t st);
+// st: ceil(log2(ksize))+1 planes of W*H bytes of scratch
+void launch_erode_gray(const uint8_t *src, int W, int H, int ksize, const int *d_j1, const int *d_j2, uint8_t *st,
+                       uint8_t *dst, hipStream_t st_);

@@ -193,3 +193,51 @@ def config_small(width=96, height=64, levels=2, radius=2, offset=2, pair=0, mask
     """Small seeded cases for parity tests."""
     return make_pair(width, height, levels, radius=radius, offset=offset, pair=pair, mask_kind=mask_kind,
                      holes=holes, **kw)
+
+
+# --- raw (unrectified) pairs for CStereoMatching::Rectify (SURVEY 8(f1)) ---------------------------------------
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = math.cos(rx), math.sin(rx), math.cos(ry), math.sin(ry), math.cos(rz), math.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def make_raw_pair(origin=(640, 480), lowest=(80, 60), pyr_levels=3, seed=7, baseline=60.0, depth=1500.0,
+                  tilt=(0.01, -0.03, 0.008), mask_border=40):
+    """Two calibrated pinhole views of a textured fronto-parallel plane Z = depth (world = camera-0 frame up to a
+    small tilt), as raw images + masks + calibration (K 3x3, E 3x4 = [R | t], x_cam = R X + t).  After
+    Rectify the true disparity is constant: f_rect * baseline / depth * scale."""
+    ow, oh = origin
+    f = 1.1 * ow
+    K0 = np.array([[f, 0, ow / 2.0 + 3.0], [0, f * 1.01, oh / 2.0 - 2.0], [0, 0, 1.0]])
+    K1 = np.array([[f * 0.99, 0, ow / 2.0 - 4.0], [0, f * 1.0, oh / 2.0 + 1.5], [0, 0, 1.0]])
+    R0 = _rot(0.004, 0.006, -0.003)
+    R1 = _rot(*tilt)
+    C0 = np.array([0.0, 0.0, 0.0])
+    C1 = np.array([baseline, 1.5, -2.0])
+    E0 = np.hstack([R0, (-R0 @ C0)[:, None]])
+    E1 = np.hstack([R1, (-R1 @ C1)[:, None]])
+    tex = make_texture(2 * ow, 2 * oh, seed, contrast=3.0).astype(np.float64)
+    s = 2 * ow / (depth / f * ow * 1.8)      # world units -> texture pixels
+    imgs, msks = [], []
+    uu, vv = np.meshgrid(np.arange(ow, dtype=np.float64), np.arange(oh, dtype=np.float64))
+    for K, R, Cc in ((K0, R0, C0), (K1, R1, C1)):
+        rays = np.stack([(uu - K[0, 2]) / K[0, 0], (vv - K[1, 2]) / K[1, 1], np.ones_like(uu)], -1) @ R  # R^T applied
+        lam = (depth - Cc[2]) / rays[..., 2]
+        X = Cc[0] + lam * rays[..., 0]
+        Y = Cc[1] + lam * rays[..., 1]
+        tx = np.clip(X * s + ow, 0, 2 * ow - 1.001)
+        ty = np.clip(Y * s + oh, 0, 2 * oh - 1.001)
+        x0 = np.floor(tx).astype(np.int64); y0 = np.floor(ty).astype(np.int64)
+        fx = (tx - x0)[..., None]; fy = (ty - y0)[..., None]
+        v = (tex[y0, x0] * (1 - fx) * (1 - fy) + tex[y0, x0 + 1] * fx * (1 - fy) +
+             tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy)
+        imgs.append(np.clip(np.rint(v), 0, 255).astype(np.uint8))
+        m = np.zeros((oh, ow), np.uint8)
+        m[mask_border:oh - mask_border, mask_border:ow - mask_border] = 255
+        msks.append(m)
+    return dict(K=[K0, K1], E=[E0, E1], origin=origin, lowest=lowest, pyr_levels=pyr_levels, image=imgs, mask=msks,
+                baseline=baseline, depth=depth)

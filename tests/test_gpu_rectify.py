@@ -1,0 +1,104 @@
+"""Rectify on the GPU against the CPU oracle: fixed-point maps, bilinear remap and grey erosion are
+integer arithmetic -> bit-exact; the fp64 plan (stereoRectify etc.) is host code on both sides -> identical."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from reconstruction_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def raw():
+    return synth.make_raw_pair()
+
+
+def test_rect_maps_bit_exact(ctx, raw):
+    K, E = raw["K"], raw["E"]
+    R = E[1][:, :3] @ E[0][:, :3].T
+    T = -R @ E[0][:, 3] + E[1][:, 3]
+    R1, R2, P1, P2, Q = orc.stereo_rectify(K[0], K[1], raw["origin"], R, T)
+    for Kv, Rv, Pv in ((K[0], R1, P1), (K[1], R2, P2)):
+        newA = Pv[:, :3].copy()
+        newA[:2] *= 0.5
+        for (W, H) in ((320, 240), (333, 201)):
+            g1, g2 = ctx.rect_map(Kv, Rv, newA, W, H)
+            o1, o2 = orc.init_rectify_map(Kv, Rv, newA, W, H)
+            assert np.array_equal(g1, o1) and np.array_equal(g2, o2)
+
+
+def test_remap_bit_exact(ctx, raw):
+    rng = np.random.default_rng(3)
+    H, W = 150, 210
+    m1 = np.zeros((H, W, 2), np.int16)
+    m1[..., 0] = rng.integers(-5, raw["origin"][0] + 5, (H, W))
+    m1[..., 1] = rng.integers(-5, raw["origin"][1] + 5, (H, W))
+    m2 = rng.integers(0, 1024, (H, W)).astype(np.uint16)
+    for src in (raw["image"][0], raw["mask"][1], rng.integers(0, 256, raw["mask"][0].shape).astype(np.uint8)):
+        assert np.array_equal(ctx.remap_linear(src, m1, m2), orc.remap_linear(src, m1, m2))
+
+
+@pytest.mark.parametrize("ksize", [1, 2, 3, 6, 12, 24, 48, 61])
+def test_grey_erosion_bit_exact(ctx, ksize):
+    rng = np.random.default_rng(ksize)
+    m = rng.integers(0, 256, (97, 131)).astype(np.uint8)
+    m[20:70, 30:110] = 255
+    m[40:44, 60:66] = rng.integers(0, 255, (4, 6))
+    assert np.array_equal(ctx.erode_ellipse_gray(m, ksize), orc.erode_ellipse(m, ksize))
+
+
+def test_rectify_pair_matches_oracle(ctx, raw):
+    g = ctx.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"])
+    o = orc.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"])
+    for v in range(2):
+        assert np.array_equal(g["image"][v], o["image"][v])
+        assert np.array_equal(g["mask"][v], o["mask"][v])
+        assert np.array_equal(g["P"][v], o["P"][v])
+    for k in ("Q", "R_final", "T_final"):
+        assert np.array_equal(g[k], o[k]), k
+
+
+def test_rectify_then_match_end_to_end(ctx):
+    """raw images + calibration -> Rectify -> MatchAllLayer body, all on the GPU, against the oracle chain.
+    The second camera sits at -X so that view-0 disparities are positive: DisparityRefine's int(d-1.5)
+    truncates toward zero (CStereoMatching.cpp:625), which biases NEGATIVE disparities by about -1 px in the
+    reference itself (measured with the oracle: Z = 1412 instead of 1500 for baseline +60)."""
+    raw = synth.make_raw_pair(baseline=-150.0)
+    g = ctx.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"],
+                         radius=2, ws=0.03, offset=2)
+    ctx.run_pair()
+    res = ctx.download_pair()
+    o = orc.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"])
+    W, H = g["size"]
+    cfg = synth.PairConfig(width=W, height=H, pyr_levels=raw["pyr_levels"], radius=2, ws=0.03, offset=2,
+                           origin_width=raw["origin"][0], image=o["image"], mask=o["mask"], Q=o["Q"],
+                           R_final=o["R_final"], T_final=o["T_final"])
+    ref = orc.match_pair(cfg)
+    assert res.margin == ref["margin"] and res.n_points == ref["n_points"] and res.n_points > 1000
+    for v in range(2):
+        a, b = res.disparity[v], ref["disparity"][v]
+        assert np.array_equal(a == -10000, b == -10000)
+        ok = b != -10000
+        assert (np.abs(a[ok] - b[ok]) / np.maximum(1, np.abs(b[ok]))).max() < 1e-5
+    fin = np.isfinite(ref["xyz"])
+    assert np.allclose(res.xyz[fin], ref["xyz"][fin], rtol=1e-4, atol=1e-6)
+    # the scene is a plane at Z = depth in the camera-0 frame up to its small tilt: the cloud must be flat
+    z = res.xyz[:, 2]
+    assert abs(np.median(z) - raw["depth"]) < 0.02 * raw["depth"]
+
+
+def test_mirror_rectifies_from_raw_inputs(ctx, raw):
+    from reconstruction_amd import Camera, ManageData, StereoMatching
+    cams = [Camera(camID=v, MatIntrinsics=raw["K"][v], MatExtrinsics=raw["E"][v]) for v in range(2)]
+    for v in range(2):
+        cams[v].raw_image, cams[v].raw_mask = raw["image"][v], raw["mask"][v]
+    data = ManageData(cam=[cams], m_PyrmNum=raw["pyr_levels"], m_LowestLevelSize=raw["lowest"], m_OriginSize=raw["origin"])
+    sm = StereoMatching(0)
+    sm.Init(data, None, 2, 0.03)
+    sm.Verbose = 0
+    sm.MatchAllLayer()
+    o = orc.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"])
+    assert np.array_equal(sm.Q, o["Q"]) and np.array_equal(data.cam[0][1].P, o["P"][1])
+    assert np.array_equal(data.cam[0][0].mask, o["mask"][0]) and data.cam[0][0].bound is not None
+    assert sm.last_result.n_points > 1000

@@ -1,0 +1,86 @@
+"""Rectify on the CPU: the oracle's restatement of cv::stereoRectify / initUndistortRectifyMap /
+remap against properties that follow from the geometry, and the product's host fp64 routine against the oracle."""
+import numpy as np
+
+from oracle import oracle as orc
+from reconstruction_amd import stereo_rectify, synth
+
+
+def test_identity_rotation_pure_baseline():
+    K = np.array([[1000.0, 0, 320], [0, 1000.0, 240], [0, 0, 1]])
+    R1, R2, P1, P2, Q = orc.stereo_rectify(K, K, (640, 480), np.eye(3), np.array([-100.0, 0, 0]))
+    assert np.allclose(R1, np.eye(3)) and np.allclose(R2, np.eye(3))
+    assert np.allclose(P1[:, :3], K) and np.allclose(P2[:, :3], K)
+    assert np.isclose(P2[0, 3], -100.0 * 1000.0) and P2[1, 3] == 0
+    assert np.isclose(Q[3, 2], 0.01) and np.isclose(Q[2, 3], 1000.0) and np.isclose(Q[0, 3], -320) and Q[3, 3] == 0
+
+
+def test_rodrigues_round_trip_and_orthonormality():
+    for r in ([0.02, -0.05, 0.01], [1.2, 0.3, -0.7], [0, 0, 0]):
+        R = orc.rodrigues(np.array(r, np.float64))
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-14) and np.isclose(np.linalg.det(R), 1)
+        assert np.allclose(orc.rodrigues(R), r, atol=1e-12)
+
+
+def test_rectified_views_are_row_aligned():
+    """Any 3-D point projects to the same row in both rectified cameras, and the x difference is f*B/Z."""
+    raw = synth.make_raw_pair()
+    K, E = raw["K"], raw["E"]
+    R = E[1][:, :3] @ E[0][:, :3].T
+    T = -R @ E[0][:, 3] + E[1][:, 3]
+    R1, R2, P1, P2, Q = orc.stereo_rectify(K[0], K[1], raw["origin"], R, T)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        Xw = np.array([rng.uniform(-300, 300), rng.uniform(-200, 200), rng.uniform(900, 2500)])
+        Xc0 = E[0][:, :3] @ Xw + E[0][:, 3]
+        Xc1 = E[1][:, :3] @ Xw + E[1][:, 3]
+        p0 = P1 @ np.append(R1 @ Xc0, 1.0)
+        p1 = P2[:, :3] @ (R2 @ Xc1)                       # camera-2 frame: the baseline column of P2 is for camera-1 coordinates
+        p1b = P2 @ np.append(R1 @ Xc0, 1.0)               # same pixel from rectified camera-1 coordinates
+        assert np.allclose(p1 / p1[2], p1b / p1b[2], atol=1e-6)
+        u0, v0, u1, v1 = p0[0] / p0[2], p0[1] / p0[2], p1[0] / p1[2], p1[1] / p1[2]
+        assert abs(v0 - v1) < 1e-6
+        Z = (R1 @ Xc0)[2]
+        # Q maps (u0, v0, disparity) back to the rectified camera-0 frame (before the reference flips Q(3,2))
+        d = u0 - u1
+        Wq = Q[3, 2] * d + Q[3, 3]
+        assert abs(Q[2, 3] / Wq - Z) < 1e-6 * Z
+
+
+def test_product_host_routine_equals_the_oracle_bit_for_bit():
+    raw = synth.make_raw_pair()
+    K, E = raw["K"], raw["E"]
+    R = E[1][:, :3] @ E[0][:, :3].T
+    T = -R @ E[0][:, 3] + E[1][:, 3]
+    a = stereo_rectify(K[0], K[1], raw["origin"], R, T)       # reconstruction_amd (C ABI, host)
+    b = orc.stereo_rectify(K[0], K[1], raw["origin"], R, T)   # oracle
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_identity_map_remap_is_a_copy_and_border_is_zero():
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, (20, 30, 3)).astype(np.uint8)
+    H, W = 20, 30
+    m1 = np.zeros((H, W, 2), np.int16)
+    m1[..., 0], m1[..., 1] = np.meshgrid(np.arange(W), np.arange(H))
+    m2 = np.zeros((H, W), np.uint16)
+    assert np.array_equal(orc.remap_linear(src, m1, m2), src)
+    m1[..., 0] += 28                                    # mostly outside: BORDER_CONSTANT 0
+    out = orc.remap_linear(src, m1, m2)
+    assert (out[:, 2:] == 0).all() and np.array_equal(out[:, :2], src[:, 28:30])
+    m2[:] = 16                                          # fx = 16/32: average of two horizontal neighbours
+    m1[..., 0] -= 28
+    out = orc.remap_linear(src[..., 0].copy(), m1, m2)
+    exp = (src[:, :-1, 0].astype(int) * 16384 + src[:, 1:, 0].astype(int) * 16384 + 16384) >> 15
+    assert np.array_equal(out[:, :-1], exp.astype(np.uint8))
+
+
+def test_rectify_pair_of_a_plane_gives_constant_disparity_geometry():
+    raw = synth.make_raw_pair()
+    r = orc.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"])
+    W, H = raw["lowest"][0] << (raw["pyr_levels"] - 1), raw["lowest"][1] << (raw["pyr_levels"] - 1)
+    assert r["image"][0].shape == (H, W, 3) and r["mask"][1].shape == (H, W)
+    assert r["Q"][3, 2] < 0                               # sign flipped at .cpp:138
+    assert (r["mask"][0] == 255).sum() > 0.3 * W * H and (r["mask"][0] == 255).sum() < 0.9 * W * H
+    assert np.allclose(r["R_final"] @ r["R_final"].T, np.eye(3), atol=1e-12)
