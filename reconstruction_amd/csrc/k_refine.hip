@@ -65,77 +65,162 @@ __device__ __forceinline__ double refine_update(int mode, double dC, double dE, 
     return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
 }
 
+__device__ __forceinline__ double byte_f64(uint32_t v, int b) { return (double)(float)((v >> (8 * b)) & 0xffu); }
+__device__ __forceinline__ int sum4(uint32_t v, int acc) { return (int)__builtin_amdgcn_sad_u8(v, 0u, (uint32_t)acc); }
+
 // Data term (pwp, delta = pdp - dCenter) of pixel (x, y) for iMatch = key: .cpp:624-650.
-__device__ __forceinline__ void refine_data_term(const DirArgs &d, int W, int H, int x, int y, int key, double &pwp,
-                                                 double &delta) {
-    // Bit-faithful fp64 restatement of CManageData::WindowToVec (CManageData.cpp:81-90) + arma::dot on
-    // the 27-element windows, same gather order (byte column outer, row inner) and the same
-    // two-accumulator sums as Armadillo (op_dot_meat.hpp:20-55, fn_norm.hpp:99-130): the sweep is
-    // ill-conditioned at int(d - 1.5) boundaries, so xi must match the reference to the last bit.
-    const uint8_t *A = d.img_own, *B = d.img_oth;
-    const long long total = (long long)W * H * 3;
-    const int rowB = W * 3;
-    int aw[27], bw[3][15];
+// Bit-faithful fp64 restatement of CManageData::WindowToVec (CManageData.cpp:81-90) + arma::dot on the
+// 27-element windows, same gather order (byte column outer, row inner) and the same two-accumulator sums as
+// Armadillo (op_dot_meat.hpp:20-55, fn_norm.hpp:99-130): the sweep is ill-conditioned at int(d - 1.5)
+// boundaries, so xi must match the reference to the last bit.
+// Reads the BGRX copies (one aligned dword per pixel, X = 0): 24 loads, the window bytes stay packed in
+// registers.  The reference's unchecked right-window reads (.cpp:628) are emulated on the flat buffer: the flat
+// byte index test fi in [0, 3WH) of the BGR image is the flat pixel index test in [0, WH) here.
+__device__ __forceinline__ void refine_data_term_packed(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
+                                                        int W, int H, int x, int y, int key, double &pwp, double &delta) {
+    const long long npx = (long long)W * H;
+    uint32_t aP[3][3], bP[3][5];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        const uint8_t *pa = A + (size_t)(y - 1 + j) * rowB + (size_t)(x - 1) * 3;
-        const long long bbase = (long long)(y - 1 + j) * rowB + (long long)key * 3;
+        const uint32_t *pa = A + (size_t)(y - 1 + j) * W + (x - 1);
+        const long long fb = (long long)(y - 1 + j) * W + key;
 #pragma unroll
-        for (int i = 0; i < 9; i++) aw[i * 3 + j] = pa[i];
+        for (int p = 0; p < 3; p++) aP[j][p] = pa[p];
 #pragma unroll
-        for (int i = 0; i < 15; i++) {
-            const long long fi = bbase + i;
-            bw[j][i] = (fi >= 0 && fi < total) ? (int)B[fi] : 0;
+        for (int q = 0; q < 5; q++) {
+            const long long fi = fb + q;
+            bP[j][q] = (fi >= 0 && fi < npx) ? B[fi] : 0u;
         }
     }
     int SL = 0;
 #pragma unroll
-    for (int k = 0; k < 27; k++) SL += aw[k];
-    const double meanL = (double)SL / 27.0; // accumulate() of integers is exact; one rounding in the divide
-    double uL[27];
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) SL = sum4(aP[j][p], SL);
+    const double meanL = (double)SL / 27.0;
     double n1 = 0.0, n2 = 0.0;
 #pragma unroll
     for (int k = 0; k < 27; k++) {
-        uL[k] = (double)aw[k] - meanL;
-        if (k & 1) n2 += uL[k] * uL[k];
-        else n1 += uL[k] * uL[k];
+        const double u = byte_f64(aP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanL;
+        if (k & 1) n2 += u * u;
+        else n1 += u * u;
     }
     double normL = sqrt(n1 + n2);
-    if (normL == 0) normL = 1; // CManageData.cpp:89
-    double xi[3];
-#pragma unroll
+    if (normL == 0) normL = 1;
+    // the three shifts c = 0, 1, 2 as a rolled loop over a sliding register window (the body reads bP[.][0..2],
+    // then the window moves one pixel): keeps the routine at ~50 registers.  The empty asm stops the compiler
+    // from hoisting the 27 left-window differences (54 registers) out of the loop; they are recomputed instead.
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+#pragma unroll 1
     for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) asm volatile("" : "+v"(aP[j][p]));
         int SR = 0;
 #pragma unroll
-        for (int k = 0; k < 27; k++) SR += bw[k % 3][k / 3 + 3 * c];
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) SR = sum4(bP[j][p], SR);
         const double meanR = (double)SR / 27.0;
         double m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 27; k++) {
-            const double ur = (double)bw[k % 3][k / 3 + 3 * c] - meanR;
+            const double ur = byte_f64(bP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanR;
+            const double ul = byte_f64(aP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanL;
             if (k & 1) {
                 m2 += ur * ur;
-                d2 += uL[k] * ur;
+                d2 += ul * ur;
             } else {
                 m1 += ur * ur;
-                d1 += uL[k] * ur;
+                d1 += ul * ur;
             }
         }
         double normR = sqrt(m1 + m2);
         if (normR == 0) normR = 1;
-        xi[c] = (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
+        x0 = x1;
+        x1 = x2;
+        x2 = (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) bP[j][q] = bP[j][q + 1];
     }
-    int index = xi[0] >= xi[1]; // .cpp:631-632
-    if (xi[index] > xi[2]) index = 2;
+    int index = x0 >= x1; // .cpp:631-632
+    if ((index ? x1 : x0) > x2) index = 2;
     if (index == 0) {
-        pwp = xi[1] - xi[0];
+        pwp = x1 - x0;
         delta = -0.5;
     } else if (index == 2) {
-        pwp = xi[1] - xi[2];
+        pwp = x1 - x2;
         delta = 0.5;
     } else {
-        pwp = 0.5 * (xi[0] + xi[2]) - xi[1];
-        delta = (pwp == 0) ? 0.0 : 0.5 * (xi[0] - xi[2]) / (xi[0] + xi[2] - 2 * xi[1]);
+        pwp = 0.5 * (x0 + x2) - x1;
+        delta = (pwp == 0) ? 0.0 : 0.5 * (x0 - x2) / (x0 + x2 - 2 * x1);
+    }
+}
+
+// One quad (4 adjacent lanes) computes refine_data_term_packed for one (x, y, key): every lane restates the left
+// window's mean and norm, lane q >= 1 the right window of shift c = q - 1 (lane 0 shadows c = 0), lane 0
+// combines.  Each value is produced by the same operation sequence as in refine_data_term_packed.
+__device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
+                                                      int W, int H, int x, int y, int key, int q, double &pwp,
+                                                      double &delta) {
+    const long long npx = (long long)W * H;
+    const int c = q > 0 ? q - 1 : 0;
+    uint32_t aP[3][3], bP[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t *pa = A + (size_t)(y - 1 + j) * W + (x - 1);
+        const long long fb = (long long)(y - 1 + j) * W + key + c;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            aP[j][p] = pa[p];
+            const long long fi = fb + p;
+            bP[j][p] = (fi >= 0 && fi < npx) ? B[fi] : 0u;
+        }
+    }
+    int SL = 0, SR = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            SL = sum4(aP[j][p], SL);
+            SR = sum4(bP[j][p], SR);
+        }
+    const double meanL = (double)SL / 27.0, meanR = (double)SR / 27.0;
+    double n1 = 0.0, n2 = 0.0, m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        const double ul = byte_f64(aP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanL;
+        const double ur = byte_f64(bP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanR;
+        if (k & 1) {
+            n2 += ul * ul;
+            m2 += ur * ur;
+            d2 += ul * ur;
+        } else {
+            n1 += ul * ul;
+            m1 += ur * ur;
+            d1 += ul * ur;
+        }
+    }
+    double normL = sqrt(n1 + n2), normR = sqrt(m1 + m2);
+    if (normL == 0) normL = 1;
+    if (normR == 0) normR = 1;
+    const double xi = (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
+    const int qb = (int)(threadIdx.x & 63) & ~3; // the quad's first lane
+    const double x0 = __shfl(xi, qb + 1), x1 = __shfl(xi, qb + 2), x2 = __shfl(xi, qb + 3);
+    int index = x0 >= x1; // .cpp:631-632
+    if ((index ? x1 : x0) > x2) index = 2;
+    if (index == 0) {
+        pwp = x1 - x0;
+        delta = -0.5;
+    } else if (index == 2) {
+        pwp = x1 - x2;
+        delta = 0.5;
+    } else {
+        pwp = 0.5 * (x0 + x2) - x1;
+        delta = (pwp == 0) ? 0.0 : 0.5 * (x0 - x2) / (x0 + x2 - 2 * x1);
     }
 }
 
@@ -168,8 +253,12 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         dE[i] = in[(size_t)yy * W + xs + 1];
         dW[i] = in[(size_t)yy * W + xs - 1];
     }
-    // phase 2: the cache way each pixel needs (2-way cache indexed by the parity of int(d - 1.5) (so neighbouring pixels share cache lines): the iteration settles
-    // into flipping between two ADJACENT iMatch values, so both data terms stay resident)
+    // phase 2: the cached data term.  Two entries per pixel.  The iteration settles into flipping between two
+    // ADJACENT iMatch values, so indexing the entries by the parity of iMatch keeps both resident -- but then
+    // neighbouring pixels sit in different arrays at random and every sweep touches the lines of BOTH (52 B per
+    // pixel measured).  opt_refine_ways = 1 indexes by the parity of the SWEEP instead: every pixel reads array
+    // s & 1 (34 B per pixel), a steady flipper still hits (iMatch(s) == iMatch(s - 2)), and a pixel whose phase
+    // slipped finds its entry in the other array, which the worklist kernel checks before recomputing.
     int key[RF_PPT], ckey[RF_PPT];
     double pwp[RF_PPT], delta[RF_PPT];
     size_t pix[RF_PPT];
@@ -178,7 +267,7 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         const int yy = min(y0 + i, ylast);
         pix[i] = (size_t)yy * W + xs;
         key[i] = (int)(col[i + 1] - 1.5) + xs; // .cpp:625
-        const size_t cpix = pix[i] + (size_t)((key[i] - xs) & 1) * a.rf_stride;
+        const size_t cpix = pix[i] + (size_t)(a.opt_refine_ways ? (a.flag2 & 1) : ((key[i] - xs) & 1)) * a.rf_stride;
         ckey[i] = (int)d.rf_key[cpix] + xs; // stored relative to the column (int16)
         pwp[i] = d.rf_pwp[cpix];
         delta[i] = d.rf_delta[cpix];
@@ -213,46 +302,126 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
 template <int FULL>
 __global__ __launch_bounds__(256) void k_refine_miss(StageArgs a) {
     const int W = a.W, H = a.H;
-    // worklist mode: block b serves shard b % RF_NSHARD, RF_SUB blocks per shard
-    const int shard = blockIdx.x & (RF_NSHARD - 1);
-    const int count = FULL ? 0 : a.rf_cnt[(a.flag2 & 1) * RF_NSHARD + shard];
-    if (!FULL && blockIdx.x < RF_NSHARD && threadIdx.x == 0)
-        a.rf_cnt[((a.flag2 + 1) & 1) * RF_NSHARD + shard] = 0; // the next sweep's counter set (idle now)
-    for (int e = (blockIdx.x / RF_NSHARD) * blockDim.x + threadIdx.x; FULL || e < count; e += RF_SUB * blockDim.x) {
-        int x, y, v;
-        if (FULL) {
-            v = blockIdx.z;
-            x = a.d[v].own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
-            y = a.d[v].own.YL + 1 + blockIdx.y;
-            if (x > a.d[v].own.XR - 1 || y > a.d[v].own.YR - 1) return;
-        } else {
-            const uint32_t ent = a.rf_list[(size_t)shard * a.rf_cap + e];
-            v = ent >> 31;
-            const uint32_t p = ent & 0x7fffffffu;
-            y = (int)(p / W);
-            x = (int)(p % W);
-        }
-        const DirArgs &d = a.d[v];
+    if (FULL) {
+        const DirArgs &d = a.d[blockIdx.z];
+        const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+        const int y = d.own.YL + 1 + blockIdx.y;
+        if (x > d.own.XR - 1 || y > d.own.YR - 1) return;
         const size_t pix = (size_t)y * W + x;
         const double *in = d.f64_a;
         const double dC = in[pix];
-        if (FULL && dC == (double)NOMATCH) return;
+        if (dC == (double)NOMATCH) return;
         const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
         const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
                          (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
-        if (FULL && mode == 0) {
+        if (mode == 0) {
             d.f64_b[pix] = dC;
             return;
         }
         const int key = (int)(dC - 1.5) + x;
         double pwp, delta;
-        refine_data_term(d, W, H, x, y, key, pwp, delta);
-        const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
+        refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, key, pwp, delta);
+        const size_t cpix = pix + (size_t)(a.opt_refine_ways ? (a.flag2 & 1) : ((key - x) & 1)) * a.rf_stride;
         d.rf_key[cpix] = (int16_t)(key - x);
         d.rf_pwp[cpix] = pwp;
         d.rf_delta[cpix] = delta;
         d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
-        if (FULL) return;
+        return;
+    }
+    // worklist mode: one workgroup per shard.  Pass 1 serves the entries whose data term sits in the other array
+    // (phase slips: copy it over) and compacts the rest in place; pass 2 recomputes those with every lane busy.
+    __shared__ int sN;
+    const int shard = blockIdx.x & (RF_NSHARD - 1);
+    const int count = a.rf_cnt[(a.flag2 & 1) * RF_NSHARD + shard];
+    if (threadIdx.x == 0) {
+        a.rf_cnt[((a.flag2 + 1) & 1) * RF_NSHARD + shard] = 0; // the next sweep's counter set (idle now)
+        sN = 0;
+    }
+    uint32_t *list = a.rf_list + (size_t)shard * a.rf_cap;
+    const int lane = threadIdx.x & 63;
+    const int byS = a.opt_refine_ways;
+    const size_t wayS = (size_t)(a.flag2 & 1) * a.rf_stride, wayO = (size_t)((a.flag2 + 1) & 1) * a.rf_stride;
+    __syncthreads();
+    int n2 = count;
+    if (byS) {
+        for (int base = 0; base < count; base += 256 * RF_EPT) {
+            uint32_t ent[RF_EPT];
+#pragma unroll
+            for (int u = 0; u < RF_EPT; u++) {
+                const int e = base + u * 256 + (int)threadIdx.x;
+                ent[u] = (e < count) ? list[e] : 0xffffffffu;
+            }
+            __syncthreads(); // the chunk is in registers: its slots may now receive compacted entries
+            // every load of the chunk up front (the pass is latency-bound)
+            double dC[RF_EPT];
+            int okey[RF_EPT];
+#pragma unroll
+            for (int u = 0; u < RF_EPT; u++) {
+                const bool ok = ent[u] != 0xffffffffu;
+                const DirArgs &d = a.d[ok ? ent[u] >> 31 : 0];
+                const size_t pix = ok ? (ent[u] & 0x7fffffffu) : 0;
+                dC[u] = d.f64_a[pix];
+                okey[u] = (int)d.rf_key[pix + wayO];
+            }
+#pragma unroll
+            for (int u = 0; u < RF_EPT; u++) {
+                const bool ok = ent[u] != 0xffffffffu;
+                bool need = false;
+                if (ok) {
+                    const DirArgs &d = a.d[ent[u] >> 31];
+                    const size_t pix = ent[u] & 0x7fffffffu;
+                    const int rel = (int)(dC[u] - 1.5);
+                    if (okey[u] == rel) {
+                        const double pwp = d.rf_pwp[pix + wayO], delta = d.rf_delta[pix + wayO];
+                        const double *in = d.f64_a;
+                        const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
+                        const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                                         (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
+                        d.rf_key[pix + wayS] = (int16_t)rel;
+                        d.rf_pwp[pix + wayS] = pwp;
+                        d.rf_delta[pix + wayS] = delta;
+                        d.f64_b[pix] = refine_update(mode, dC[u], dE, dW, dN, dS, pwp, delta, a.ws);
+                    } else {
+                        need = true;
+                    }
+                }
+                const unsigned long long mm = __ballot(need);
+                if (mm) {
+                    const int leader = __builtin_ctzll(mm);
+                    int b0 = 0;
+                    if (lane == leader) b0 = atomicAdd(&sN, __popcll(mm));
+                    b0 = __shfl(b0, leader);
+                    if (need) list[b0 + __popcll(mm & ((1ull << lane) - 1ull))] = ent[u];
+                }
+            }
+        }
+        __syncthreads();
+        n2 = sN;
+    }
+    // four lanes per entry (refine_data_term_quad): the pass is one dependent chain per entry, so a shorter chain
+    // matters more than lane utilisation
+    for (int e0 = 0; e0 < n2; e0 += 64) { // uniform
+        const int e = e0 + ((int)threadIdx.x >> 2), q = threadIdx.x & 3;
+        const bool live = e < n2;
+        const uint32_t ent = list[live ? e : e0];
+        const DirArgs &d = a.d[ent >> 31];
+        const size_t pix = ent & 0x7fffffffu;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        const double *in = d.f64_a;
+        const double dC = in[pix];
+        const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
+        const int key = (int)(dC - 1.5) + x;
+        double pwp, delta;
+        refine_data_term_quad(d.img4_own, d.img4_oth, W, H, x, y, key, q, pwp, delta);
+        if (live && q == 0) {
+            const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                             (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
+            const size_t cpix = pix + (byS ? wayS : (size_t)((key - x) & 1) * a.rf_stride);
+            d.rf_key[cpix] = (int16_t)(key - x);
+            d.rf_pwp[cpix] = pwp;
+            d.rf_delta[cpix] = delta;
+            d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+        }
     }
 }
 
@@ -281,7 +450,7 @@ __global__ __launch_bounds__(256) void k_refine_fused(StageArgs a) {
         pwp = d.rf_pwp[cpix];
         delta = d.rf_delta[cpix];
     } else {
-        refine_data_term(d, W, H, x, y, key, pwp, delta);
+        refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, key, pwp, delta);
         d.rf_key[cpix] = (int16_t)(key - x);
         d.rf_pwp[cpix] = pwp;
         d.rf_delta[cpix] = delta;

@@ -89,6 +89,7 @@ struct rsm_ctx {
     // options (rsm_set_option)
     long long opt_refine_fused_max = 1ll << 20;
     int opt_ncc_bytes = 0;
+    int opt_refine_ways = 0;
 
     // profiling
     bool profile = false;
@@ -314,6 +315,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "refine_fused_max")) c->opt_refine_fused_max = value;
     else if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
+    else if (!strcmp(name, "refine_ways")) c->opt_refine_ways = value != 0;
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
     return RSM_OK;
 }
@@ -352,6 +354,7 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.rf_stride = c->cap_px;
     a.opt_refine_fused_max = c->opt_refine_fused_max;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
+    a.opt_refine_ways = c->opt_refine_ways;
     for (int v = 0; v < 2; v++) {
         DirArgs &d = a.d[v];
         const int o = 1 - v;
@@ -771,6 +774,7 @@ StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, cons
     StageArgs a{};
     a.opt_refine_fused_max = c->opt_refine_fused_max;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
+    a.opt_refine_ways = c->opt_refine_ways;
     a.ndir = 1;
     a.W = W;
     a.H = H;
@@ -951,6 +955,7 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.d16_in = t.up(disp_in, px);
     d.img_own = t.up(img_own, px * 3);
     d.img_oth = t.up(img_oth, px * 3);
+    uint32_t *i4o = t.alloc<uint32_t>(px), *i4t = t.alloc<uint32_t>(px);
     double *A = t.alloc<double>(px), *B = t.alloc<double>(px);
     d.rf_key = t.alloc<int16_t>(2 * px);
     d.rf_pwp = t.alloc<double>(2 * px);
@@ -962,6 +967,10 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     if (iterations > RF_MAX_SWEEPS) return set_err(c, RSM_E_INVALID, "iterations");
     d.f64_a = A;
     d.f64_b = B;
+    launch_bgr_to_bgrx(d.img_own, W, H, i4o, c->stream);
+    launch_bgr_to_bgrx(d.img_oth, W, H, i4t, c->stream);
+    d.img4_own = i4o;
+    d.img4_oth = i4t;
     launch_refine_init(a, c->stream);
     for (int it = 0; it < iterations; it++) {
         a.flag2 = it;

@@ -9,7 +9,8 @@
 #define WAVE 64
 #define RF_MAX_SWEEPS 1024
 #define RF_NOKEY ((int16_t)-32768)
-#define RF_NSHARD 256 // refine worklist shards (power of 2)
+#define RF_NSHARD 1024 // refine worklist shards (power of 2) = workgroups of the worklist kernel
+#define RF_EPT 2       // worklist entries per thread and round of the copy pass
 #define RF_SUB 1      // worklist blocks per shard
 #define RF_PPT 4      // pixels per thread of the light sweep kernel
 // worklist capacity (entries) for ndir directions of a WxH level
@@ -52,6 +53,7 @@ struct StageArgs {
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
     long long opt_refine_fused_max; // refine: levels with fewer pixel-threads use the fused kernel
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
+    int opt_refine_ways;            // refine cache indexing: 0 = by parity of iMatch, 1 = by parity of the sweep (default)
     int32_t *rf_cnt;   // refine: worklist counters [2 sets][RF_NSHARD]
     uint32_t *rf_list; // refine / NCC: worklist of (dir << 31 | pixel index)
     int32_t *ncc_cnt;  // NCC: number of wide pixels in rf_list
