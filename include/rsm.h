@@ -106,9 +106,7 @@ int rsm_export_cloud_device(rsm_ctx *ctx, double *d_xyz, uint8_t *d_bgr, int64_t
 
 /* Tuning / validation knobs (results never change): "refine_fused_max" = pixel-thread count below which a
  * level's refine sweeps use the single fused kernel (default 1<<20; 0 forces the split light+worklist
- * kernels), "ncc_bytes" = 1 forces the generic byte-wise NCC kernel instead of the dot4 one, "refine_ways" =
- * 1 indexes the two refine cache entries of a pixel by the parity of the sweep instead of iMatch's (default 0;
- * measured slower: a fifth of the pixels then misses per sweep). */
+ * kernels), "ncc_bytes" = 1 forces the generic byte-wise NCC kernel instead of the dot4 one. */
 int rsm_set_option(rsm_ctx *ctx, const char *name, long long value);
 
 /* ---- measurement ------------------------------------------------------------------------- */

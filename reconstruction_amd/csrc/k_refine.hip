@@ -30,7 +30,7 @@ __global__ void k_refine_init(StageArgs a) {
     const size_t n = (size_t)a.W * a.H;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    if (blockIdx.z == 0 && i < 2 * RF_NSHARD) a.rf_cnt[i] = 0;
+    if (blockIdx.z == 0 && i < RF_COUNTERS) a.rf_cnt[i] = 0;
     for (; i < n; i += stride) {
         const double v = (double)d.d16_in[i]; // convertTo CV_64F, .cpp:585
         d.f64_a[i] = v;
@@ -44,7 +44,7 @@ void launch_refine_init(const StageArgs &a, hipStream_t st) {
     const size_t n = (size_t)a.W * a.H;
     size_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (blocks < (2 * RF_NSHARD + 255) / 256) blocks = (2 * RF_NSHARD + 255) / 256;
+    if (blocks < (RF_COUNTERS + 255) / 256) blocks = (RF_COUNTERS + 255) / 256;
     hipLaunchKernelGGL(k_refine_init, dim3((unsigned)blocks, 1, a.ndir), dim3(256), 0, st, a);
 }
 
@@ -224,22 +224,31 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
     }
 }
 
-// Light sweep kernel: one pixel per thread, every load issued up front. A pixel whose cached data term
-// belongs to another iMatch (cache miss) is appended to the sweep's worklist instead of being updated
-// here; k_refine_miss handles it before the next sweep starts (stream order).
-// TOP only gives the top level's launches (the dominant kernel) their own name in rocprof traces.
-// RF_PPT vertically adjacent pixels per thread: more loads in flight per wave (the kernel is latency-bound)
-template <int TOP>
-__global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
-    const DirArgs &d = a.d[blockIdx.z];
-    const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int y0 = d.own.YL + 1 + blockIdx.y * RF_PPT;
+// Worklist bookkeeping: every direction has RF_NSHARD shards (a counter + a list region each; a single counter
+// serialises at ~88 appends/us) and two counter sets, used by alternate sweeps.
+__device__ __forceinline__ int32_t *rf_counter(const StageArgs &a, int dir, int sweep, int shard) {
+    return a.rf_cnt + ((dir * 2 + (sweep & 1)) * RF_NSHARD + shard);
+}
+__device__ __forceinline__ uint32_t *rf_shard_list(const StageArgs &a, int dir, int shard) {
+    return a.rf_list + ((size_t)dir * RF_NSHARD + shard) * a.rf_cap;
+}
+
+// Light sweep: RF_PPT vertically adjacent pixels per thread, every load issued up front.  A pixel whose cached
+// data term belongs to another iMatch (cache miss) is appended to the sweep's worklist instead of being updated
+// here; refine_miss_body serves it before the direction's next sweep starts.
+// The cache holds two entries per pixel, indexed by the parity of iMatch - x: the iteration settles into flipping
+// between two ADJACENT iMatch values, so both stay resident (0.74 % misses per sweep on C2's top level).
+__device__ __forceinline__ void refine_light_body(const StageArgs &a, int dir, int sweep, int bx, int by, int lin_block) {
+    const DirArgs &d = a.d[dir];
+    const int x = d.own.XL + 1 + bx * 256 + (int)threadIdx.x;
+    const int y0 = d.own.YL + 1 + by * RF_PPT;
     const int W = a.W;
     const bool colok = x <= d.own.XR - 1;
     const int xs = colok ? x : d.own.XL + 1; // out-of-range lanes shadow a valid column (no stores)
     const double *__restrict__ in = d.f64_a;
     double *__restrict__ out = d.f64_b;
     const int ylast = d.own.YR - 1;
+    if (y0 > ylast) return; // uniform (the other direction may have more rows)
     // phase 1: every state load of the RF_PPT pixels
     double col[RF_PPT + 2], dE[RF_PPT], dW[RF_PPT];
 #pragma unroll
@@ -253,12 +262,7 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         dE[i] = in[(size_t)yy * W + xs + 1];
         dW[i] = in[(size_t)yy * W + xs - 1];
     }
-    // phase 2: the cached data term.  Two entries per pixel.  The iteration settles into flipping between two
-    // ADJACENT iMatch values, so indexing the entries by the parity of iMatch keeps both resident -- but then
-    // neighbouring pixels sit in different arrays at random and every sweep touches the lines of BOTH (52 B per
-    // pixel measured).  opt_refine_ways = 1 indexes by the parity of the SWEEP instead: every pixel reads array
-    // s & 1 (34 B per pixel), a steady flipper still hits (iMatch(s) == iMatch(s - 2)), and a pixel whose phase
-    // slipped finds its entry in the other array, which the worklist kernel checks before recomputing.
+    // phase 2: the cache entry each pixel needs
     int key[RF_PPT], ckey[RF_PPT];
     double pwp[RF_PPT], delta[RF_PPT];
     size_t pix[RF_PPT];
@@ -267,13 +271,15 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         const int yy = min(y0 + i, ylast);
         pix[i] = (size_t)yy * W + xs;
         key[i] = (int)(col[i + 1] - 1.5) + xs; // .cpp:625
-        const size_t cpix = pix[i] + (size_t)(a.opt_refine_ways ? (a.flag2 & 1) : ((key[i] - xs) & 1)) * a.rf_stride;
+        const size_t cpix = pix[i] + (size_t)((key[i] - xs) & 1) * a.rf_stride;
         ckey[i] = (int)d.rf_key[cpix] + xs; // stored relative to the column (int16)
         pwp[i] = d.rf_pwp[cpix];
         delta[i] = d.rf_delta[cpix];
     }
     const int lane = threadIdx.x & 63;
-    const int shard = (blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & (RF_NSHARD - 1);
+    const int shard = lin_block & (RF_NSHARD - 1);
+    int32_t *cnt = rf_counter(a, dir, sweep, shard);
+    uint32_t *list = rf_shard_list(a, dir, shard);
 #pragma unroll
     for (int i = 0; i < RF_PPT; i++) {
         const double dC = col[i + 1], dN = col[i], dS = col[i + 2];
@@ -286,128 +292,29 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         if (mm) {
             const int leader = __builtin_ctzll(mm);
             int base = 0;
-            if (lane == leader) base = atomicAdd(&a.rf_cnt[(a.flag2 & 1) * RF_NSHARD + shard], __popcll(mm));
+            if (lane == leader) base = atomicAdd(cnt, __popcll(mm));
             base = __shfl(base, leader);
-            if (miss)
-                a.rf_list[(size_t)shard * a.rf_cap + base + __popcll(mm & ((1ull << lane) - 1ull))] =
-                    (uint32_t)pix[i] | ((uint32_t)blockIdx.z << 31);
+            if (miss) list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)pix[i];
         }
         if (live && !miss)
             out[pix[i]] = (mode == 0) ? dC /* .cpp:655 */ : refine_update(mode, dC, dE[i], dW[i], dN, dS, pwp[i], delta[i], a.ws);
     }
 }
 
-// FULL = 1 is the first sweep of a level: every cache entry is empty, so instead of a worklist the
-// kernel walks the whole interior (and also does the mode 0 copy-through).
-template <int FULL>
-__global__ __launch_bounds__(256) void k_refine_miss(StageArgs a) {
+// Serves one shard of a sweep's worklist: four lanes per entry (refine_data_term_quad) -- the work is one
+// dependent chain per entry, so a shorter chain matters more than lane utilisation.
+__device__ __forceinline__ void refine_miss_body(const StageArgs &a, int dir, int sweep, int shard) {
     const int W = a.W, H = a.H;
-    if (FULL) {
-        const DirArgs &d = a.d[blockIdx.z];
-        const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
-        const int y = d.own.YL + 1 + blockIdx.y;
-        if (x > d.own.XR - 1 || y > d.own.YR - 1) return;
-        const size_t pix = (size_t)y * W + x;
-        const double *in = d.f64_a;
-        const double dC = in[pix];
-        if (dC == (double)NOMATCH) return;
-        const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
-        const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
-                         (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
-        if (mode == 0) {
-            d.f64_b[pix] = dC;
-            return;
-        }
-        const int key = (int)(dC - 1.5) + x;
-        double pwp, delta;
-        refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, key, pwp, delta);
-        const size_t cpix = pix + (size_t)(a.opt_refine_ways ? (a.flag2 & 1) : ((key - x) & 1)) * a.rf_stride;
-        d.rf_key[cpix] = (int16_t)(key - x);
-        d.rf_pwp[cpix] = pwp;
-        d.rf_delta[cpix] = delta;
-        d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
-        return;
-    }
-    // worklist mode: one workgroup per shard.  Pass 1 serves the entries whose data term sits in the other array
-    // (phase slips: copy it over) and compacts the rest in place; pass 2 recomputes those with every lane busy.
-    __shared__ int sN;
-    const int shard = blockIdx.x & (RF_NSHARD - 1);
-    const int count = a.rf_cnt[(a.flag2 & 1) * RF_NSHARD + shard];
-    if (threadIdx.x == 0) {
-        a.rf_cnt[((a.flag2 + 1) & 1) * RF_NSHARD + shard] = 0; // the next sweep's counter set (idle now)
-        sN = 0;
-    }
-    uint32_t *list = a.rf_list + (size_t)shard * a.rf_cap;
-    const int lane = threadIdx.x & 63;
-    const int byS = a.opt_refine_ways;
-    const size_t wayS = (size_t)(a.flag2 & 1) * a.rf_stride, wayO = (size_t)((a.flag2 + 1) & 1) * a.rf_stride;
-    __syncthreads();
-    int n2 = count;
-    if (byS) {
-        for (int base = 0; base < count; base += 256 * RF_EPT) {
-            uint32_t ent[RF_EPT];
-#pragma unroll
-            for (int u = 0; u < RF_EPT; u++) {
-                const int e = base + u * 256 + (int)threadIdx.x;
-                ent[u] = (e < count) ? list[e] : 0xffffffffu;
-            }
-            __syncthreads(); // the chunk is in registers: its slots may now receive compacted entries
-            // every load of the chunk up front (the pass is latency-bound)
-            double dC[RF_EPT];
-            int okey[RF_EPT];
-#pragma unroll
-            for (int u = 0; u < RF_EPT; u++) {
-                const bool ok = ent[u] != 0xffffffffu;
-                const DirArgs &d = a.d[ok ? ent[u] >> 31 : 0];
-                const size_t pix = ok ? (ent[u] & 0x7fffffffu) : 0;
-                dC[u] = d.f64_a[pix];
-                okey[u] = (int)d.rf_key[pix + wayO];
-            }
-#pragma unroll
-            for (int u = 0; u < RF_EPT; u++) {
-                const bool ok = ent[u] != 0xffffffffu;
-                bool need = false;
-                if (ok) {
-                    const DirArgs &d = a.d[ent[u] >> 31];
-                    const size_t pix = ent[u] & 0x7fffffffu;
-                    const int rel = (int)(dC[u] - 1.5);
-                    if (okey[u] == rel) {
-                        const double pwp = d.rf_pwp[pix + wayO], delta = d.rf_delta[pix + wayO];
-                        const double *in = d.f64_a;
-                        const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
-                        const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
-                                         (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
-                        d.rf_key[pix + wayS] = (int16_t)rel;
-                        d.rf_pwp[pix + wayS] = pwp;
-                        d.rf_delta[pix + wayS] = delta;
-                        d.f64_b[pix] = refine_update(mode, dC[u], dE, dW, dN, dS, pwp, delta, a.ws);
-                    } else {
-                        need = true;
-                    }
-                }
-                const unsigned long long mm = __ballot(need);
-                if (mm) {
-                    const int leader = __builtin_ctzll(mm);
-                    int b0 = 0;
-                    if (lane == leader) b0 = atomicAdd(&sN, __popcll(mm));
-                    b0 = __shfl(b0, leader);
-                    if (need) list[b0 + __popcll(mm & ((1ull << lane) - 1ull))] = ent[u];
-                }
-            }
-        }
-        __syncthreads();
-        n2 = sN;
-    }
-    // four lanes per entry (refine_data_term_quad): the pass is one dependent chain per entry, so a shorter chain
-    // matters more than lane utilisation
-    for (int e0 = 0; e0 < n2; e0 += 64) { // uniform
+    const DirArgs &d = a.d[dir];
+    const int count = *rf_counter(a, dir, sweep, shard);
+    if (threadIdx.x == 0) *rf_counter(a, dir, sweep + 1, shard) = 0; // the next sweep's counter set (idle now)
+    const uint32_t *list = rf_shard_list(a, dir, shard);
+    const double *__restrict__ in = d.f64_a;
+    for (int e0 = 0; e0 < count; e0 += 64) { // uniform
         const int e = e0 + ((int)threadIdx.x >> 2), q = threadIdx.x & 3;
-        const bool live = e < n2;
-        const uint32_t ent = list[live ? e : e0];
-        const DirArgs &d = a.d[ent >> 31];
-        const size_t pix = ent & 0x7fffffffu;
+        const bool live = e < count;
+        const size_t pix = list[live ? e : e0];
         const int y = (int)(pix / W), x = (int)(pix % W);
-        const double *in = d.f64_a;
         const double dC = in[pix];
         const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
         const int key = (int)(dC - 1.5) + x;
@@ -416,13 +323,50 @@ __global__ __launch_bounds__(256) void k_refine_miss(StageArgs a) {
         if (live && q == 0) {
             const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
                              (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
-            const size_t cpix = pix + (byS ? wayS : (size_t)((key - x) & 1) * a.rf_stride);
+            const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
             d.rf_key[cpix] = (int16_t)(key - x);
             d.rf_pwp[cpix] = pwp;
             d.rf_delta[cpix] = delta;
             d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
         }
     }
+}
+
+// Per-sweep kernels (one direction, or both at once through gridDim.z): light sweep, then its worklist.
+// TOP only gives the top level's launches (the dominant kernel) their own name in rocprof traces.
+template <int TOP>
+__global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
+    refine_light_body(a, blockIdx.z, a.flag2, blockIdx.x, blockIdx.y, blockIdx.x + blockIdx.y * gridDim.x);
+}
+__global__ __launch_bounds__(256) void k_refine_worklist(StageArgs a) { refine_miss_body(a, blockIdx.z, a.flag2, blockIdx.x); }
+
+// First sweep of a level: every cache entry is empty, so instead of a worklist the kernel walks the whole
+// interior (and also does the mode 0 copy-through).
+__global__ __launch_bounds__(256) void k_refine_first(StageArgs a) {
+    const int W = a.W, H = a.H;
+    const DirArgs &d = a.d[blockIdx.z];
+    const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = d.own.YL + 1 + blockIdx.y;
+    if (x > d.own.XR - 1 || y > d.own.YR - 1) return;
+    const size_t pix = (size_t)y * W + x;
+    const double *in = d.f64_a;
+    const double dC = in[pix];
+    if (dC == (double)NOMATCH) return;
+    const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
+    const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                     (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
+    if (mode == 0) {
+        d.f64_b[pix] = dC;
+        return;
+    }
+    const int key = (int)(dC - 1.5) + x;
+    double pwp, delta;
+    refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, key, pwp, delta);
+    const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
+    d.rf_key[cpix] = (int16_t)(key - x);
+    d.rf_pwp[cpix] = pwp;
+    d.rf_delta[cpix] = delta;
+    d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
 }
 
 // Small levels are launch-latency bound: one fused kernel (data term inline on a miss) per sweep.
@@ -458,36 +402,46 @@ __global__ __launch_bounds__(256) void k_refine_fused(StageArgs a) {
     d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
 }
 
-static void launch_refine_sweep_impl(const StageArgs &a, dim3 grid, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
-
-void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    int rows = 0, cols = 0;
+static void refine_extent(const StageArgs &a, int &rows, int &cols) {
+    rows = cols = 0;
     for (int v = 0; v < a.ndir; v++) {
         rows = max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
         cols = max(cols, a.d[v].own.XR - a.d[v].own.XL - 1);
     }
-    if (rows <= 0 || cols <= 0) return;
-    const dim3 grid((cols + 255) / 256, rows, a.ndir);
-    StageArgs b = a;
-    // worklist shard capacity: every light-kernel workgroup of a shard could append all its pixels
-    const long long lblocks = (long long)grid.x * ((grid.y + RF_PPT - 1) / RF_PPT) * grid.z;
-    b.rf_cap = (int)(((lblocks + RF_NSHARD - 1) / RF_NSHARD) * 256 * RF_PPT);
-    return launch_refine_sweep_impl(b, grid, st, ev0, ev1);
 }
 
-static void launch_refine_sweep_impl(const StageArgs &a, dim3 grid, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    if ((long long)grid.x * grid.y * grid.z * 256 < a.opt_refine_fused_max) { // small level
+// worklist shard capacity: every light workgroup of a shard could append all its pixels
+static int refine_shard_cap(int gx, int gyL) {
+    const long long lblocks = (long long)gx * gyL;
+    return (int)(((lblocks + RF_NSHARD - 1) / RF_NSHARD) * 256 * RF_PPT);
+}
+
+bool refine_is_small(const StageArgs &a) {
+    int rows, cols;
+    refine_extent(a, rows, cols);
+    return (long long)((cols + 255) / 256) * rows * a.ndir * 256 < a.opt_refine_fused_max;
+}
+
+// One sweep f64_a -> f64_b (a.flag2 = sweep index) with per-sweep launches.
+void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    int rows, cols;
+    refine_extent(a, rows, cols);
+    if (rows <= 0 || cols <= 0) return;
+    const dim3 grid((cols + 255) / 256, rows, a.ndir);
+    if (refine_is_small(a)) { // small level: launch-latency bound
         hipLaunchKernelGGL(k_refine_fused, grid, dim3(256), 0, st, a);
         return;
     }
     if (a.flag2 == 0) { // first sweep: everything misses
-        hipLaunchKernelGGL(k_refine_miss<1>, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_refine_first, grid, dim3(256), 0, st, a);
         return;
     }
     const dim3 lgrid(grid.x, (grid.y + RF_PPT - 1) / RF_PPT, grid.z);
-    if (ev0) (void)hipEventRecord(ev0, st); // optional: time exactly the light kernel (roofline of bench.py)
-    if (a.flag) hipLaunchKernelGGL(k_refine_sweep<1>, lgrid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_refine_sweep<0>, lgrid, dim3(256), 0, st, a);
+    StageArgs b = a;
+    b.rf_cap = refine_shard_cap(lgrid.x, lgrid.y);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    if (a.flag) hipLaunchKernelGGL(k_refine_sweep<1>, lgrid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(k_refine_sweep<0>, lgrid, dim3(256), 0, st, b);
     if (ev1) (void)hipEventRecord(ev1, st);
-    hipLaunchKernelGGL(k_refine_miss<0>, dim3(RF_NSHARD * RF_SUB), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_refine_worklist, dim3(RF_NSHARD, 1, a.ndir), dim3(256), 0, st, b);
 }

@@ -89,7 +89,6 @@ struct rsm_ctx {
     // options (rsm_set_option)
     long long opt_refine_fused_max = 1ll << 20;
     int opt_ncc_bytes = 0;
-    int opt_refine_ways = 0;
 
     // profiling
     bool profile = false;
@@ -246,7 +245,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         DALLOC(c, c->rf_pwp[v], 2 * px);
         DALLOC(c, c->rf_delta[v], 2 * px);
     }
-    DALLOC(c, c->rf_cnt, 2 * RF_NSHARD + 16);
+    DALLOC(c, c->rf_cnt, RF_COUNTERS + 16);
     DALLOC(c, c->rf_list, RF_LIST_ENTRIES(in->width, in->height, 2));
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->d_j1, 4096);
@@ -315,7 +314,6 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "refine_fused_max")) c->opt_refine_fused_max = value;
     else if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
-    else if (!strcmp(name, "refine_ways")) c->opt_refine_ways = value != 0;
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
     return RSM_OK;
 }
@@ -350,11 +348,10 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.ws = c->in.ws;
     a.rf_cnt = c->rf_cnt;
     a.rf_list = c->rf_list;
-    a.ncc_cnt = c->rf_cnt + 2 * RF_NSHARD;
+    a.ncc_cnt = c->rf_cnt + RF_COUNTERS;
     a.rf_stride = c->cap_px;
     a.opt_refine_fused_max = c->opt_refine_fused_max;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
-    a.opt_refine_ways = c->opt_refine_ways;
     for (int v = 0; v < 2; v++) {
         DirArgs &d = a.d[v];
         const int o = 1 - v;
@@ -529,7 +526,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
                 a.d[v].f64_b = c->f64[nxt][v];
             }
             a.flag2 = it;
-            if (c->profile && k == N - 1 && (it & 7) == 4) { // events around every 8th launch of the dominant kernel
+            if (c->profile && k == N - 1 && (it & 7) == 4 && !refine_is_small(a)) { // every 8th launch of the dominant kernel
                 const int es = prof_slot(c, ST_REFINE_LIGHT_TOP);
                 launch_refine_sweep(a, st, c->evpool[es].a, c->evpool[es].b);
                 c->prof_launches[ST_REFINE_LIGHT_TOP] += 1;
@@ -774,7 +771,6 @@ StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, cons
     StageArgs a{};
     a.opt_refine_fused_max = c->opt_refine_fused_max;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
-    a.opt_refine_ways = c->opt_refine_ways;
     a.ndir = 1;
     a.W = W;
     a.H = H;
@@ -961,7 +957,7 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.rf_pwp = t.alloc<double>(2 * px);
     d.rf_delta = t.alloc<double>(2 * px);
     a.rf_stride = px;
-    a.rf_cnt = t.alloc<int32_t>(2 * RF_NSHARD);
+    a.rf_cnt = t.alloc<int32_t>(RF_COUNTERS);
     a.rf_list = t.alloc<uint32_t>(RF_LIST_ENTRIES(W, H, 1));
     if (!t.ok) return finish(c, t);
     if (iterations > RF_MAX_SWEEPS) return set_err(c, RSM_E_INVALID, "iterations");

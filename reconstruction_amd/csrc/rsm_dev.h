@@ -9,12 +9,12 @@
 #define WAVE 64
 #define RF_MAX_SWEEPS 1024
 #define RF_NOKEY ((int16_t)-32768)
-#define RF_NSHARD 1024 // refine worklist shards (power of 2) = workgroups of the worklist kernel
-#define RF_EPT 2       // worklist entries per thread and round of the copy pass
+#define RF_NSHARD 512 // refine worklist shards per direction (power of 2) = workgroups of a worklist pass
 #define RF_SUB 1      // worklist blocks per shard
 #define RF_PPT 4      // pixels per thread of the light sweep kernel
 // worklist capacity (entries) for ndir directions of a WxH level
-#define RF_LIST_ENTRIES(W, H, ndir) ((size_t)(ndir) * ((size_t)(W) + 256) * ((size_t)(H) + RF_PPT) + (size_t)RF_NSHARD * 256 * RF_PPT)
+#define RF_LIST_ENTRIES(W, H, ndir) ((size_t)(ndir) * (((size_t)(W) + 256) * ((size_t)(H) + RF_PPT) + (size_t)RF_NSHARD * 256 * RF_PPT))
+#define RF_COUNTERS (4 * RF_NSHARD) // [direction][sweep parity][shard]
 
 // Margin of one view at one level (struct Boundary, CManageData.h:10-14, without width/height).
 struct Mg {
@@ -53,9 +53,8 @@ struct StageArgs {
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
     long long opt_refine_fused_max; // refine: levels with fewer pixel-threads use the fused kernel
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
-    int opt_refine_ways;            // refine cache indexing: 0 = by parity of iMatch, 1 = by parity of the sweep (default)
-    int32_t *rf_cnt;   // refine: worklist counters [2 sets][RF_NSHARD]
-    uint32_t *rf_list; // refine / NCC: worklist of (dir << 31 | pixel index)
+    int32_t *rf_cnt;   // refine: worklist counters [RF_COUNTERS]
+    uint32_t *rf_list; // refine: per direction and shard, pixel indices; NCC: (dir << 31 | pixel index)
     int32_t *ncc_cnt;  // NCC: number of wide pixels in rf_list
 };
 
@@ -85,6 +84,7 @@ void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+bool refine_is_small(const StageArgs &a);
 
 // cloud: returns nothing; *d_npoints (device int64) receives the point count
 void launch_bad_prefix(const uint8_t *mask, int W, int H, int32_t *prefix, hipStream_t st);

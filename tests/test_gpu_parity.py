@@ -268,10 +268,10 @@ def test_order_constraint_heavy_crossings(ctx):
     assert np.array_equal(a, b), diff_report("order heavy", a, b)
 
 
-@pytest.mark.parametrize("opt", [("refine_fused_max", 1 << 40), ("ncc_bytes", 1), ("refine_ways", 1)])
+@pytest.mark.parametrize("opt", [("refine_fused_max", 1 << 40), ("ncc_bytes", 1)])
 def test_kernel_variants_give_identical_results(ctx, opt):
-    """The split (light + worklist) and fused refine kernels, both indexings of the refine cache, and the dot4 /
-    byte-wise NCC kernels, are interchangeable bit for bit."""
+    """The split (light + worklist) and fused refine kernels, and the dot4 / byte-wise NCC kernels, are
+    interchangeable bit for bit."""
     cfg = synth.config_small(**CASES["s320x160_occluded_neg_r4"])
     ctx.set_option("refine_fused_max", 0)   # base = split light + worklist kernels on every level
     base = ctx.match_pair(cfg)
@@ -281,7 +281,6 @@ def test_kernel_variants_give_identical_results(ctx, opt):
     finally:
         ctx.set_option("refine_fused_max", 1 << 20)
         ctx.set_option("ncc_bytes", 0)
-        ctx.set_option("refine_ways", 0)
     for v in range(2):
         assert np.array_equal(base.disparity[v], alt.disparity[v]), opt
     assert np.array_equal(base.xyz, alt.xyz, equal_nan=True)
