@@ -346,155 +346,103 @@ __global__ void k_setb_vert(StageArgs a) {
     BR[(size_t)YL * W + x] = (int16_t)br;
 }
 
-// horizontal sweeps (.cpp:903-941): sequential along x inside a row. One workgroup handles SBH_R rows;
-// SBH_R x SBH_W tiles of BL / BR / mask go through LDS (coalesced row-segment loads and stores), lane t
-// (< SBH_R) walks row t of the tile with the running (bl, br) pair in registers.
-#define SBH_R 16   // rows per wave
-#define SBH_W 256  // tile width (columns)
-#define SBH_LD 258 // LDS row stride in int16 elements
-#define SBH_LM 260 // LDS row stride of the mask tile (bytes)
+// horizontal sweeps (.cpp:903-941): sequential along x in the reference, but both are max-plus / min-plus
+// recurrences, i.e. segmented prefix scans:
+//   left -> right (:909-916)   bl[x] = max(bl[x], bl[x-1] - 1), br[x] = min(br[x], br[x-1] + 2) where mask[x-1] == 255
+//     <=> bl[x] + x = running max of (bl + x), br[x] - 2x = running min of (br - 2x) over the run of linked pixels;
+//   right -> left (:917-931)   with c = value arriving at x: where mask[x] == 255 the pixel stores the absolute
+//     columns max(c + x, XL1) / min(c' + x, XR1) and hands max(c, XL1 - x) - 2 / min(c', XR1 - x) + 1 on to x - 1
+//     <=> c[x] - 2x = running max (from the right) of u - 2x, c'[x] + x = running min of u' + x, where
+//     u[x] = max(bl[x], XL1 - x - 3), u'[x] = min(br[x], XR1 - x) at pixels that have a link from x + 1.
+// One wave per row walks it in 64-column chunks with a segmented wave scan (6 shuffle steps) and a carry.
+// All values stay within +-(10000 + W), so the reference's int16 stores never wrap and the scan is exact.
 __global__ __launch_bounds__(256) void k_setb_horiz(StageArgs a) {
-    __shared__ int16_t tl[SBH_R * SBH_LD], tr[SBH_R * SBH_LD];
-    __shared__ uint8_t tm[SBH_R * SBH_LM];
     const DirArgs &d = a.d[blockIdx.z];
-    const int y0 = d.own.YL + blockIdx.x * SBH_R;
-    if (y0 > d.own.YR) return;
-    const int W = a.W, XL = d.own.XL, XR = d.own.XR, XL1 = d.oth.XL, XR1 = d.oth.XR, YR = d.own.YR;
-    const int lane = threadIdx.x;
-    const int nrows = min(SBH_R, YR - y0 + 1);
-    const bool rowok = lane < nrows; // the first SBH_R lanes of wave 0 walk the rows
-    // ---- left -> right (.cpp:909-916), target-centric: x' = x + 1
-    int cbl = 0, cbr = 0, cm = 0; // running values / mask at x' - 1
-    for (int c0 = XL; c0 <= XR; c0 += SBH_W) {
-        const int nc = min(SBH_W, XR - c0 + 1);
-        { // the 256 threads fetch the SBH_R x SBH_W tile: thread = column, all rows' loads in flight at once
-            const int cc = threadIdx.x;
-            int16_t vl[SBH_R], vr[SBH_R];
-            uint8_t vm[SBH_R];
+    const int lane = threadIdx.x & 63;
+    const int y = d.own.YL + blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (y > d.own.YR) return; // wave-uniform
+    const int W = a.W, XL = d.own.XL, XR = d.own.XR, XL1 = d.oth.XL, XR1 = d.oth.XR;
+    int16_t *__restrict__ bl = d.BL + (size_t)y * W;
+    int16_t *__restrict__ br = d.BR + (size_t)y * W;
+    const uint8_t *__restrict__ mk = d.mask_own + (size_t)y * W;
+    const int nchunk = (XR - XL) / 64 + 1;
+    // ---- left -> right
+    int carryL = 0, carryR = 0;
+    for (int k = 0; k < nchunk; k++) {
+        const int x = XL + k * 64 + lane;
+        const bool in = x <= XR;
+        const bool link = in && x > XL && mk[x - 1] == 255;
+        int VL = in ? (int)bl[x] + x : 0, VR = in ? (int)br[x] - 2 * x : 0;
+        const unsigned long long heads = __ballot(!link);
+        const unsigned long long below = heads & ((2ull << lane) - 1ull); // lanes <= this one
+        const int head = below ? 63 - __builtin_clzll(below) : -1;       // -1: the run started in an earlier chunk
+        const int lo = head < 0 ? 0 : head;
 #pragma unroll
-            for (int r = 0; r < SBH_R; r++) {
-                const bool ok = r < nrows && cc < nc;
-                const size_t o = ok ? (size_t)(y0 + r) * W + c0 + cc : (size_t)y0 * W + c0;
-                vl[r] = d.BL[o];
-                vr[r] = d.BR[o];
-                vm[r] = d.mask_own[o];
-            }
-#pragma unroll
-            for (int r = 0; r < SBH_R; r++) {
-                tl[r * SBH_LD + cc] = vl[r];
-                tr[r * SBH_LD + cc] = vr[r];
-                tm[r * SBH_LM + cc] = vm[r];
+        for (int s = 1; s < 64; s <<= 1) {
+            const int oL = __shfl_up(VL, s), oR = __shfl_up(VR, s);
+            if (lane - s >= lo) {
+                VL = max(VL, oL);
+                VR = min(VR, oR);
             }
         }
-        __syncthreads();
-        if (rowok) {
-            for (int i = 0; i < nc; i++) {
-                int vbl = tl[lane * SBH_LD + i], vbr = tr[lane * SBH_LD + i];
-                if (c0 + i > XL && cm == 255) {
-                    vbl = max(cbl - 1, vbl);
-                    vbr = min(cbr + MAX_DISPARITY, vbr);
-                    tl[lane * SBH_LD + i] = (int16_t)vbl;
-                    tr[lane * SBH_LD + i] = (int16_t)vbr;
-                }
-                cbl = vbl;
-                cbr = vbr;
-                cm = tm[lane * SBH_LM + i];
-            }
+        if (head < 0) {
+            VL = max(VL, carryL);
+            VR = min(VR, carryR);
         }
-        __syncthreads();
-        {
-            const int cc = threadIdx.x;
-            if (cc < nc)
-#pragma unroll
-                for (int r = 0; r < SBH_R; r++)
-                    if (r < nrows) {
-                        const size_t o = (size_t)(y0 + r) * W + c0 + cc;
-                        d.BL[o] = tl[r * SBH_LD + cc];
-                        d.BR[o] = tr[r * SBH_LD + cc];
-                    }
+        if (link) {
+            bl[x] = (int16_t)(VL - x);
+            br[x] = (int16_t)(VR + 2 * x);
         }
-        __syncthreads();
+        carryL = __shfl(VL, 63);
+        carryR = __shfl(VR, 63);
     }
-    // ---- right -> left (.cpp:917-940). cbl/cbr hold the values at XR.
-    const int ntile = (XR - XL) / SBH_W + 1;
-    for (int t = ntile - 1; t >= 0; t--) {
-        const int c0 = XL + t * SBH_W;
-        const int nc = min(SBH_W, XR - c0 + 1);
-        { // the 256 threads fetch the SBH_R x SBH_W tile: thread = column, all rows' loads in flight at once
-            const int cc = threadIdx.x;
-            int16_t vl[SBH_R], vr[SBH_R];
-            uint8_t vm[SBH_R];
+    // ---- right -> left (each lane re-reads the columns it wrote itself above)
+    for (int k = nchunk - 1; k >= 0; k--) {
+        const int x = XL + k * 64 + lane;
+        const bool in = x <= XR;
+        const int m = in ? (int)mk[x] : 0;
+        const bool link = in && x < XR && mk[x + 1] == 255; // the pixel receives from x + 1
+        int tl = in ? (int)bl[x] : 0, tr = in ? (int)br[x] : 0;
+        if (link) {
+            tl = max(tl, XL1 - x - 3);
+            tr = min(tr, XR1 - x);
+        }
+        int VL = tl - 2 * x, VR = tr + x;
+        const unsigned long long heads = __ballot(!link);
+        const unsigned long long above = heads & ~((1ull << lane) - 1ull); // lanes >= this one
+        const int head = above ? __builtin_ctzll(above) : 64;             // 64: the run continues in the chunk to the right
+        const int hi = head > 63 ? 63 : head;
 #pragma unroll
-            for (int r = 0; r < SBH_R; r++) {
-                const bool ok = r < nrows && cc < nc;
-                const size_t o = ok ? (size_t)(y0 + r) * W + c0 + cc : (size_t)y0 * W + c0;
-                vl[r] = d.BL[o];
-                vr[r] = d.BR[o];
-                vm[r] = d.mask_own[o];
-            }
-#pragma unroll
-            for (int r = 0; r < SBH_R; r++) {
-                tl[r * SBH_LD + cc] = vl[r];
-                tr[r * SBH_LD + cc] = vr[r];
-                tm[r * SBH_LM + cc] = vm[r];
+        for (int s = 1; s < 64; s <<= 1) {
+            const int oL = __shfl_down(VL, s), oR = __shfl_down(VR, s);
+            if (lane + s <= hi) {
+                VL = max(VL, oL);
+                VR = min(VR, oR);
             }
         }
-        __syncthreads();
-        if (rowok) {
-            for (int i = nc - 1; i >= 0; i--) {
-                const int x = c0 + i;
-                if (x == XL) { // .cpp:932-940 (with the bl/br typo of :938-939)
-                    if (tm[lane * SBH_LM + i] == 255) {
-                        int A = (int16_t)(cbl + XL), B = (int16_t)(cbr + XL);
-                        if (A < XL1) A = XL1;
-                        if (B > XR1) A = XR1;
-                        tl[lane * SBH_LD + i] = (int16_t)A;
-                        tr[lane * SBH_LD + i] = (int16_t)B;
-                    } else {
-                        tl[lane * SBH_LD + i] = (int16_t)cbl;
-                        tr[lane * SBH_LD + i] = (int16_t)cbr;
-                    }
-                    break;
-                }
-                // value at x-1 before this step: from the tile, or from the next tile to the left
-                int lbl, lbr;
-                if (i > 0) {
-                    lbl = tl[lane * SBH_LD + i - 1];
-                    lbr = tr[lane * SBH_LD + i - 1];
-                } else {
-                    const size_t o = (size_t)(y0 + lane) * W + x - 1;
-                    lbl = d.BL[o];
-                    lbr = d.BR[o];
-                }
-                if (tm[lane * SBH_LM + i] == 255) {
-                    int A = (int16_t)(cbl + x), B = (int16_t)(cbr + x);
+        if (head == 64) {
+            VL = max(VL, carryL);
+            VR = min(VR, carryR);
+        }
+        carryL = __shfl(VL, 0);
+        carryR = __shfl(VR, 0);
+        if (in) {
+            const int cl = VL + 2 * x, cr = VR - x; // the values arriving at x
+            int A = cl, B = cr;
+            if (m == 255) {
+                A = (int16_t)(cl + x);
+                B = (int16_t)(cr + x);
+                if (x > XL) {
                     if (A < XL1) A = XL1;
                     if (B > XR1) B = XR1;
-                    tl[lane * SBH_LD + i] = (int16_t)A;
-                    tr[lane * SBH_LD + i] = (int16_t)B;
-                    lbl = max(A - x - MAX_DISPARITY, lbl);
-                    lbr = min(B - x + 1, lbr);
-                } else {
-                    tl[lane * SBH_LD + i] = (int16_t)cbl;
-                    tr[lane * SBH_LD + i] = (int16_t)cbr;
+                } else { // .cpp:932-940 with the bl/br typo of :938-939
+                    if (A < XL1) A = XL1;
+                    if (B > XR1) A = XR1;
                 }
-                cbl = lbl;
-                cbr = lbr;
             }
+            bl[x] = (int16_t)A;
+            br[x] = (int16_t)B;
         }
-        __syncthreads();
-        {
-            const int cc = threadIdx.x;
-            if (cc < nc)
-#pragma unroll
-                for (int r = 0; r < SBH_R; r++)
-                    if (r < nrows) {
-                        const size_t o = (size_t)(y0 + r) * W + c0 + cc;
-                        d.BL[o] = tl[r * SBH_LD + cc];
-                        d.BR[o] = tr[r * SBH_LD + cc];
-                    }
-        }
-        __syncthreads();
     }
 }
 
@@ -506,7 +454,7 @@ void launch_set_boundary(const StageArgs &a, hipStream_t st) {
     }
     if (rows <= 0 || cols <= 0) return;
     hipLaunchKernelGGL(k_setb_vert, dim3((cols + 63) / 64, 1, a.ndir), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_setb_horiz, dim3((rows + SBH_R - 1) / SBH_R, 1, a.ndir), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_setb_horiz, dim3((rows + 3) / 4, 1, a.ndir), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------- MedianFilter (1 iteration)
