@@ -237,113 +237,151 @@ void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, h
 
 // ---------------------------------------------------------------- SetBoundary_smooth<short>
 #define MAX_DISPARITY 2 // .cpp:4
-// vertical sweeps (.cpp:842-901): columns are independent -> one thread per column. The only serial
-// dependency is the (bl, br) register pair; loads are batched SB_U rows ahead of it.
-#define SB_U 16
-__global__ void k_setb_vert(StageArgs a) {
+// vertical sweeps (.cpp:842-901): columns are independent, rows are a serial recurrence on the (bl, br) pair --
+// but a recurrence of max-plus (bl) / min-plus (br) maps  x -> max(x + a, c)  only (assign a constant, step by
+// MAX_DISPARITY against a floor, or for the upward sweep against the downward result of the row above).  So a
+// column is cut into SBV_S row segments:
+//   k_setb_vert<UP, 0>  runs the reference's own row step over a segment on two probe pairs and stores the
+//                       segment's map (a, c) per bound (4 ints);
+//   k_setb_vert<UP, 1>  starts each segment from the true incoming pair (the maps of the segments before it
+//                       applied in order) and runs the same row step again, now storing the rows.
+// Threads = 64 columns x SBV_S segments per direction instead of one thread per column.
+// The upward sweep reads the downward result of the row above the one it is at; at a segment's last row that row
+// belongs to the neighbouring segment, whose thread overwrites it first thing, so the summary pass saves it.
+#define SBV_U 16              // rows loaded per batch
+#define SBV_LO (-(1 << 24))   // probes: far outside any value the recurrence can produce or clamp to
+#define SBV_HI (1 << 24)
+#define SBV_INF (1 << 26)
+// scratch (int32, in rf_list): per direction [SBV_S][W][6] = map (a_bl, c_bl, a_br, c_br) + saved pair, then [W][2]
+__device__ __forceinline__ int *sbv_scratch(const StageArgs &a, int dir) {
+    return (int *)a.rf_list + (size_t)dir * SETB_SCRATCH(a.W);
+}
+
+struct SbvPair {
+    int bl, br;
+};
+// one row of .cpp:844-868 (downward; UP = 0) or .cpp:876-899 (upward; UP = 1, (ul, ur) = the pair stored at the
+// row above by the downward sweep): `out` is what the row stores, `s` becomes the pair handed to the next row
+template <int UP>
+__device__ __forceinline__ void sbv_step(int m, int r, int ul, int ur, SbvPair &s, SbvPair &out) {
+    int nbl = UP ? ul : -10000, nbr = UP ? ur : 10000; // .cpp:832-833 / :880-881
+    if (m == 255) {
+        if (r != NOMATCH) {
+            s.bl = r;
+            s.br = r;
+        }
+        nbl = max(s.bl - MAX_DISPARITY, nbl);
+        nbr = min(s.br + MAX_DISPARITY, nbr);
+    }
+    out = s;
+    s.bl = nbl;
+    s.br = nbr;
+}
+
+template <int UP, int APPLY>
+__global__ __launch_bounds__(64) void k_setb_vert(StageArgs a) {
     const DirArgs &d = a.d[blockIdx.z];
-    const int x = d.own.XL + blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = d.own.XL + blockIdx.x * 64 + (int)threadIdx.x;
     if (x > d.own.XR) return;
-    const int W = a.W, YL = d.own.YL, YR = d.own.YR;
+    const int W = a.W, YL = d.own.YL, YR = d.own.YR, seg = blockIdx.y;
+    const int R = YR - YL, L = (R + SBV_S - 1) / SBV_S, base = YL + UP; // rows base .. base + R - 1 are swept
+    const int y0 = base + seg * L, y1 = min(y0 + L, base + R);          // this segment: rows [y0, y1), maybe empty
     const uint8_t *__restrict__ mk = d.mask_own;
     const int16_t *__restrict__ src = d.d16_in;
-    int16_t *__restrict__ BL = d.BL;
-    int16_t *__restrict__ BR = d.BR;
-    int bl = -10000, br = 10000; // .cpp:832-833
-    int y = YL;
-    for (; y + SB_U <= YR; y += SB_U) { // rows y .. y+SB_U-1 are all <= YR-1
-        int m[SB_U], r[SB_U];
+    int16_t *BL = d.BL, *BR = d.BR;
+    int *sc = sbv_scratch(a, blockIdx.z);
+    int *initp = sc + (size_t)SBV_S * W * 6 + (size_t)x * 2;
+    auto rec = [&](int k) { return sc + ((size_t)k * W + x) * 6; };
+
+    SbvPair s0, s1; // APPLY: s0 = the true pair.  Summary: s0 = (LO, HI) gives the maps' constants, s1 = (HI, LO) their slopes
+    int sav_l = 0, sav_r = 0;
+    if (APPLY) {
+        if (UP) { // from the pair the downward sweep ended with (:870-874), through the segments below this one
+            s0.bl = initp[0];
+            s0.br = initp[1];
+            for (int k = SBV_S - 1; k > seg; k--) {
+                const int *q = rec(k);
+                s0.bl = max(s0.bl + q[0], q[1]);
+                s0.br = min(s0.br + q[2], q[3]);
+            }
+            sav_l = rec(seg)[4];
+            sav_r = rec(seg)[5];
+        } else {
+            s0.bl = -10000;
+            s0.br = 10000;
+            for (int k = 0; k < seg; k++) {
+                const int *q = rec(k);
+                s0.bl = max(s0.bl + q[0], q[1]);
+                s0.br = min(s0.br + q[2], q[3]);
+            }
+        }
+        s1 = s0;
+    } else {
+        s0.bl = SBV_LO;
+        s0.br = SBV_HI;
+        s1.bl = SBV_HI;
+        s1.br = SBV_LO;
+        if (UP && seg == 0) { // rows are intact during the summary pass
+            initp[0] = BL[(size_t)YR * W + x];
+            initp[1] = BR[(size_t)YR * W + x];
+        }
+    }
+    // the segment's rows, SBV_U at a time (all loads of a batch before its stores), in sweep order
+    for (int t0 = 0; t0 < y1 - y0; t0 += SBV_U) {
+        int m[SBV_U], r[SBV_U], ul[SBV_U], ur[SBV_U];
 #pragma unroll
-        for (int i = 0; i < SB_U; i++) {
-            const size_t o = (size_t)(y + i) * W + x;
+        for (int i = 0; i < SBV_U; i++) {
+            const int t = min(t0 + i, y1 - y0 - 1);
+            const int y = UP ? y1 - 1 - t : y0 + t;
+            const size_t o = (size_t)y * W + x;
             m[i] = mk[o];
             r[i] = src[o];
-        }
-#pragma unroll
-        for (int i = 0; i < SB_U; i++) {
-            const size_t o = (size_t)(y + i) * W + x;
-            int nbl = -10000, nbr = 10000;
-            if (m[i] == 255) {
-                if (r[i] != NOMATCH) {
-                    bl = r[i];
-                    br = r[i];
+            if (UP) {
+                ul[i] = BL[o - W];
+                ur[i] = BR[o - W];
+                if (APPLY && y == y0) { // the neighbouring segment's thread may already have overwritten that row
+                    ul[i] = sav_l;
+                    ur[i] = sav_r;
                 }
-                nbl = max(bl - MAX_DISPARITY, nbl);
-                nbr = min(br + MAX_DISPARITY, nbr);
+            } else {
+                ul[i] = ur[i] = 0;
             }
-            BL[o] = (int16_t)bl;
-            BR[o] = (int16_t)br;
-            bl = nbl;
-            br = nbr;
-        }
-    }
-    for (; y <= YR - 1; y++) {
-        const size_t o = (size_t)y * W + x;
-        int nbl = -10000, nbr = 10000;
-        if (mk[o] == 255) {
-            const int ref = src[o];
-            if (ref != NOMATCH) {
-                bl = ref;
-                br = ref;
-            }
-            nbl = max(bl - MAX_DISPARITY, nbl);
-            nbr = min(br + MAX_DISPARITY, nbr);
-        }
-        BL[o] = (int16_t)bl;
-        BR[o] = (int16_t)br;
-        bl = nbl;
-        br = nbr;
-    }
-    BL[(size_t)YR * W + x] = (int16_t)bl;
-    BR[(size_t)YR * W + x] = (int16_t)br;
-    y = YR;
-    for (; y - SB_U >= YL; y -= SB_U) { // rows y .. y-SB_U+1 are all >= YL+1
-        int m[SB_U], r[SB_U], ul[SB_U], ur[SB_U];
-#pragma unroll
-        for (int i = 0; i < SB_U; i++) {
-            const size_t o = (size_t)(y - i) * W + x;
-            m[i] = mk[o];
-            r[i] = src[o];
-            ul[i] = BL[o - W];
-            ur[i] = BR[o - W];
         }
 #pragma unroll
-        for (int i = 0; i < SB_U; i++) {
-            const size_t o = (size_t)(y - i) * W + x;
-            int ubl = ul[i], ubr = ur[i];
-            if (m[i] == 255) {
-                if (r[i] != NOMATCH) {
-                    bl = r[i];
-                    br = r[i];
+        for (int i = 0; i < SBV_U; i++) {
+            if (t0 + i < y1 - y0) {
+                const int y = UP ? y1 - 1 - (t0 + i) : y0 + t0 + i;
+                SbvPair out;
+                sbv_step<UP>(m[i], r[i], ul[i], ur[i], s0, out);
+                if (APPLY) {
+                    BL[(size_t)y * W + x] = (int16_t)out.bl;
+                    BR[(size_t)y * W + x] = (int16_t)out.br;
+                } else {
+                    sbv_step<UP>(m[i], r[i], ul[i], ur[i], s1, out);
+                    if (UP && y == y0) {
+                        sav_l = ul[i];
+                        sav_r = ur[i];
+                    }
                 }
-                ubl = max(bl - MAX_DISPARITY, ubl);
-                ubr = min(br + MAX_DISPARITY, ubr);
             }
-            BL[o] = (int16_t)bl;
-            BR[o] = (int16_t)br;
-            bl = ubl;
-            br = ubr;
         }
     }
-    for (; y >= YL + 1; y--) {
-        const size_t o = (size_t)y * W + x;
-        int ubl = BL[o - W], ubr = BR[o - W];
-        if (mk[o] == 255) {
-            const int ref = src[o];
-            if (ref != NOMATCH) {
-                bl = ref;
-                br = ref;
-            }
-            ubl = max(bl - MAX_DISPARITY, ubl);
-            ubr = min(br + MAX_DISPARITY, ubr);
+    if (APPLY) {
+        // the sweep's last store: row YR after the downward sweep (:870-874), row YL after the upward one (:900-901)
+        if (y0 < y1 && (UP ? seg == 0 : y1 == base + R)) {
+            const size_t o = (size_t)(UP ? YL : YR) * W + x;
+            BL[o] = (int16_t)s0.bl;
+            BR[o] = (int16_t)s0.br;
         }
-        BL[o] = (int16_t)bl;
-        BR[o] = (int16_t)br;
-        bl = ubl;
-        br = ubr;
+    } else {
+        int *q = rec(seg);
+        q[0] = s1.bl > (1 << 23) ? s1.bl - SBV_HI : -SBV_INF; // slope part survived: x + a, else a constant map
+        q[1] = s0.bl;
+        q[2] = s1.br < -(1 << 23) ? s1.br - SBV_LO : SBV_INF;
+        q[3] = s0.br;
+        q[4] = sav_l;
+        q[5] = sav_r;
     }
-    BL[(size_t)YL * W + x] = (int16_t)bl;
-    BR[(size_t)YL * W + x] = (int16_t)br;
 }
 
 // horizontal sweeps (.cpp:903-941): sequential along x in the reference, but both are max-plus / min-plus
@@ -453,7 +491,11 @@ void launch_set_boundary(const StageArgs &a, hipStream_t st) {
         cols = max(cols, a.d[v].own.XR - a.d[v].own.XL + 1);
     }
     if (rows <= 0 || cols <= 0) return;
-    hipLaunchKernelGGL(k_setb_vert, dim3((cols + 63) / 64, 1, a.ndir), dim3(64), 0, st, a);
+    const dim3 vgrid((cols + 63) / 64, SBV_S, a.ndir);
+    hipLaunchKernelGGL((k_setb_vert<0, 0>), vgrid, dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_setb_vert<0, 1>), vgrid, dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_setb_vert<1, 0>), vgrid, dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_setb_vert<1, 1>), vgrid, dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_setb_horiz, dim3((rows + 3) / 4, 1, a.ndir), dim3(256), 0, st, a);
 }
 

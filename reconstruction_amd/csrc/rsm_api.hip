@@ -8,6 +8,8 @@
 #include "rectify_host.h"
 #include "rsm_dev.h"
 
+#include <algorithm>
+
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -751,7 +753,7 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     b.it = t.up(img_oth, px * 3);
     b.mo = t.up(mask_own, px);
     b.mt = t.up(mask_oth, px);
-    b.wl = t.alloc<uint32_t>(px + 64);
+    b.wl = t.alloc<uint32_t>(std::max(px + 64, SETB_SCRATCH(W))); // NCC worklist / SetBoundary scratch
     b.wc = t.alloc<int32_t>(16);
     b.i4o = t.alloc<uint32_t>(px);
     b.i4t = t.alloc<uint32_t>(px);
@@ -894,6 +896,7 @@ extern "C" int rsm_stage_set_boundary(rsm_ctx *c, const int16_t *disp, const uin
     a.d[0].mask_own = t.up(mask_own, px);
     a.d[0].BL = t.alloc<int16_t>(px);
     a.d[0].BR = t.alloc<int16_t>(px);
+    a.rf_list = t.alloc<uint32_t>(SETB_SCRATCH(W));
     if (!t.ok) return finish(c, t);
     launch_fill_i16(a.d[0].BL, px, (int16_t)-10000, c->stream);
     launch_fill_i16(a.d[0].BR, px, (int16_t)10000, c->stream);

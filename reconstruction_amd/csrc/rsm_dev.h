@@ -15,6 +15,9 @@
 // worklist capacity (entries) for ndir directions of a WxH level
 #define RF_LIST_ENTRIES(W, H, ndir) ((size_t)(ndir) * (((size_t)(W) + 256) * ((size_t)(H) + RF_PPT) + (size_t)RF_NSHARD * 256 * RF_PPT))
 #define RF_COUNTERS (4 * RF_NSHARD) // [direction][sweep parity][shard]
+#define SBV_S 32 // SetBoundary: row segments per column of the vertical sweeps
+// int32 scratch of launch_set_boundary (carved from rf_list), per direction
+#define SETB_SCRATCH(W) ((size_t)(SBV_S * 6 + 2) * (size_t)(W))
 
 // Margin of one view at one level (struct Boundary, CManageData.h:10-14, without width/height).
 struct Mg {
