@@ -42,10 +42,36 @@ void launch_bad_prefix(const uint8_t *mask, int W, int H, int32_t *prefix, hipSt
     hipLaunchKernelGGL(k_bad_prefix, dim3(H), dim3(256), 0, st, mask, W, H, prefix);
 }
 
-__device__ __forceinline__ bool eroded_is_255(const int32_t *__restrict__ prefix, int W, int H, int ksize,
-                                              const int *__restrict__ j1, const int *__restrict__ j2, int x,
-                                              int y) {
+// Coarse map for a quick accept: blk[by * nbx + bx] = 1 if the EB x EB block holds any pixel != 255.  A pixel whose
+// structuring-element bounding box only meets clean blocks is certainly kept; only the band of ~ksize pixels around
+// the mask's edges and holes runs the per-row span test.
+#define EB 32
+__global__ void k_bad_blocks(const int32_t *__restrict__ prefix, int W, int H, int nbx, int nby, uint8_t *__restrict__ blk) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbx * nby) return;
+    const int bx = b % nbx, by = b / nbx;
+    const int x0 = bx * EB, x1 = min(x0 + EB, W), y1 = min(by * EB + EB, H);
+    int bad = 0;
+    for (int y = by * EB; y < y1; y++) {
+        const int32_t *p = prefix + (size_t)y * (W + 1);
+        bad |= p[x1] - p[x0];
+    }
+    blk[b] = bad != 0;
+}
+
+__device__ __forceinline__ bool eroded_is_255(const int32_t *__restrict__ prefix, const uint8_t *__restrict__ blk, int W,
+                                              int H, int ksize, const int *__restrict__ j1, const int *__restrict__ j2,
+                                              int x, int y) {
     const int ax = ksize / 2, ay = ksize / 2;
+    if (blk) {
+        const int nbx = (W + EB - 1) / EB;
+        const int bx0 = max(x - ax, 0) / EB, bx1 = min(x + ksize - 1 - ax, W - 1) / EB;
+        const int by0 = max(y - ay, 0) / EB, by1 = min(y + ksize - 1 - ay, H - 1) / EB;
+        int bad = 0;
+        for (int by = by0; by <= by1; by++)
+            for (int bx = bx0; bx <= bx1; bx++) bad |= blk[by * nbx + bx];
+        if (!bad) return true;
+    }
     for (int i = 0; i < ksize; i++) {
         const int yy = y + i - ay;
         if (yy < 0 || yy >= H) continue;
@@ -64,7 +90,7 @@ __global__ void k_erode_binary(const int32_t *__restrict__ prefix, int W, int H,
                                uint8_t *__restrict__ dst) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
-    dst[(size_t)y * W + x] = eroded_is_255(prefix, W, H, ksize, j1, j2, x, y) ? 255 : 0;
+    dst[(size_t)y * W + x] = eroded_is_255(prefix, nullptr, W, H, ksize, j1, j2, x, y) ? 255 : 0;
 }
 
 void launch_erode_binary(const int32_t *prefix, int W, int H, int ksize, const int *d_j1, const int *d_j2,
@@ -82,7 +108,8 @@ struct CloudArgs {
     const double *q; // 16 doubles, column 3 already scaled (.cpp:698)
     const double *R, *T;
     Mg own;
-    uint8_t *flags; // W*H scratch: pass 0 stores cloud_flag, pass 1 reads it back
+    uint8_t *flags; // W*H scratch: pass 0 stores cloud_flag, pass 1 reads it back; then the coarse bad-block map
+    const uint8_t *blk;
     int32_t *row_count;
     int64_t *row_offset;
     int64_t *npoints;
@@ -94,7 +121,7 @@ struct CloudArgs {
 __device__ __forceinline__ bool cloud_flag(const CloudArgs &c, int x, int y) {
     if (x > c.own.XR) return false;
     if (c.disp[(size_t)y * c.W + x] == (double)NOMATCH) return false; // .cpp:743
-    return eroded_is_255(c.prefix, c.W, c.H, c.ksize, c.j1, c.j2, x, y); // .cpp:741
+    return eroded_is_255(c.prefix, c.blk, c.W, c.H, c.ksize, c.j1, c.j2, x, y); // .cpp:741
 }
 
 // pass 0: count per row; pass 1: ordered write. One 256-thread workgroup per margin row.
@@ -193,7 +220,10 @@ void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *
         (void)hipMemsetAsync(d_npoints, 0, sizeof(int64_t), st);
         return;
     }
-    CloudArgs c{disp, bad_prefix, img, W, H, ksize, d_j1, d_j2, q16_scaled, R, T, own, flags,
+    uint8_t *blk = flags + (size_t)W * H; // flags holds W*H + CLOUD_BLOCKS(W, H) bytes
+    const int nbx = (W + EB - 1) / EB, nby = (H + EB - 1) / EB;
+    hipLaunchKernelGGL(k_bad_blocks, dim3((nbx * nby + 255) / 256), dim3(256), 0, st, bad_prefix, W, H, nbx, nby, blk);
+    CloudArgs c{disp, bad_prefix, img, W, H, ksize, d_j1, d_j2, q16_scaled, R, T, own, flags, blk,
                 row_count, row_offset, d_npoints, xyz, bgr, max_points};
     hipLaunchKernelGGL(k_cloud<0>, dim3(rows), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(256), 0, st, row_count, rows, row_offset, d_npoints);

@@ -74,54 +74,70 @@ __global__ void k_margin_init(int *out4, int W, int H, int r) {
     out4[3] = r;         // YR
 }
 
-// one block per row y in [r, H-r); columns [r, W-r)
-__global__ void k_find_margin(const uint8_t *__restrict__ mask, int W, int H, int r, int *out4) {
-    const int y = r + blockIdx.x;
-    if (y >= H - r) return;
-    const uint8_t *p = mask + (size_t)y * W;
-    int lo = 0x7fffffff, hi = -1;
-    // 16 bytes per thread and load (row bases are only byte aligned: unaligned dwordx4 loads)
-    for (int x0 = r + 16 * threadIdx.x; x0 < W - r; x0 += 16 * blockDim.x) {
-        if (x0 + 16 <= W - r) {
-            uint32_t v[4];
-            __builtin_memcpy(v, p + x0, 16);
+// FM_ROWS rows y in [r, H-r) per block (one wave per row at a time); columns [r, W-r).  Few blocks, so that the
+// four global atomics per block do not pile up on one address (~88 same-address atomics per microsecond).
+#define FM_ROWS 16
+__global__ __launch_bounds__(256) void k_find_margin(const uint8_t *__restrict__ mask, int W, int H, int r, int *out4) {
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int lo = 0x7fffffff, hi = -1, ylo = 0x7fffffff, yhi = -1;
+    for (int k = wid; k < FM_ROWS; k += 4) {
+        const int y = r + blockIdx.x * FM_ROWS + k;
+        if (y >= H - r) break;
+        const uint8_t *p = mask + (size_t)y * W;
+        int rlo = 0x7fffffff, rhi = -1;
+        // 16 bytes per lane and load (row bases are only byte aligned: unaligned dwordx4 loads)
+        for (int x0 = r + 16 * lane; x0 < W - r; x0 += 16 * 64) {
+            if (x0 + 16 <= W - r) {
+                uint32_t v[4];
+                __builtin_memcpy(v, p + x0, 16);
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (((v[k >> 2] >> (8 * (k & 3))) & 255u) == 255u) {
-                    lo = min(lo, x0 + k);
-                    hi = max(hi, x0 + k);
-                }
-        } else {
-            for (int x = x0; x < W - r; x++)
-                if (p[x] == 255) {
-                    lo = min(lo, x);
-                    hi = max(hi, x);
-                }
+                for (int q = 0; q < 16; q++)
+                    if (((v[q >> 2] >> (8 * (q & 3))) & 255u) == 255u) {
+                        rlo = min(rlo, x0 + q);
+                        rhi = max(rhi, x0 + q);
+                    }
+            } else {
+                for (int x = x0; x < W - r; x++)
+                    if (p[x] == 255) {
+                        rlo = min(rlo, x);
+                        rhi = max(rhi, x);
+                    }
+            }
+        }
+        if (rhi >= 0) {
+            lo = min(lo, rlo);
+            hi = max(hi, rhi);
+            ylo = min(ylo, y);
+            yhi = max(yhi, y);
         }
     }
-    // wave reduce
     for (int o = 32; o > 0; o >>= 1) {
         lo = min(lo, __shfl_xor(lo, o));
         hi = max(hi, __shfl_xor(hi, o));
+        ylo = min(ylo, __shfl_xor(ylo, o));
+        yhi = max(yhi, __shfl_xor(yhi, o));
     }
-    __shared__ int slo[4], shi[4];
-    const int wid = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        slo[wid] = lo;
-        shi[wid] = hi;
+    __shared__ int sv[4][4];
+    if (lane == 0) {
+        sv[wid][0] = lo;
+        sv[wid][1] = hi;
+        sv[wid][2] = ylo;
+        sv[wid][3] = yhi;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < (int)(blockDim.x >> 6); i++) {
-            lo = min(lo, slo[i]);
-            hi = max(hi, shi[i]);
+        for (int i = 1; i < 4; i++) {
+            lo = min(lo, sv[i][0]);
+            hi = max(hi, sv[i][1]);
+            ylo = min(ylo, sv[i][2]);
+            yhi = max(yhi, sv[i][3]);
         }
-        if (hi >= 0) { // a stale read only costs a redundant atomic: ~12k same-address atomics would serialise
+        if (hi >= 0) { // a stale read only costs a redundant atomic
             volatile int *o = out4;
             if (lo < o[0]) atomicMin(&out4[0], lo);
             if (hi > o[1]) atomicMax(&out4[1], hi);
-            if (y < o[2]) atomicMin(&out4[2], y);
-            if (y > o[3]) atomicMax(&out4[3], y);
+            if (ylo < o[2]) atomicMin(&out4[2], ylo);
+            if (yhi > o[3]) atomicMax(&out4[3], yhi);
         }
     }
 }
@@ -130,22 +146,28 @@ void launch_find_margin(const uint8_t *mask, int W, int H, int r, int *out4, hip
     hipLaunchKernelGGL(k_margin_init, dim3(1), dim3(1), 0, st, out4, W, H, r);
     const int rows = H - 2 * r;
     if (rows <= 0 || W - 2 * r <= 0) return;
-    hipLaunchKernelGGL(k_find_margin, dim3(rows), dim3(256), 0, st, mask, W, H, r, out4);
+    hipLaunchKernelGGL(k_find_margin, dim3((rows + FM_ROWS - 1) / FM_ROWS), dim3(256), 0, st, mask, W, H, r, out4);
 }
 
-__global__ void k_count_masked(const uint8_t *__restrict__ mask, int W, Mg m, unsigned long long *count) {
-    const int y = m.YL + blockIdx.x;
-    if (y > m.YR) return;
+// masked pixels inside a margin (V_top of the metric): rows strided over a fixed number of blocks, one atomic each
+__global__ __launch_bounds__(256) void k_count_masked(const uint8_t *__restrict__ mask, int W, Mg m, unsigned long long *count) {
     int c = 0;
-    for (int x = m.XL + threadIdx.x; x <= m.XR; x += blockDim.x) c += mask[(size_t)y * W + x] == 255;
+    for (int y = m.YL + blockIdx.x; y <= m.YR; y += gridDim.x)
+        for (int x = m.XL + threadIdx.x; x <= m.XR; x += 256) c += mask[(size_t)y * W + x] == 255;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+    __shared__ int sc[4];
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = sc[0] + sc[1] + sc[2] + sc[3];
+        if (c) atomicAdd(count, (unsigned long long)c);
+    }
 }
 void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long long *d_count, hipStream_t st) {
     (void)H;
     (void)hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st);
     if (m.YR < m.YL || m.XR < m.XL) return;
-    hipLaunchKernelGGL(k_count_masked, dim3(m.YR - m.YL + 1), dim3(256), 0, st, mask, W, m, d_count);
+    hipLaunchKernelGGL(k_count_masked, dim3(min(m.YR - m.YL + 1, 512)), dim3(256), 0, st, mask, W, m, d_count);
 }
 
 // ---------------------------------------------------------------- window-sum tables

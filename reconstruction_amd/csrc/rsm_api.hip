@@ -1011,7 +1011,7 @@ extern "C" int rsm_stage_cloud(rsm_ctx *c, const double *disp, const uint8_t *ma
     uint8_t *db = (bgr && cap) ? t.alloc<uint8_t>((size_t)cap * 3) : nullptr;
     if (!t.ok) return finish(c, t);
     launch_bad_prefix(dm, W, H, pre, c->stream);
-    uint8_t *fl = t.alloc<uint8_t>(px);
+    uint8_t *fl = t.alloc<uint8_t>(px + CLOUD_BLOCKS(W, H));
     if (!t.ok) return finish(c, t);
     launch_cloud(dd, pre, di, W, H, ksize, d1, d2, dq, dR, dT, to_mg(*own), fl, rc, ro, dn, dx, db, cap, c->stream);
     int64_t n = 0;

@@ -89,7 +89,8 @@ void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 bool refine_is_small(const StageArgs &a);
 
-// cloud: returns nothing; *d_npoints (device int64) receives the point count
+// cloud: returns nothing; *d_npoints (device int64) receives the point count; `flags` = W*H + CLOUD_BLOCKS(W,H) bytes
+#define CLOUD_BLOCKS(W, H) ((size_t)(((W) + 31) / 32) * (size_t)(((H) + 31) / 32))
 void launch_bad_prefix(const uint8_t *mask, int W, int H, int32_t *prefix, hipStream_t st);
 void launch_erode_binary(const int32_t *prefix, int W, int H, int ksize, const int *d_j1, const int *d_j2,
                          uint8_t *dst255, hipStream_t st);
