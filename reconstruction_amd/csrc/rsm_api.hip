@@ -74,7 +74,8 @@ struct rsm_ctx {
     uint32_t *rf_list = nullptr;
     double *rf_pwp[2]{}, *rf_delta[2]{};
     int32_t *prefix = nullptr;
-    int *d_j1 = nullptr, *d_j2 = nullptr;
+    int *d_j1 = nullptr, *d_j2 = nullptr;   // structuring-element spans: Rectify's mask erosion
+    int *d_cj1 = nullptr, *d_cj2 = nullptr; // ... and DisparityToCloud's (uploaded with the pair)
     int32_t *row_count = nullptr;
     int64_t *row_offset = nullptr;
     int64_t *d_npoints = nullptr;
@@ -252,6 +253,8 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->d_j1, 4096);
     DALLOC(c, c->d_j2, 4096);
+    DALLOC(c, c->d_cj1, 4096);
+    DALLOC(c, c->d_cj2, 4096);
     DALLOC(c, c->row_count, (size_t)in->height);
     DALLOC(c, c->row_offset, (size_t)in->height);
     DALLOC(c, c->d_npoints, 2);
@@ -262,6 +265,28 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->xyz, px * 3);
     DALLOC(c, c->bgr, px * 3);
     c->cap_px = px;
+    return RSM_OK;
+}
+
+// The per-pair constants of DisparityToCloud travel with the pair: ellipse spans for ceil(0.02 * rows) (.cpp:703),
+// Q with its last column scaled (.cpp:692,698), R_final, T_final.  Synchronous (the sources are temporaries).
+static int upload_cloud_params(rsm_ctx *c) {
+    const int k = c->N - 1, H = c->Hk[k];
+    const int ksize = (int)ceil(0.02 * H);
+    if (ksize > 4096) return set_err(c, RSM_E_INVALID, "erode size");
+    std::vector<int> j1, j2;
+    ellipse_spans(ksize, j1, j2);
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_cj1, j1.data(), sizeof(int) * ksize, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_cj2, j2.data(), sizeof(int) * ksize, hipMemcpyHostToDevice, st));
+    double q[16];
+    memcpy(q, c->in.Q, sizeof q);
+    const double scale = (double)c->Wk[0] / c->in.origin_width * (1 << k); // .cpp:692
+    for (int i = 0; i < 4; i++) q[i * 4 + 3] *= scale;                     // .cpp:698
+    HIPCHK(c, hipMemcpyAsync(c->d_q, q, sizeof q, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_R, c->in.R_final, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_T, c->in.T_final, sizeof(double) * 3, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     return RSM_OK;
 }
 
@@ -278,6 +303,8 @@ static int upload_common(rsm_ctx *c, const rsm_pair_in *in, hipMemcpyKind kind) 
         HIPCHK(c, hipMemcpyAsync(c->msk[top][v], in->mask[v], px, kind, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    s = upload_cloud_params(c);
+    if (s != RSM_OK) return s;
     c->have_pair = true;
     c->have_result = false;
     return RSM_OK;
@@ -555,22 +582,9 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     {
         const int k = N - 1, W = c->Wk[k], H = c->Hk[k];
         const int ps14 = prof_begin(c, ST_CLOUD);
-        const int ksize = (int)ceil(0.02 * H); // .cpp:703
-        if (ksize > 4096) return set_err(c, RSM_E_INVALID, "erode size");
-        std::vector<int> j1, j2;
-        ellipse_spans(ksize, j1, j2);
-        HIPCHK(c, hipMemcpyAsync(c->d_j1, j1.data(), sizeof(int) * ksize, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->d_j2, j2.data(), sizeof(int) * ksize, hipMemcpyHostToDevice, st));
-        double q[16];
-        memcpy(q, c->in.Q, sizeof q);
-        const double scale = (double)c->Wk[0] / c->in.origin_width * (1 << k); // .cpp:692
-        for (int i = 0; i < 4; i++) q[i * 4 + 3] *= scale;                     // .cpp:698
-        HIPCHK(c, hipMemcpyAsync(c->d_q, q, sizeof q, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->d_R, c->in.R_final, sizeof(double) * 9, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->d_T, c->in.T_final, sizeof(double) * 3, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st)); // j1/j2/q are stack/vector storage
+        const int ksize = (int)ceil(0.02 * H); // .cpp:703; spans, Q, R, T: upload_cloud_params
         launch_bad_prefix(c->msk[k][0], W, H, c->prefix, st);
-        launch_cloud(c->f64[par][0], c->prefix, c->img[k][0], W, H, ksize, c->d_j1, c->d_j2, c->d_q, c->d_R, c->d_T,
+        launch_cloud(c->f64[par][0], c->prefix, c->img[k][0], W, H, ksize, c->d_cj1, c->d_cj2, c->d_q, c->d_R, c->d_T,
                      c->mg[k][0], (uint8_t *)c->d16a[0], c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
         const Mg &m = c->mg[k][0];
         prof_end(c, ps14, ST_CLOUD, 4, 28.0 * (double)(m.XR - m.XL + 1) * (m.YR - m.YL + 1));
@@ -1106,6 +1120,8 @@ extern "C" int rsm_rectify_pair(rsm_ctx *c, const rsm_rectify_in *in, int radius
     out->width = W;
     out->height = H;
     HIPCHK(c, hipStreamSynchronize(st));
+    s = upload_cloud_params(c);
+    if (s != RSM_OK) return s;
     c->have_pair = true;
     c->have_result = false;
     return RSM_OK;
