@@ -229,8 +229,10 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
 __device__ __forceinline__ int32_t *rf_counter(const StageArgs &a, int dir, int sweep, int shard) {
     return a.rf_cnt + ((dir * 2 + (sweep & 1)) * RF_NSHARD + shard);
 }
-__device__ __forceinline__ uint32_t *rf_shard_list(const StageArgs &a, int dir, int shard) {
-    return a.rf_list + ((size_t)dir * RF_NSHARD + shard) * a.rf_cap;
+// entries: pixel index | (iMatch - x) << 32 -- with the key in the entry the worklist pass can fetch the image
+// windows without first waiting for the pixel's state
+__device__ __forceinline__ uint64_t *rf_shard_list(const StageArgs &a, int dir, int shard) {
+    return (uint64_t *)a.rf_list + ((size_t)dir * RF_NSHARD + shard) * a.rf_cap;
 }
 
 // Light sweep: RF_PPT vertically adjacent pixels per thread, every load issued up front.  A pixel whose cached
@@ -279,7 +281,7 @@ __device__ __forceinline__ void refine_light_body(const StageArgs &a, int dir, i
     const int lane = threadIdx.x & 63;
     const int shard = lin_block & (RF_NSHARD - 1);
     int32_t *cnt = rf_counter(a, dir, sweep, shard);
-    uint32_t *list = rf_shard_list(a, dir, shard);
+    uint64_t *list = rf_shard_list(a, dir, shard);
 #pragma unroll
     for (int i = 0; i < RF_PPT; i++) {
         const double dC = col[i + 1], dN = col[i], dS = col[i + 2];
@@ -294,7 +296,9 @@ __device__ __forceinline__ void refine_light_body(const StageArgs &a, int dir, i
             int base = 0;
             if (lane == leader) base = atomicAdd(cnt, __popcll(mm));
             base = __shfl(base, leader);
-            if (miss) list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)pix[i];
+            if (miss)
+                list[base + __popcll(mm & ((1ull << lane) - 1ull))] =
+                    (uint64_t)(uint32_t)pix[i] | ((uint64_t)(uint32_t)(key[i] - xs) << 32);
         }
         if (live && !miss)
             out[pix[i]] = (mode == 0) ? dC /* .cpp:655 */ : refine_update(mode, dC, dE[i], dW[i], dN, dS, pwp[i], delta[i], a.ws);
@@ -306,25 +310,50 @@ __device__ __forceinline__ void refine_light_body(const StageArgs &a, int dir, i
 __device__ __forceinline__ void refine_miss_body(const StageArgs &a, int dir, int sweep, int shard) {
     const int W = a.W, H = a.H;
     const DirArgs &d = a.d[dir];
+    const uint64_t *list = rf_shard_list(a, dir, shard);
+    const int q = threadIdx.x & 3, e_first = (int)threadIdx.x >> 2;
+    // the first round's entries are fetched together with the count (stale slots are harmless): the pass is a
+    // chain of dependent memory round trips, not work
+    uint64_t ent = list[e_first];
     const int count = *rf_counter(a, dir, sweep, shard);
     if (threadIdx.x == 0) *rf_counter(a, dir, sweep + 1, shard) = 0; // the next sweep's counter set (idle now)
-    const uint32_t *list = rf_shard_list(a, dir, shard);
     const double *__restrict__ in = d.f64_a;
-    for (int e0 = 0; e0 < count; e0 += 64) { // uniform
-        const int e = e0 + ((int)threadIdx.x >> 2), q = threadIdx.x & 3;
-        const bool live = e < count;
-        const size_t pix = list[live ? e : e0];
+    int done = 0;
+    // long lists (the first sweeps of a level, before the iteration has settled): one lane per entry, all busy
+    for (; count - done >= 256; done += 256) { // uniform
+        const uint64_t en = list[done + (int)threadIdx.x];
+        const size_t pix = (uint32_t)en;
+        const int rel = (int)(en >> 32);
         const int y = (int)(pix / W), x = (int)(pix % W);
         const double dC = in[pix];
         const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
-        const int key = (int)(dC - 1.5) + x;
         double pwp, delta;
-        refine_data_term_quad(d.img4_own, d.img4_oth, W, H, x, y, key, q, pwp, delta);
+        refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, rel + x, pwp, delta);
+        const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                         (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
+        const size_t cpix = pix + (size_t)(rel & 1) * a.rf_stride;
+        d.rf_key[cpix] = (int16_t)rel;
+        d.rf_pwp[cpix] = pwp;
+        d.rf_delta[cpix] = delta;
+        d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+    }
+    for (int e0 = done; e0 < count; e0 += 64) { // uniform
+        const int e = e0 + e_first;
+        const bool live = e < count;
+        if (e0 > 0) ent = list[live ? e : e0]; // (round 0 was fetched with the count)
+        // idle lanes of the last round shadow a pixel that is certainly inside the image (no stores)
+        const size_t pix = live ? (size_t)(uint32_t)ent : (size_t)(d.own.YL + 1) * W + d.own.XL + 1;
+        const int rel = live ? (int)(ent >> 32) : 0;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        const double dC = in[pix];
+        const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
+        double pwp, delta;
+        refine_data_term_quad(d.img4_own, d.img4_oth, W, H, x, y, rel + x, q, pwp, delta);
         if (live && q == 0) {
             const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
                              (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
-            const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
-            d.rf_key[cpix] = (int16_t)(key - x);
+            const size_t cpix = pix + (size_t)(rel & 1) * a.rf_stride;
+            d.rf_key[cpix] = (int16_t)rel;
             d.rf_pwp[cpix] = pwp;
             d.rf_delta[cpix] = delta;
             d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);

@@ -249,7 +249,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         DALLOC(c, c->rf_delta[v], 2 * px);
     }
     DALLOC(c, c->rf_cnt, RF_COUNTERS + 16);
-    DALLOC(c, c->rf_list, RF_LIST_ENTRIES(in->width, in->height, 2));
+    DALLOC(c, c->rf_list, 2 * RF_LIST_ENTRIES(in->width, in->height, 2));
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->d_j1, 4096);
     DALLOC(c, c->d_j2, 4096);
@@ -975,7 +975,7 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.rf_delta = t.alloc<double>(2 * px);
     a.rf_stride = px;
     a.rf_cnt = t.alloc<int32_t>(RF_COUNTERS);
-    a.rf_list = t.alloc<uint32_t>(RF_LIST_ENTRIES(W, H, 1));
+    a.rf_list = t.alloc<uint32_t>(2 * RF_LIST_ENTRIES(W, H, 1));
     if (!t.ok) return finish(c, t);
     if (iterations > RF_MAX_SWEEPS) return set_err(c, RSM_E_INVALID, "iterations");
     d.f64_a = A;

@@ -12,7 +12,7 @@
 #define RF_NSHARD 512 // refine worklist shards per direction (power of 2) = workgroups of a worklist pass
 #define RF_SUB 1      // worklist blocks per shard
 #define RF_PPT 4      // pixels per thread of the light sweep kernel
-// worklist capacity (entries) for ndir directions of a WxH level
+// worklist capacity (8-byte entries) for ndir directions of a WxH level
 #define RF_LIST_ENTRIES(W, H, ndir) ((size_t)(ndir) * (((size_t)(W) + 256) * ((size_t)(H) + RF_PPT) + (size_t)RF_NSHARD * 256 * RF_PPT))
 #define RF_COUNTERS (4 * RF_NSHARD) // [direction][sweep parity][shard]
 #define SBV_S 32 // SetBoundary: row segments per column of the vertical sweeps
@@ -57,7 +57,7 @@ struct StageArgs {
     long long opt_refine_fused_max; // refine: levels with fewer pixel-threads use the fused kernel
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int32_t *rf_cnt;   // refine: worklist counters [RF_COUNTERS]
-    uint32_t *rf_list; // refine: per direction and shard, pixel indices; NCC: (dir << 31 | pixel index)
+    uint32_t *rf_list; // refine: per direction and shard, 8-byte entries (pixel | key << 32); NCC: (dir << 31 | pixel index)
     int32_t *ncc_cnt;  // NCC: number of wide pixels in rf_list
 };
 
