@@ -66,91 +66,291 @@ void launch_smooth(const StageArgs &a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- OrderConstraint
-// One 256-thread workgroup per row. Valid pixels are compacted in ascending x into LDS
-// (m = p[x] + x). Crossing count of i = #{j<i : m_j > m_i} + #{j>i : m_j < m_i} -- the row sums of the
-// reference's symmetric matrix A (.cpp:337-353) without ever materialising it. Then the greedy loop of
-// .cpp:354-364: remove the first pixel with the largest count until no crossings remain.
-__global__ __launch_bounds__(64) void k_order(StageArgs a, int maxL) {
-    // One wave (= one 64-thread workgroup) per row: no cross-wave barriers in the greedy loop.
+// One wave per row.  Valid pixels are compacted in ascending x into LDS (m = p[x] + x).  Crossing count of i =
+// #{j<i : m_j > m_i} + #{j>i : m_j < m_i} -- the row sums of the reference's symmetric matrix A (.cpp:337-353)
+// without ever materialising it -- then the greedy loop of .cpp:354-364: remove the first pixel with the largest
+// count until no crossings remain.
+// Crossings are local: position i is a cut (no pair j <= i < k crosses) iff max(m_0..m_i) <= min(m_i+1..), and
+// removals on one side of a cut never change a count on the other side, so the greedy order restricted to a
+// cut-free run ("component") is the order the reference's global arg-max visits that run in.  The row therefore
+// splits into independent components (typically 2-5 pixels around a disparity step): counts only look inside
+// the component, and every lane runs the greedy loop of its own components; only components longer than
+// ORD_BIG are worked on by the whole wave.
+#define ORD_BIG 48
+#define ORD_U 8
+#define ORD_NW 4 // waves per row: wave 0 does the serial passes, all of them the counting and the greedy loops
+__global__ __launch_bounds__(64 * ORD_NW) void k_order(StageArgs a, int maxL) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_n, s_win, s_go, s_ncomp, s_nbig, s_removed, s_bv[ORD_NW], s_bi[ORD_NW];
     const DirArgs &d = a.d[blockIdx.z];
     const int y = d.own.YL + blockIdx.x;
     if (y > d.own.YR) return;
     const int W = a.W, XL = d.own.XL, XR = d.own.XR;
-    int16_t *line = (int16_t *)smem; // [maxL] m = p[x] + x of the valid pixels, ascending x
-    int16_t *idx = line + maxL;      // [maxL] their x
-    int16_t *cnt = idx + maxL;       // [maxL] crossing counts (-1 = removed)
+    int16_t *line = (int16_t *)smem;                    // [maxL] m of the valid pixels, ascending x
+    int16_t *cnt = line + maxL;                         // [maxL] prefix max, later crossing counts (-1 = removed)
+    uint32_t *comps = (uint32_t *)(cnt + maxL);         // [maxL / 2] components with crossings: first | last << 16
+    unsigned long long *ends = (unsigned long long *)(comps + maxL / 2); // [maxL / 64 + 1] bit i: a component ends at i
+    int16_t *bmx = (int16_t *)(ends + maxL / 64 + 1), *bmn = bmx + maxL / 64 + 1; // max / min of every 64-element block
+    uint32_t *bigq = (uint32_t *)(bmn + maxL / 64 + 1); // [maxL / ORD_BIG + 1] the long components
     int16_t *p = d.d16_in + (size_t)y * W;
-    const int lane = threadIdx.x;
-    int n = 0, pmin = 0x7fffffff, pmax = -0x7fffffff;
-    for (int x0 = XL; x0 <= XR; x0 += 64) {
-        const int x = x0 + lane;
-        const int v = (x <= XR) ? (int)p[x] : NOMATCH;
-        const bool valid = v != NOMATCH;
-        const unsigned long long m = __ballot(valid);
-        if (valid) {
-            const int k = n + __popcll(m & ((1ull << lane) - 1ull));
-            line[k] = (int16_t)(v + x);
-            idx[k] = (int16_t)x;
-            pmin = min(pmin, v);
-            pmax = max(pmax, v);
-        }
-        n += __popcll(m);
-    }
-    if (n < 2) return;
-    __syncthreads();
-    // already non-decreasing -> no crossings at all
-    bool inv = false;
-    for (int i = lane; i + 1 < n; i += 64) inv = inv || (line[i] > line[i + 1]);
-    if (!__any(inv)) return;
-    for (int o = 32; o > 0; o >>= 1) {
-        pmin = min(pmin, __shfl_xor(pmin, o));
-        pmax = max(pmax, __shfl_xor(pmax, o));
-    }
-    // j < i crosses i only if x_i - x_j < p_j - p_i <= pmax - pmin, and x_i - x_j >= i - j:
-    // a window of `win` list positions on each side is exhaustive.
-    const int win = pmax - pmin;
-    for (int i = lane; i < n; i += 64) {
-        const int mi = line[i];
-        int c = 0;
-        const int j0 = max(0, i - win), j1 = min(n - 1, i + win);
-        for (int j = j0; j < i; j++) c += line[j] > mi;
-        for (int j = i + 1; j <= j1; j++) c += line[j] < mi;
-        cnt[i] = (int16_t)c;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull; // lanes below this one
+    if (tid == 0) {
+        s_go = 0;
+        s_ncomp = 0;
+        s_nbig = 0;
+        s_removed = 0;
     }
     __syncthreads();
-    for (;;) {
-        // first index of the maximum count (Armadillo's max(idx): strict '>' scan -> first maximum)
-        int bv = -1, bi = 0x7fffffff;
-        for (int i = lane; i < n; i += 64) {
-            const int c = cnt[i];
-            if (c > bv) {
-                bv = c;
-                bi = i;
+    if (wv == 0) {
+        int n = 0, pmin = 0x7fffffff, pmax = -0x7fffffff;
+        for (int x0 = XL; x0 <= XR; x0 += 64 * ORD_U) { // ORD_U row segments in flight: the pass is load latency
+            int v[ORD_U];
+#pragma unroll
+            for (int u = 0; u < ORD_U; u++) {
+                const int x = x0 + u * 64 + lane;
+                v[u] = (x <= XR) ? (int)p[x] : NOMATCH;
+            }
+#pragma unroll
+            for (int u = 0; u < ORD_U; u++) {
+                const bool valid = v[u] != NOMATCH;
+                const unsigned long long m = __ballot(valid);
+                if (valid) {
+                    line[n + __popcll(m & lt)] = (int16_t)(v[u] + x0 + u * 64 + lane);
+                    pmin = min(pmin, v[u]);
+                    pmax = max(pmax, v[u]);
+                }
+                n += __popcll(m);
             }
         }
+        // prefix max (kept in cnt for now); a row that is already non-decreasing has no crossings at all
+        bool inv = false;
+        int carry = -32768;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int i = c0 + lane;
+            const int own = (i < n) ? (int)line[i] : -32768;
+            int v = own;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const int o = __shfl_up(v, s);
+                if (lane >= s) v = max(v, o);
+            }
+            if (lane == 63) bmx[c0 >> 6] = (int16_t)v; // the block's own max (before the carry) ...
+            v = max(v, carry);
+            inv = inv || (i < n && own < v);
+            if (i < n) cnt[i] = (int16_t)v;
+            carry = __shfl(v, 63);
+            int mn = (i < n) ? own : 32767; // ... and min
+            for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+            if (lane == 0) bmn[c0 >> 6] = (int16_t)mn;
+        }
+        if (n >= 2 && __any(inv)) {
+            for (int o = 32; o > 0; o >>= 1) {
+                pmin = min(pmin, __shfl_xor(pmin, o));
+                pmax = max(pmax, __shfl_xor(pmax, o));
+            }
+            // suffix min -> where components end
+            carry = 32767;
+            for (int c = ((n + 63) >> 6) - 1; c >= 0; c--) {
+                const int i = c * 64 + lane;
+                int v = (i < n) ? (int)line[i] : 32767;
+#pragma unroll
+                for (int s = 1; s < 64; s <<= 1) {
+                    const int o = __shfl_down(v, s);
+                    if (lane + s < 64) v = min(v, o);
+                }
+                v = min(v, carry);           // min(m_i ..)
+                int nxt = __shfl_down(v, 1); // min(m_i+1 ..)
+                if (lane == 63) nxt = carry;
+                const bool end = i < n && (i == n - 1 || (int)cnt[i] <= nxt);
+                const unsigned long long e = __ballot(end);
+                if (lane == 0) ends[c] = e;
+                carry = __shfl(v, 0);
+            }
+            if (lane == 0) {
+                s_n = n;
+                // j < i crosses i only if x_i - x_j < p_j - p_i <= pmax - pmin, and x_i - x_j >= i - j: besides the
+                // component, a window of `win` list positions on each side bounds every search
+                s_win = pmax - pmin;
+                s_go = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_go) return;
+    const int n = s_n, win = s_win, nchunk = (n + 63) >> 6;
+    // counts inside the components; list of the components that have any crossing
+    for (int c = wv; c < nchunk; c += ORD_NW) {
+        const int c0 = c << 6, i = c0 + lane;
+        int cs = 0, ce = 0;
+        bool head = false;
+        const unsigned long long E = ends[c];
+        int prev_end = -1, next_end = n - 1; // last end before this chunk / first end after it (uniform look-ups)
+        for (int q = c - 1; q >= 0; q--) {
+            const unsigned long long m = ends[q];
+            if (m) {
+                prev_end = q * 64 + 63 - __builtin_clzll(m);
+                break;
+            }
+        }
+        for (int q = c + 1; q < nchunk; q++) {
+            const unsigned long long m = ends[q];
+            if (m) {
+                next_end = q * 64 + __builtin_ctzll(m);
+                break;
+            }
+        }
+        if (i < n) {
+            unsigned long long m = E & ~lt; // ends at or after i
+            ce = m ? c0 + __builtin_ctzll(m) : next_end;
+            m = E & lt;                     // ends before i
+            cs = m ? c0 + 64 - __builtin_clzll(m) : prev_end + 1;
+            head = (i == cs) && (ce > cs);
+        }
+        // crossing counts of the chunk's 64 pixels, the wave walking the 64-element blocks their components (and
+        // the +-win window) reach: block loads are wave-uniform (LDS broadcasts in a pipelined loop), and a block
+        // is skipped when its min / max say nothing in it can cross, counted whole when everything does.
+        const int mi = (i < n) ? (int)line[i] : 0;
+        int j0 = 0x7fffffff, j1 = -1, k = 0; // this lane's search range [j0, j1] (empty for a lone pixel)
+        if (i < n && ce > cs) {
+            j0 = max(cs, i - win);
+            j1 = min(ce, i + win);
+        }
+        int lo = j0, hi = j1;
         for (int o = 32; o > 0; o >>= 1) {
-            const int ov = __shfl_xor(bv, o), oi = __shfl_xor(bi, o);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        for (int b = lo >> 6; hi >= 0 && b <= (hi >> 6); b++) { // uniform
+            const int t0 = b << 6, t1 = min(t0 + 63, n - 1);
+            const int mx = bmx[b], mn = bmn[b];
+            bool scan = false;
+            if (t1 < j0 || t0 > j1) {
+                // out of this lane's range
+            } else if (t0 >= j0 && t1 < i) { // wholly to the left: crosses where m_j > m_i
+                if (mn > mi) k += t1 - t0 + 1;
+                else scan = mx > mi;
+            } else if (t0 > i && t1 <= j1) { // wholly to the right: crosses where m_j < m_i
+                if (mx < mi) k += t1 - t0 + 1;
+                else scan = mn < mi;
+            } else {
+                scan = true;
+            }
+            if (__any(scan)) {
+                for (int t = t0; t <= t1; t++) {
+                    const int v = line[t];
+                    if (scan) k += (t >= j0 && t < i && v > mi) || (t > i && t <= j1 && v < mi);
+                }
             }
         }
-        if (bv <= 0) break; // ones_count == 0 (.cpp:354)
-        const int mb = line[bi];
-        const int j0 = max(0, bi - win), j1 = min(n - 1, bi + win);
-        __syncthreads();
-        for (int j = j0 + lane; j <= j1; j += 64) {
-            const int c = cnt[j];
-            if (c < 0 || j == bi) continue; // removed pixels have no edges left
-            const int mj = line[j];
-            if ((j < bi && mj > mb) || (j > bi && mj < mb)) cnt[j] = (int16_t)(c - 1);
+        const unsigned long long hm = __ballot(head);
+        int base = 0;
+        if (hm && lane == 0) base = atomicAdd(&s_ncomp, __popcll(hm));
+        base = __shfl(base, 0);
+        if (head) comps[base + __popcll(hm & lt)] = (uint32_t)cs | ((uint32_t)ce << 16);
+        // (the prefix max in cnt is no longer needed: the ends are final)
+        if (i < n) cnt[i] = (int16_t)k;
+    }
+    __syncthreads();
+    // greedy removal: a lane per small component, the long ones are queued
+    const int ncomp = s_ncomp;
+    for (int t = tid; t < ncomp; t += 64 * ORD_NW) {
+        const uint32_t cc = comps[t];
+        const int cs = cc & 0xffff, ce = cc >> 16;
+        if (ce - cs + 1 > ORD_BIG) {
+            bigq[atomicAdd(&s_nbig, 1)] = cc;
+            continue;
         }
-        if (lane == 0) {
+        for (;;) {
+            int bv = -1, bi = cs;
+            for (int j = cs; j <= ce; j++) { // first index of the maximum (Armadillo's max(idx))
+                const int c = cnt[j];
+                if (c > bv) {
+                    bv = c;
+                    bi = j;
+                }
+            }
+            if (bv <= 0) break; // no crossing left here (.cpp:354)
+            const int mb = line[bi];
+            for (int j = max(cs, bi - win); j <= min(ce, bi + win); j++) {
+                const int c = cnt[j];
+                if (c < 0 || j == bi) continue; // removed pixels have no edges left
+                const int mj = line[j];
+                if ((j < bi && mj > mb) || (j > bi && mj < mb)) cnt[j] = (int16_t)(c - 1);
+            }
             cnt[bi] = -1; // row/col of A zeroed (.cpp:359-361)
-            p[idx[bi]] = (int16_t)NOMATCH;
+            s_removed = 1;
+        }
+    }
+    __syncthreads();
+    const int nbig = s_nbig;
+    for (int t = 0; t < nbig; t++) { // the whole workgroup on one long component at a time
+        const uint32_t cc = bigq[t];
+        const int cs = cc & 0xffff, ce = cc >> 16;
+        for (;;) {
+            int bv = -1, bi = 0x7fffffff;
+            for (int i = cs + tid; i <= ce; i += 64 * ORD_NW) {
+                const int c = cnt[i];
+                if (c > bv) {
+                    bv = c;
+                    bi = i;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const int ov = __shfl_xor(bv, o), oi = __shfl_xor(bi, o);
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                s_bv[wv] = bv;
+                s_bi[wv] = bi;
+            }
+            __syncthreads();
+            bv = s_bv[0];
+            bi = s_bi[0];
+#pragma unroll
+            for (int w = 1; w < ORD_NW; w++)
+                if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) {
+                    bv = s_bv[w];
+                    bi = s_bi[w];
+                }
+            if (bv <= 0) break; // uniform
+            const int mb = line[bi];
+            const int j0 = max(cs, bi - win), j1 = min(ce, bi + win);
+            for (int j = j0 + tid; j <= j1; j += 64 * ORD_NW) {
+                const int c = cnt[j];
+                if (c < 0 || j == bi) continue;
+                const int mj = line[j];
+                if ((j < bi && mj > mb) || (j > bi && mj < mb)) cnt[j] = (int16_t)(c - 1);
+            }
+            if (tid == 0) {
+                cnt[bi] = -1;
+                s_removed = 1;
+            }
+            __syncthreads();
         }
         __syncthreads();
+    }
+    __syncthreads();
+    if (!s_removed || wv != 0) return;
+    // the removed pixels become NOMATCH (.cpp:363): same compaction order as above
+    int k = 0;
+    for (int x0 = XL; x0 <= XR; x0 += 64 * ORD_U) {
+        int v[ORD_U];
+#pragma unroll
+        for (int u = 0; u < ORD_U; u++) {
+            const int x = x0 + u * 64 + lane;
+            v[u] = (x <= XR) ? (int)p[x] : NOMATCH;
+        }
+#pragma unroll
+        for (int u = 0; u < ORD_U; u++) {
+            const bool valid = v[u] != NOMATCH;
+            const unsigned long long m = __ballot(valid);
+            if (valid && cnt[k + __popcll(m & lt)] < 0) p[x0 + u * 64 + lane] = (int16_t)NOMATCH;
+            k += __popcll(m);
+        }
     }
 }
 
@@ -161,9 +361,9 @@ void launch_order(const StageArgs &a, hipStream_t st) {
         maxL = max(maxL, a.d[v].own.XR - a.d[v].own.XL + 1);
     }
     if (rows <= 0 || maxL <= 0) return;
-    maxL = (maxL + 7) & ~7;
-    const size_t lds = (size_t)maxL * 6;
-    hipLaunchKernelGGL(k_order, dim3(rows, 1, a.ndir), dim3(64), lds, st, a, maxL);
+    maxL = (maxL + 63) & ~63;
+    const size_t lds = (size_t)maxL * 6 + ((size_t)maxL / 64 + 1) * 12 + ((size_t)maxL / ORD_BIG + 1) * 4;
+    hipLaunchKernelGGL(k_order, dim3(rows, 1, a.ndir), dim3(64 * ORD_NW), lds, st, a, maxL);
 }
 
 // ---------------------------------------------------------------- UniquenessContraint_<T>
