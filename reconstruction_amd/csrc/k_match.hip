@@ -393,11 +393,17 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
     if (narrow && best != -1) d.d16_out[pix] = (int16_t)(best - x); // .cpp:219-222 / 301-302 / 563-564
 }
 
-// One workgroup per wide pixel (worklist of k_ncc_dot4), candidates spread over the 256 lanes.
+// One workgroup per wide pixel (worklist of k_ncc_dot4), candidates spread over the 256 lanes, NCC_G consecutive
+// ones per lane and pass.  The other view's rows of a pass (256 * NCC_G candidates + window) are staged in LDS with
+// coalesced loads first: read straight from global memory every lane would fetch 15 dwords per window row.
 template <int R>
 __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
     constexpr int WS = 2 * R + 1, G = NCC_G, NB = G + WS - 1;
     constexpr int n = WS * WS * 3;
+    constexpr int CHW = NCC_TX * G;  // candidates per pass
+    constexpr int SBW = CHW + 2 * R; // dwords per staged row
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *sB = (uint32_t *)smem; // [WS][SBW]
     __shared__ uint32_t sAw[WS * WS];
     __shared__ double s_v[NCC_TX / 64];
     __shared__ int s_c[NCC_TX / 64];
@@ -419,40 +425,54 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
         }
         L = max(L, R);
         Rr = min(Rr, W - 1 - R);
-        __syncthreads(); // previous item done with sAw / s_v / s_c
+        __syncthreads(); // previous item done with sAw / s_v / s_c / sB
         if (tid < WS * WS) sAw[tid] = d.img4_own[(size_t)(y - R + tid / WS) * W + x - R + tid % WS];
         const int Sa = d.S1_own[pix];
         const long long va = (long long)n * d.S2_own[pix] - (long long)Sa * Sa;
-        __syncthreads();
         double bv = -1.0;
         int bc = 0x7fffffff;
-        for (int c0 = L + tid * G; c0 <= Rr; c0 += NCC_TX * G) {
-            uint32_t acc[G];
+        for (int lo = L; lo <= Rr; lo += CHW) { // uniform
+            const int hi = min(lo + CHW - 1, Rr);
+            const int ndw = hi - lo + 1 + 2 * R + (G - 1); // columns lo - R .. hi + R (+ group padding)
+            __syncthreads();
+            for (int i = tid; i < ndw; i += NCC_TX) {
+                const int col = min(lo - R + i, W - 1); // clamped columns belong to candidates > Rr only
+                uint32_t v[WS];
 #pragma unroll
-            for (int g = 0; g < G; g++) acc[g] = 0u;
+                for (int j = 0; j < WS; j++) v[j] = d.img4_oth[(size_t)(y - R + j) * W + col];
+#pragma unroll
+                for (int j = 0; j < WS; j++) sB[j * (SBW + G) + i] = v[j];
+            }
+            __syncthreads();
+            const int c0 = lo + tid * G;
+            if (c0 <= hi) {
+                uint32_t acc[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = 0u;
+                const int bo = c0 - lo;
 #pragma unroll 1
-            for (int j = 0; j < WS; j++) {
-                const uint32_t *brow = d.img4_oth + (size_t)(y - R + j) * W;
-                uint32_t av[WS], bw[NB];
+                for (int j = 0; j < WS; j++) {
+                    uint32_t av[WS], bw[NB];
 #pragma unroll
-                for (int m = 0; m < WS; m++) av[m] = sAw[j * WS + m];
+                    for (int m = 0; m < WS; m++) av[m] = sAw[j * WS + m];
 #pragma unroll
-                for (int t = 0; t < NB; t++) bw[t] = brow[min(c0 - R + t, W - 1)]; // clamped columns belong to c > Rr only
+                    for (int t = 0; t < NB; t++) bw[t] = sB[j * (SBW + G) + bo + t];
 #pragma unroll
-                for (int m = 0; m < WS; m++)
+                    for (int m = 0; m < WS; m++)
 #pragma unroll
-                    for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_udot4(av[m], bw[g + m], acc[g], false);
+                        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_udot4(av[m], bw[g + m], acc[g], false);
+                }
+                uint8_t mk[G];
+                int32_t s1[G], s2[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const size_t o = (size_t)y * W + min(c0 + g, Rr);
+                    mk[g] = d.mask_oth[o];
+                    s1[g] = d.S1_oth[o];
+                    s2[g] = d.S2_oth[o];
+                }
+                ncc_score_group<R>(acc, c0, Rr, mk, s1, s2, Sa, va, bv, bc);
             }
-            uint8_t mk[G];
-            int32_t s1[G], s2[G];
-#pragma unroll
-            for (int g = 0; g < G; g++) {
-                const size_t o = (size_t)y * W + min(c0 + g, Rr);
-                mk[g] = d.mask_oth[o];
-                s1[g] = d.S1_oth[o];
-                s2[g] = d.S2_oth[o];
-            }
-            ncc_score_group<R>(acc, c0, Rr, mk, s1, s2, Sa, va, bv, bc);
         }
         // block argmax; equal scores -> the smaller column (the reference scans ascending with '>')
         for (int o = 32; o > 0; o >>= 1) {
@@ -485,7 +505,8 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
     const size_t lds = 16 + (size_t)WS * (SA + SB) * 4 + (size_t)(NCC_CH + NCC_G) * 9 + 16;
     (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), st);
     hipLaunchKernelGGL(k_ncc_dot4<R>, grid, dim3(NCC_TX), lds, st, a, mode);
-    hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), 0, st, a, mode);
+    const size_t ldsw = (size_t)WS * (NCC_TX * NCC_G + 2 * R + NCC_G) * 4;
+    hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), ldsw, st, a, mode);
 }
 
 void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
