@@ -173,46 +173,62 @@ void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long 
 // ---------------------------------------------------------------- window-sum tables
 // S1(x,y) = sum of the (2r+1)x(2r+1)x3 bytes centred on (x,y); S2 = sum of their squares.
 // Defined where the window fits; 0 elsewhere. Separable: horizontal then vertical.
-__global__ void k_box_h(const uint8_t *__restrict__ img, int W, int H, int r, int32_t *__restrict__ h1,
+// Horizontal pass on the BGRX copy: one aligned dword per pixel, v_sad_u8 sums its three bytes (X = 0) and
+// v_dot4_u32_u8 with itself their squares.
+__global__ void k_box_h(const uint32_t *__restrict__ img4, int W, int H, int r, int32_t *__restrict__ h1,
                         int32_t *__restrict__ h2) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
-    int s1 = 0, s2 = 0;
+    uint32_t s1 = 0, s2 = 0;
     if (x - r >= 0 && x + r < W) {
-        const uint8_t *p = img + ((size_t)y * W + (x - r)) * 3;
-        const int n = (2 * r + 1) * 3;
-        for (int i = 0; i < n; i++) {
-            const int v = p[i];
-            s1 += v;
-            s2 += v * v;
+        const uint32_t *p = img4 + (size_t)y * W + (x - r);
+        for (int i = 0; i <= 2 * r; i++) {
+            const uint32_t v = p[i];
+            s1 = __builtin_amdgcn_sad_u8(v, 0u, s1);
+            s2 = __builtin_amdgcn_udot4(v, v, s2, false);
         }
     }
-    h1[(size_t)y * W + x] = s1;
-    h2[(size_t)y * W + x] = s2;
+    h1[(size_t)y * W + x] = (int32_t)s1;
+    h2[(size_t)y * W + x] = (int32_t)s2;
 }
 
+// Vertical pass: a thread walks BV_ROWS consecutive rows of its column with running sums (one row enters, one
+// leaves) instead of re-adding 2r+1 rows per output.
+#define BV_ROWS 16
 __global__ void k_box_v(const int32_t *__restrict__ h1, const int32_t *__restrict__ h2, int W, int H, int r,
                         int32_t *__restrict__ S1, int32_t *__restrict__ S2) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
+    const int y0 = blockIdx.y * BV_ROWS;
     if (x >= W) return;
     int s1 = 0, s2 = 0;
-    if (y - r >= 0 && y + r < H) {
-        for (int j = -r; j <= r; j++) {
-            s1 += h1[(size_t)(y + j) * W + x];
-            s2 += h2[(size_t)(y + j) * W + x];
+    bool have = false; // s1 / s2 hold the window sums of the previous row
+    for (int y = y0; y < min(y0 + BV_ROWS, H); y++) {
+        int o1 = 0, o2 = 0;
+        if (y - r >= 0 && y + r < H) {
+            if (have) {
+                s1 += h1[(size_t)(y + r) * W + x] - h1[(size_t)(y - r - 1) * W + x];
+                s2 += h2[(size_t)(y + r) * W + x] - h2[(size_t)(y - r - 1) * W + x];
+            } else {
+                s1 = s2 = 0;
+                for (int j = -r; j <= r; j++) {
+                    s1 += h1[(size_t)(y + j) * W + x];
+                    s2 += h2[(size_t)(y + j) * W + x];
+                }
+                have = true;
+            }
+            o1 = s1;
+            o2 = s2;
         }
+        S1[(size_t)y * W + x] = o1;
+        S2[(size_t)y * W + x] = o2;
     }
-    S1[(size_t)y * W + x] = s1;
-    S2[(size_t)y * W + x] = s2;
 }
 
-void launch_box_sums(const uint8_t *img, int W, int H, int r, int32_t *tmp1, int32_t *tmp2, int32_t *S1,
+void launch_box_sums(const uint32_t *img4, int W, int H, int r, int32_t *tmp1, int32_t *tmp2, int32_t *S1,
                      int32_t *S2, hipStream_t st) {
-    dim3 grid((W + 255) / 256, H);
-    hipLaunchKernelGGL(k_box_h, grid, dim3(256), 0, st, img, W, H, r, tmp1, tmp2);
-    hipLaunchKernelGGL(k_box_v, grid, dim3(256), 0, st, tmp1, tmp2, W, H, r, S1, S2);
+    hipLaunchKernelGGL(k_box_h, dim3((W + 255) / 256, H), dim3(256), 0, st, img4, W, H, r, tmp1, tmp2);
+    hipLaunchKernelGGL(k_box_v, dim3((W + 255) / 256, (H + BV_ROWS - 1) / BV_ROWS), dim3(256), 0, st, tmp1, tmp2, W, H, r, S1, S2);
 }
 
 // ---------------------------------------------------------------- BGR -> BGRX (one dword per pixel)

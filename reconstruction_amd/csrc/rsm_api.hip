@@ -461,8 +461,8 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
 
         const int ps3 = prof_begin(c, ST_BOXSUM);
         for (int v = 0; v < 2; v++) {
-            launch_box_sums(c->img[k][v], W, H, r, c->tmp1, c->tmp2, c->S1[v], c->S2[v], st);
             launch_bgr_to_bgrx(c->img[k][v], W, H, c->img4[v], st);
+            launch_box_sums(c->img4[v], W, H, r, c->tmp1, c->tmp2, c->S1[v], c->S2[v], st);
         }
         prof_end(c, ps3, ST_BOXSUM, 6, 0);
 
@@ -777,10 +777,10 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     b.S2t = t.alloc<int32_t>(px);
     int32_t *t1 = t.alloc<int32_t>(px), *t2 = t.alloc<int32_t>(px);
     if (!t.ok) return false;
-    launch_box_sums(b.io, W, H, r, t1, t2, b.S1o, b.S2o, c->stream);
-    launch_box_sums(b.it, W, H, r, t1, t2, b.S1t, b.S2t, c->stream);
     launch_bgr_to_bgrx(b.io, W, H, b.i4o, c->stream);
     launch_bgr_to_bgrx(b.it, W, H, b.i4t, c->stream);
+    launch_box_sums(b.i4o, W, H, r, t1, t2, b.S1o, b.S2o, c->stream);
+    launch_box_sums(b.i4t, W, H, r, t1, t2, b.S1t, b.S2t, c->stream);
     return true;
 }
 StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, const rsm_boundary *oth) {

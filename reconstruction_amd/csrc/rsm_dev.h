@@ -69,7 +69,7 @@ void launch_pyr_down(const uint8_t *src, int W, int H, int C, uint8_t *dst, hipS
 // out4 = {XL, XR, YL, YR} initialised by the kernel launcher (inverted defaults, .cpp:1014-1017)
 void launch_find_margin(const uint8_t *mask, int W, int H, int r, int *out4, hipStream_t st);
 void launch_bgr_to_bgrx(const uint8_t *img, int W, int H, uint32_t *out, hipStream_t st);
-void launch_box_sums(const uint8_t *img, int W, int H, int r, int32_t *tmp1, int32_t *tmp2,
+void launch_box_sums(const uint32_t *img4, int W, int H, int r, int32_t *tmp1, int32_t *tmp2,
                      int32_t *S1, int32_t *S2, hipStream_t st);
 
 void launch_next_valid(const double *parent, int Wp, int Hp, int32_t *nv, hipStream_t st);
