@@ -398,37 +398,113 @@ __global__ __launch_bounds__(256) void k_refine_first(StageArgs a) {
     d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
 }
 
-// Small levels are launch-latency bound: one fused kernel (data term inline on a miss) per sweep.
+// Small levels are launch-latency bound: one kernel per sweep.  Misses are served inside the workgroup: they are
+// compacted through an LDS list and served by quads (or a lane each when the list is long, as in a level's first
+// sweeps); serving them in place would run the data-term routine in every second wave for one or two lanes.
+#define RFU_CAP (256 * RF_PPT) // every pixel of the workgroup may miss
 __global__ __launch_bounds__(256) void k_refine_fused(StageArgs a) {
+    __shared__ uint32_t s_list[RFU_CAP]; // slot of the owner (thread * RF_PPT + i) | (iMatch - x) << 16
+    __shared__ double s_res[RFU_CAP][2];
+    __shared__ int s_n;
     const DirArgs &d = a.d[blockIdx.z];
-    const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = d.own.YL + 1 + blockIdx.y;
-    if (x > d.own.XR - 1 || y > d.own.YR - 1) return;
     const int W = a.W, H = a.H;
+    const int x = d.own.XL + 1 + blockIdx.x * 256 + (int)threadIdx.x;
+    const int y0 = d.own.YL + 1 + blockIdx.y * RF_PPT;
+    const int ylast = d.own.YR - 1;
+    if (y0 > ylast) return; // uniform
+    const bool colok = x <= d.own.XR - 1;
+    const int xs = colok ? x : d.own.XL + 1; // out-of-range lanes shadow a valid column (no stores)
     const double *__restrict__ in = d.f64_a;
-    const size_t pix = (size_t)y * W + x;
-    const double dC = in[pix];
-    if (dC == (double)NOMATCH) return;
-    const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
-    const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
-                     (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
-    if (mode == 0) {
-        d.f64_b[pix] = dC;
-        return;
+    double *__restrict__ out = d.f64_b;
+    if (threadIdx.x == 0) s_n = 0;
+    double col[RF_PPT + 2], dE[RF_PPT], dW[RF_PPT];
+#pragma unroll
+    for (int i = 0; i < RF_PPT + 2; i++) {
+        const int yy = min(y0 - 1 + i, ylast + 1);
+        col[i] = in[(size_t)yy * W + xs];
     }
-    const int key = (int)(dC - 1.5) + x;
-    const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
-    double pwp, delta;
-    if ((int)d.rf_key[cpix] + x == key) {
-        pwp = d.rf_pwp[cpix];
-        delta = d.rf_delta[cpix];
-    } else {
-        refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, key, pwp, delta);
-        d.rf_key[cpix] = (int16_t)(key - x);
-        d.rf_pwp[cpix] = pwp;
-        d.rf_delta[cpix] = delta;
+#pragma unroll
+    for (int i = 0; i < RF_PPT; i++) {
+        const int yy = min(y0 + i, ylast);
+        dE[i] = in[(size_t)yy * W + xs + 1];
+        dW[i] = in[(size_t)yy * W + xs - 1];
     }
-    d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+    int rel[RF_PPT], crel[RF_PPT];
+    double pwp[RF_PPT], delta[RF_PPT];
+#pragma unroll
+    for (int i = 0; i < RF_PPT; i++) {
+        const int yy = min(y0 + i, ylast);
+        rel[i] = (int)(col[i + 1] - 1.5); // .cpp:625 (iMatch - x)
+        const size_t cpix = (size_t)yy * W + xs + (size_t)(rel[i] & 1) * a.rf_stride;
+        crel[i] = d.rf_key[cpix];
+        pwp[i] = d.rf_pwp[cpix];
+        delta[i] = d.rf_delta[cpix];
+    }
+    __syncthreads(); // s_n = 0
+    const int lane = threadIdx.x & 63;
+    unsigned live = 0, miss = 0;
+    int mode[RF_PPT];
+#pragma unroll
+    for (int i = 0; i < RF_PPT; i++) {
+        const double dC = col[i + 1], dN = col[i], dS = col[i + 2];
+        const bool lv = colok && (y0 + i <= ylast) && dC != (double)NOMATCH; // .cpp:613
+        mode[i] = (int)(dE[i] != (double)NOMATCH && dW[i] != (double)NOMATCH) +
+                  (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
+        const bool ms = lv && mode[i] != 0 && crel[i] != rel[i];
+        const unsigned long long mm = __ballot(ms);
+        if (mm) {
+            const int leader = __builtin_ctzll(mm);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_n, __popcll(mm));
+            base = __shfl(base, leader);
+            if (ms) s_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (threadIdx.x * RF_PPT + i) | ((uint32_t)(rel[i] & 0xffff) << 16);
+        }
+        live |= (unsigned)lv << i;
+        miss |= (unsigned)ms << i;
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n) { // uniform
+        int done = 0;
+        for (; n - done >= 256; done += 256) { // long list: a lane per entry
+            const uint32_t en = s_list[done + threadIdx.x];
+            const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
+            const int ex = d.own.XL + 1 + blockIdx.x * 256 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
+            double p, q;
+            refine_data_term_packed(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, p, q);
+            s_res[slot][0] = p;
+            s_res[slot][1] = q;
+        }
+        for (int e0 = done; e0 < n; e0 += 64) { // short list: four lanes per entry
+            const int e = e0 + ((int)threadIdx.x >> 2);
+            const bool ok = e < n;
+            const uint32_t en = s_list[ok ? e : e0];
+            const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
+            const int ex = d.own.XL + 1 + blockIdx.x * 256 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
+            double p, q;
+            refine_data_term_quad(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, threadIdx.x & 3, p, q);
+            if (ok && (threadIdx.x & 3) == 0) {
+                s_res[slot][0] = p;
+                s_res[slot][1] = q;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < RF_PPT; i++) {
+        if (!((live >> i) & 1u)) continue;
+        const size_t pix = (size_t)(y0 + i) * W + x;
+        if ((miss >> i) & 1u) {
+            pwp[i] = s_res[threadIdx.x * RF_PPT + i][0];
+            delta[i] = s_res[threadIdx.x * RF_PPT + i][1];
+            const size_t cpix = pix + (size_t)(rel[i] & 1) * a.rf_stride;
+            d.rf_key[cpix] = (int16_t)rel[i];
+            d.rf_pwp[cpix] = pwp[i];
+            d.rf_delta[cpix] = delta[i];
+        }
+        out[pix] = (mode[i] == 0) ? col[i + 1] /* .cpp:655 */
+                                  : refine_update(mode[i], col[i + 1], dE[i], dW[i], col[i], col[i + 2], pwp[i], delta[i], a.ws);
+    }
 }
 
 static void refine_extent(const StageArgs &a, int &rows, int &cols) {
@@ -458,7 +534,7 @@ void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hip
     if (rows <= 0 || cols <= 0) return;
     const dim3 grid((cols + 255) / 256, rows, a.ndir);
     if (refine_is_small(a)) { // small level: launch-latency bound
-        hipLaunchKernelGGL(k_refine_fused, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_refine_fused, dim3(grid.x, (grid.y + RF_PPT - 1) / RF_PPT, grid.z), dim3(256), 0, st, a);
         return;
     }
     if (a.flag2 == 0) { // first sweep: everything misses
