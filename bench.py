@@ -128,7 +128,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = v_total / (dt / args.steps) / 1e6
-        # ---- roofline of the dominant kernel: the top level's Jacobi sweep (k_refine_sweep<1>)
+        # ---- roofline of the dominant kernel: the top level's Jacobi sweep (k_refine_sweep<1>, one launch per sweep)
         # (hipEvents recorded by the library right around every 8th k_refine_sweep<1> launch, on its own stream)
         top = prof_acc["refine_light_top"]
         launches = max(1, top["launches"])

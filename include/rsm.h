@@ -104,9 +104,8 @@ int rsm_result_device(rsm_ctx *ctx, const double **disparity0, const double **di
  * buffers an RCCL gather sends from): up to max_points points, xyz fp64 x3 and/or bgr u8 x3. */
 int rsm_export_cloud_device(rsm_ctx *ctx, double *d_xyz, uint8_t *d_bgr, int64_t max_points);
 
-/* Tuning / validation knobs (results never change): "refine_fused_max" = pixel-thread count below which a
- * level's refine sweeps use the single fused kernel (default 1<<20; 0 forces the split light+worklist
- * kernels), "ncc_bytes" = 1 forces the generic byte-wise NCC kernel instead of the dot4 one. */
+/* Validation knob (results never change): "ncc_bytes" = 1 forces the generic byte-wise NCC kernel instead of the
+ * dot4 one. */
 int rsm_set_option(rsm_ctx *ctx, const char *name, long long value);
 
 /* ---- measurement ------------------------------------------------------------------------- */

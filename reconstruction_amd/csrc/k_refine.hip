@@ -30,7 +30,6 @@ __global__ void k_refine_init(StageArgs a) {
     const size_t n = (size_t)a.W * a.H;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    if (blockIdx.z == 0 && i < RF_COUNTERS) a.rf_cnt[i] = 0;
     for (; i < n; i += stride) {
         const double v = (double)d.d16_in[i]; // convertTo CV_64F, .cpp:585
         d.f64_a[i] = v;
@@ -44,7 +43,6 @@ void launch_refine_init(const StageArgs &a, hipStream_t st) {
     const size_t n = (size_t)a.W * a.H;
     size_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (blocks < (RF_COUNTERS + 255) / 256) blocks = (RF_COUNTERS + 255) / 256;
     hipLaunchKernelGGL(k_refine_init, dim3((unsigned)blocks, 1, a.ndir), dim3(256), 0, st, a);
 }
 
@@ -224,151 +222,6 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
     }
 }
 
-// Worklist bookkeeping: every direction has RF_NSHARD shards (a counter + a list region each; a single counter
-// serialises at ~88 appends/us) and two counter sets, used by alternate sweeps.
-__device__ __forceinline__ int32_t *rf_counter(const StageArgs &a, int dir, int sweep, int shard) {
-    return a.rf_cnt + ((dir * 2 + (sweep & 1)) * RF_NSHARD + shard);
-}
-// entries: pixel index | (iMatch - x) << 32 -- with the key in the entry the worklist pass can fetch the image
-// windows without first waiting for the pixel's state
-__device__ __forceinline__ uint64_t *rf_shard_list(const StageArgs &a, int dir, int shard) {
-    return (uint64_t *)a.rf_list + ((size_t)dir * RF_NSHARD + shard) * a.rf_cap;
-}
-
-// Light sweep: RF_PPT vertically adjacent pixels per thread, every load issued up front.  A pixel whose cached
-// data term belongs to another iMatch (cache miss) is appended to the sweep's worklist instead of being updated
-// here; refine_miss_body serves it before the direction's next sweep starts.
-// The cache holds two entries per pixel, indexed by the parity of iMatch - x: the iteration settles into flipping
-// between two ADJACENT iMatch values, so both stay resident (0.74 % misses per sweep on C2's top level).
-__device__ __forceinline__ void refine_light_body(const StageArgs &a, int dir, int sweep, int bx, int by, int lin_block) {
-    const DirArgs &d = a.d[dir];
-    const int x = d.own.XL + 1 + bx * 256 + (int)threadIdx.x;
-    const int y0 = d.own.YL + 1 + by * RF_PPT;
-    const int W = a.W;
-    const bool colok = x <= d.own.XR - 1;
-    const int xs = colok ? x : d.own.XL + 1; // out-of-range lanes shadow a valid column (no stores)
-    const double *__restrict__ in = d.f64_a;
-    double *__restrict__ out = d.f64_b;
-    const int ylast = d.own.YR - 1;
-    if (y0 > ylast) return; // uniform (the other direction may have more rows)
-    // phase 1: every state load of the RF_PPT pixels
-    double col[RF_PPT + 2], dE[RF_PPT], dW[RF_PPT];
-#pragma unroll
-    for (int i = 0; i < RF_PPT + 2; i++) {
-        const int yy = min(y0 - 1 + i, ylast + 1);
-        col[i] = in[(size_t)yy * W + xs];
-    }
-#pragma unroll
-    for (int i = 0; i < RF_PPT; i++) {
-        const int yy = min(y0 + i, ylast);
-        dE[i] = in[(size_t)yy * W + xs + 1];
-        dW[i] = in[(size_t)yy * W + xs - 1];
-    }
-    // phase 2: the cache entry each pixel needs
-    int key[RF_PPT], ckey[RF_PPT];
-    double pwp[RF_PPT], delta[RF_PPT];
-    size_t pix[RF_PPT];
-#pragma unroll
-    for (int i = 0; i < RF_PPT; i++) {
-        const int yy = min(y0 + i, ylast);
-        pix[i] = (size_t)yy * W + xs;
-        key[i] = (int)(col[i + 1] - 1.5) + xs; // .cpp:625
-        const size_t cpix = pix[i] + (size_t)((key[i] - xs) & 1) * a.rf_stride;
-        ckey[i] = (int)d.rf_key[cpix] + xs; // stored relative to the column (int16)
-        pwp[i] = d.rf_pwp[cpix];
-        delta[i] = d.rf_delta[cpix];
-    }
-    const int lane = threadIdx.x & 63;
-    const int shard = lin_block & (RF_NSHARD - 1);
-    int32_t *cnt = rf_counter(a, dir, sweep, shard);
-    uint64_t *list = rf_shard_list(a, dir, shard);
-#pragma unroll
-    for (int i = 0; i < RF_PPT; i++) {
-        const double dC = col[i + 1], dN = col[i], dS = col[i + 2];
-        const bool live = colok && (y0 + i <= ylast) && dC != (double)NOMATCH; // .cpp:613
-        const int mode = (int)(dE[i] != (double)NOMATCH && dW[i] != (double)NOMATCH) +
-                         (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
-        const bool miss = live && mode != 0 && ckey[i] != key[i];
-        // wave-aggregated append of the missing pixels to this sweep's (sharded) worklist
-        const unsigned long long mm = __ballot(miss);
-        if (mm) {
-            const int leader = __builtin_ctzll(mm);
-            int base = 0;
-            if (lane == leader) base = atomicAdd(cnt, __popcll(mm));
-            base = __shfl(base, leader);
-            if (miss)
-                list[base + __popcll(mm & ((1ull << lane) - 1ull))] =
-                    (uint64_t)(uint32_t)pix[i] | ((uint64_t)(uint32_t)(key[i] - xs) << 32);
-        }
-        if (live && !miss)
-            out[pix[i]] = (mode == 0) ? dC /* .cpp:655 */ : refine_update(mode, dC, dE[i], dW[i], dN, dS, pwp[i], delta[i], a.ws);
-    }
-}
-
-// Serves one shard of a sweep's worklist: four lanes per entry (refine_data_term_quad) -- the work is one
-// dependent chain per entry, so a shorter chain matters more than lane utilisation.
-__device__ __forceinline__ void refine_miss_body(const StageArgs &a, int dir, int sweep, int shard) {
-    const int W = a.W, H = a.H;
-    const DirArgs &d = a.d[dir];
-    const uint64_t *list = rf_shard_list(a, dir, shard);
-    const int q = threadIdx.x & 3, e_first = (int)threadIdx.x >> 2;
-    // the first round's entries are fetched together with the count (stale slots are harmless): the pass is a
-    // chain of dependent memory round trips, not work
-    uint64_t ent = list[e_first];
-    const int count = *rf_counter(a, dir, sweep, shard);
-    if (threadIdx.x == 0) *rf_counter(a, dir, sweep + 1, shard) = 0; // the next sweep's counter set (idle now)
-    const double *__restrict__ in = d.f64_a;
-    int done = 0;
-    // long lists (the first sweeps of a level, before the iteration has settled): one lane per entry, all busy
-    for (; count - done >= 256; done += 256) { // uniform
-        const uint64_t en = list[done + (int)threadIdx.x];
-        const size_t pix = (uint32_t)en;
-        const int rel = (int)(en >> 32);
-        const int y = (int)(pix / W), x = (int)(pix % W);
-        const double dC = in[pix];
-        const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
-        double pwp, delta;
-        refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, rel + x, pwp, delta);
-        const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
-                         (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
-        const size_t cpix = pix + (size_t)(rel & 1) * a.rf_stride;
-        d.rf_key[cpix] = (int16_t)rel;
-        d.rf_pwp[cpix] = pwp;
-        d.rf_delta[cpix] = delta;
-        d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
-    }
-    for (int e0 = done; e0 < count; e0 += 64) { // uniform
-        const int e = e0 + e_first;
-        const bool live = e < count;
-        if (e0 > 0) ent = list[live ? e : e0]; // (round 0 was fetched with the count)
-        // idle lanes of the last round shadow a pixel that is certainly inside the image (no stores)
-        const size_t pix = live ? (size_t)(uint32_t)ent : (size_t)(d.own.YL + 1) * W + d.own.XL + 1;
-        const int rel = live ? (int)(ent >> 32) : 0;
-        const int y = (int)(pix / W), x = (int)(pix % W);
-        const double dC = in[pix];
-        const double dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
-        double pwp, delta;
-        refine_data_term_quad(d.img4_own, d.img4_oth, W, H, x, y, rel + x, q, pwp, delta);
-        if (live && q == 0) {
-            const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
-                             (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2;
-            const size_t cpix = pix + (size_t)(rel & 1) * a.rf_stride;
-            d.rf_key[cpix] = (int16_t)rel;
-            d.rf_pwp[cpix] = pwp;
-            d.rf_delta[cpix] = delta;
-            d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
-        }
-    }
-}
-
-// Per-sweep kernels (one direction, or both at once through gridDim.z): light sweep, then its worklist.
-// TOP only gives the top level's launches (the dominant kernel) their own name in rocprof traces.
-template <int TOP>
-__global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
-    refine_light_body(a, blockIdx.z, a.flag2, blockIdx.x, blockIdx.y, blockIdx.x + blockIdx.y * gridDim.x);
-}
-__global__ __launch_bounds__(256) void k_refine_worklist(StageArgs a) { refine_miss_body(a, blockIdx.z, a.flag2, blockIdx.x); }
-
 // First sweep of a level: every cache entry is empty, so instead of a worklist the kernel walks the whole
 // interior (and also does the mode 0 copy-through).
 __global__ __launch_bounds__(256) void k_refine_first(StageArgs a) {
@@ -398,11 +251,17 @@ __global__ __launch_bounds__(256) void k_refine_first(StageArgs a) {
     d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
 }
 
-// Small levels are launch-latency bound: one kernel per sweep.  Misses are served inside the workgroup: they are
-// compacted through an LDS list and served by quads (or a lane each when the list is long, as in a level's first
-// sweeps); serving them in place would run the data-term routine in every second wave for one or two lanes.
+// One Jacobi sweep f64_a -> f64_b: RF_PPT vertically adjacent pixels per thread, every load issued up front.
+// The data term (pwp, delta) of a pixel is cached, two entries per pixel indexed by the parity of iMatch - x: the
+// iteration settles into flipping between two ADJACENT iMatch values, so both stay resident (0.74 % misses per
+// sweep on C2's top level once settled, up to 70 % in a level's first sweeps).  A pixel whose entry belongs to
+// another iMatch is a miss.  Misses are served inside the workgroup: compacted through an LDS list and computed
+// four lanes per entry (a lane each when the list is long); computing them in place would run the data-term
+// routine in every second wave for one or two lanes.
+// TOP only gives the top level's launches (the dominant kernel) their own name in rocprof traces.
 #define RFU_CAP (256 * RF_PPT) // every pixel of the workgroup may miss
-__global__ __launch_bounds__(256) void k_refine_fused(StageArgs a) {
+template <int TOP>
+__global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     __shared__ uint32_t s_list[RFU_CAP]; // slot of the owner (thread * RF_PPT + i) | (iMatch - x) << 16
     __shared__ double s_res[RFU_CAP][2];
     __shared__ int s_n;
@@ -507,46 +366,22 @@ __global__ __launch_bounds__(256) void k_refine_fused(StageArgs a) {
     }
 }
 
-static void refine_extent(const StageArgs &a, int &rows, int &cols) {
-    rows = cols = 0;
+// One sweep f64_a -> f64_b (a.flag2 = sweep index, a.flag = top level); ev0 / ev1 (optional) bracket the launch.
+void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    int rows = 0, cols = 0;
     for (int v = 0; v < a.ndir; v++) {
         rows = max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
         cols = max(cols, a.d[v].own.XR - a.d[v].own.XL - 1);
     }
-}
-
-// worklist shard capacity: every light workgroup of a shard could append all its pixels
-static int refine_shard_cap(int gx, int gyL) {
-    const long long lblocks = (long long)gx * gyL;
-    return (int)(((lblocks + RF_NSHARD - 1) / RF_NSHARD) * 256 * RF_PPT);
-}
-
-bool refine_is_small(const StageArgs &a) {
-    int rows, cols;
-    refine_extent(a, rows, cols);
-    return (long long)((cols + 255) / 256) * rows * a.ndir * 256 < a.opt_refine_fused_max;
-}
-
-// One sweep f64_a -> f64_b (a.flag2 = sweep index) with per-sweep launches.
-void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    int rows, cols;
-    refine_extent(a, rows, cols);
     if (rows <= 0 || cols <= 0) return;
     const dim3 grid((cols + 255) / 256, rows, a.ndir);
-    if (refine_is_small(a)) { // small level: launch-latency bound
-        hipLaunchKernelGGL(k_refine_fused, dim3(grid.x, (grid.y + RF_PPT - 1) / RF_PPT, grid.z), dim3(256), 0, st, a);
-        return;
-    }
-    if (a.flag2 == 0) { // first sweep: everything misses
-        hipLaunchKernelGGL(k_refine_first, grid, dim3(256), 0, st, a);
-        return;
-    }
-    const dim3 lgrid(grid.x, (grid.y + RF_PPT - 1) / RF_PPT, grid.z);
-    StageArgs b = a;
-    b.rf_cap = refine_shard_cap(lgrid.x, lgrid.y);
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (a.flag) hipLaunchKernelGGL(k_refine_sweep<1>, lgrid, dim3(256), 0, st, b);
-    else hipLaunchKernelGGL(k_refine_sweep<0>, lgrid, dim3(256), 0, st, b);
+    if (a.flag2 == 0) { // first sweep: every pixel needs its data term
+        hipLaunchKernelGGL(k_refine_first, grid, dim3(256), 0, st, a);
+    } else {
+        const dim3 sgrid(grid.x, (grid.y + RF_PPT - 1) / RF_PPT, grid.z);
+        if (a.flag) hipLaunchKernelGGL(k_refine_sweep<1>, sgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_refine_sweep<0>, sgrid, dim3(256), 0, st, a);
+    }
     if (ev1) (void)hipEventRecord(ev1, st);
-    hipLaunchKernelGGL(k_refine_worklist, dim3(RF_NSHARD, 1, a.ndir), dim3(256), 0, st, b);
 }

@@ -70,7 +70,7 @@ struct rsm_ctx {
     double *f64[3][2]{};
     int32_t *nv[2]{};
     int16_t *rf_key[2]{};
-    int32_t *rf_cnt = nullptr;
+    int32_t *rf_cnt = nullptr; // NCC wide-pixel counter
     uint32_t *rf_list = nullptr;
     double *rf_pwp[2]{}, *rf_delta[2]{};
     int32_t *prefix = nullptr;
@@ -90,7 +90,6 @@ struct rsm_ctx {
     int64_t v_top = 0;
 
     // options (rsm_set_option)
-    long long opt_refine_fused_max = 1ll << 20;
     int opt_ncc_bytes = 0;
 
     // profiling
@@ -248,8 +247,8 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         DALLOC(c, c->rf_pwp[v], 2 * px);
         DALLOC(c, c->rf_delta[v], 2 * px);
     }
-    DALLOC(c, c->rf_cnt, RF_COUNTERS + 16);
-    DALLOC(c, c->rf_list, 2 * RF_LIST_ENTRIES(in->width, in->height, 2));
+    DALLOC(c, c->rf_cnt, 16);
+    DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->d_j1, 4096);
     DALLOC(c, c->d_j2, 4096);
@@ -341,8 +340,7 @@ static void prof_end(rsm_ctx *c, int slot, int stage, int launches, double bytes
 
 extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
-    if (!strcmp(name, "refine_fused_max")) c->opt_refine_fused_max = value;
-    else if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
+    if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
     return RSM_OK;
 }
@@ -375,11 +373,9 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.r = c->in.radius;
     a.offset = c->in.offset;
     a.ws = c->in.ws;
-    a.rf_cnt = c->rf_cnt;
     a.rf_list = c->rf_list;
-    a.ncc_cnt = c->rf_cnt + RF_COUNTERS;
+    a.ncc_cnt = c->rf_cnt;
     a.rf_stride = c->cap_px;
-    a.opt_refine_fused_max = c->opt_refine_fused_max;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
     for (int v = 0; v < 2; v++) {
         DirArgs &d = a.d[v];
@@ -555,7 +551,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
                 a.d[v].f64_b = c->f64[nxt][v];
             }
             a.flag2 = it;
-            if (c->profile && k == N - 1 && (it & 7) == 4 && !refine_is_small(a)) { // every 8th launch of the dominant kernel
+            if (c->profile && k == N - 1 && (it & 7) == 4) { // every 8th launch of the dominant kernel
                 const int es = prof_slot(c, ST_REFINE_LIGHT_TOP);
                 launch_refine_sweep(a, st, c->evpool[es].a, c->evpool[es].b);
                 c->prof_launches[ST_REFINE_LIGHT_TOP] += 1;
@@ -567,7 +563,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             cur = nxt;
             nxt = t;
         }
-        prof_end(c, ps12, st_sweep, iters, 32.0 * Pk * iters); // launches = sweeps (each = light kernel + worklist kernel)
+        prof_end(c, ps12, st_sweep, iters, 32.0 * Pk * iters); // one launch per sweep
 
         // ---- UniquenessContraint<double> (.cpp:109) on the refined maps (now in f64[cur])
         const int ps13 = prof_begin(c, ST_UNIQ64);
@@ -785,7 +781,6 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
 }
 StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, const rsm_boundary *oth) {
     StageArgs a{};
-    a.opt_refine_fused_max = c->opt_refine_fused_max;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
     a.ndir = 1;
     a.W = W;
@@ -974,8 +969,6 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.rf_pwp = t.alloc<double>(2 * px);
     d.rf_delta = t.alloc<double>(2 * px);
     a.rf_stride = px;
-    a.rf_cnt = t.alloc<int32_t>(RF_COUNTERS);
-    a.rf_list = t.alloc<uint32_t>(2 * RF_LIST_ENTRIES(W, H, 1));
     if (!t.ok) return finish(c, t);
     if (iterations > RF_MAX_SWEEPS) return set_err(c, RSM_E_INVALID, "iterations");
     d.f64_a = A;

@@ -9,14 +9,9 @@
 #define WAVE 64
 #define RF_MAX_SWEEPS 1024
 #define RF_NOKEY ((int16_t)-32768)
-#define RF_NSHARD 512 // refine worklist shards per direction (power of 2) = workgroups of a worklist pass
-#define RF_SUB 1      // worklist blocks per shard
-#define RF_PPT 4      // pixels per thread of the light sweep kernel
-// worklist capacity (8-byte entries) for ndir directions of a WxH level
-#define RF_LIST_ENTRIES(W, H, ndir) ((size_t)(ndir) * (((size_t)(W) + 256) * ((size_t)(H) + RF_PPT) + (size_t)RF_NSHARD * 256 * RF_PPT))
-#define RF_COUNTERS (4 * RF_NSHARD) // [direction][sweep parity][shard]
+#define RF_PPT 4      // pixels per thread of the refine sweep kernel
 #define SBV_S 32 // SetBoundary: row segments per column of the vertical sweeps
-// int32 scratch of launch_set_boundary (carved from rf_list), per direction
+// int32 scratch of launch_set_boundary (in rf_list), per direction
 #define SETB_SCRATCH(W) ((size_t)(SBV_S * 6 + 2) * (size_t)(W))
 
 // Margin of one view at one level (struct Boundary, CManageData.h:10-14, without width/height).
@@ -52,12 +47,9 @@ struct StageArgs {
     double ws;   // m_ws
     int flag;    // stage-specific
     int flag2;   // refine: sweep index
-    int rf_cap;        // refine: worklist entries per shard
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
-    long long opt_refine_fused_max; // refine: levels with fewer pixel-threads use the fused kernel
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
-    int32_t *rf_cnt;   // refine: worklist counters [RF_COUNTERS]
-    uint32_t *rf_list; // refine: per direction and shard, 8-byte entries (pixel | key << 32); NCC: (dir << 31 | pixel index)
+    uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
     int32_t *ncc_cnt;  // NCC: number of wide pixels in rf_list
 };
 
@@ -87,7 +79,6 @@ void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-bool refine_is_small(const StageArgs &a);
 
 // cloud: returns nothing; *d_npoints (device int64) receives the point count; `flags` = W*H + CLOUD_BLOCKS(W,H) bytes
 #define CLOUD_BLOCKS(W, H) ((size_t)(((W) + 31) / 32) * (size_t)(((H) + 31) / 32))

@@ -129,11 +129,9 @@ def test_integer_stages_bit_exact(ctx, name):
     assert not fails, "\n".join(fails[:12])
 
 
-@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("name", list(CASES))
-def test_fp64_stages(ctx, name, split):
+def test_fp64_stages(ctx, name):
     cfg, rec, fin = stages(name)
-    ctx.set_option("refine_fused_max", 0 if split else 1 << 20)
     imgs, msks = fin["imgs"], fin["msks"]
     worst = 0.0
     for q in rec:
@@ -147,7 +145,6 @@ def test_fp64_stages(ctx, name, split):
             g0, g1 = ctx.uniqueness(q["inp"][0], q["inp"][1], mg[0], mg[1])
             assert np.array_equal(g0, q["out"][0]), diff_report("uniq64 d0 L%d" % k, g0, q["out"][0])
             assert np.array_equal(g1, q["out"][1]), diff_report("uniq64 d1 L%d" % k, g1, q["out"][1])
-    ctx.set_option("refine_fused_max", 1 << 20)
     print("worst refine rel err", worst)
 
 
@@ -268,18 +265,15 @@ def test_order_constraint_heavy_crossings(ctx):
     assert np.array_equal(a, b), diff_report("order heavy", a, b)
 
 
-@pytest.mark.parametrize("opt", [("refine_fused_max", 1 << 40), ("ncc_bytes", 1)])
+@pytest.mark.parametrize("opt", [("ncc_bytes", 1)])
 def test_kernel_variants_give_identical_results(ctx, opt):
-    """The split (light + worklist) and fused refine kernels, and the dot4 / byte-wise NCC kernels, are
-    interchangeable bit for bit."""
+    """The dot4 and the generic byte-wise NCC kernels are interchangeable bit for bit."""
     cfg = synth.config_small(**CASES["s320x160_occluded_neg_r4"])
-    ctx.set_option("refine_fused_max", 0)   # base = split light + worklist kernels on every level
     base = ctx.match_pair(cfg)
     ctx.set_option(*opt)
     try:
         alt = ctx.match_pair(cfg)
     finally:
-        ctx.set_option("refine_fused_max", 1 << 20)
         ctx.set_option("ncc_bytes", 0)
     for v in range(2):
         assert np.array_equal(base.disparity[v], alt.disparity[v]), opt
