@@ -324,27 +324,34 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     __syncthreads();
     const int n = s_n;
     if (n) { // uniform
-        int done = 0;
-        for (; n - done >= 256; done += 256) { // long list: a lane per entry
-            const uint32_t en = s_list[done + threadIdx.x];
-            const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
-            const int ex = d.own.XL + 1 + blockIdx.x * 256 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
-            double p, q;
-            refine_data_term_packed(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, p, q);
-            s_res[slot][0] = p;
-            s_res[slot][1] = q;
-        }
-        for (int e0 = done; e0 < n; e0 += 64) { // short list: four lanes per entry
-            const int e = e0 + ((int)threadIdx.x >> 2);
-            const bool ok = e < n;
-            const uint32_t en = s_list[ok ? e : e0];
-            const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
-            const int ex = d.own.XL + 1 + blockIdx.x * 256 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
-            double p, q;
-            refine_data_term_quad(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, threadIdx.x & 3, p, q);
-            if (ok && (threadIdx.x & 3) == 0) {
-                s_res[slot][0] = p;
-                s_res[slot][1] = q;
+        for (int done = 0; done < n;) { // uniform
+            if (n - done > 64) { // a lane per entry: one round serves up to 256 with 1/3 of the quads' instructions
+                const int e = done + (int)threadIdx.x;
+                if (e < n) {
+                    const uint32_t en = s_list[e];
+                    const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
+                    const int ex = d.own.XL + 1 + blockIdx.x * 256 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
+                    double p, q;
+                    refine_data_term_packed(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, p, q);
+                    s_res[slot][0] = p;
+                    s_res[slot][1] = q;
+                }
+                done += 256;
+            } else { // four lanes per entry: a third of the latency, which is what a handful of misses costs
+                const int e = done + ((int)threadIdx.x >> 2);
+                if (done + (((int)threadIdx.x >> 6) << 4) < n) { // wave-uniform: this wave's 16 quads reach the list
+                    const bool ok = e < n;
+                    const uint32_t en = s_list[ok ? e : done];
+                    const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
+                    const int ex = d.own.XL + 1 + blockIdx.x * 256 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
+                    double p, q;
+                    refine_data_term_quad(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, threadIdx.x & 3, p, q);
+                    if (ok && (threadIdx.x & 3) == 0) {
+                        s_res[slot][0] = p;
+                        s_res[slot][1] = q;
+                    }
+                }
+                done += 64;
             }
         }
         __syncthreads();
