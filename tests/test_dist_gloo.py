@@ -81,3 +81,47 @@ def test_single_process_gather_is_identity():
            (1, torch.ones(1, 3, dtype=torch.float64), torch.ones(1, 3, dtype=torch.uint8))]
     out = gather_clouds(loc)
     assert [p for p, _, _ in out] == [1, 3]
+
+
+def _worker_async(rank, world, port, rounds, q):
+    """bench.py's pattern: the gather of round i is left in flight while round i + 1 is prepared."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from reconstruction_amd.dist import gather_clouds_async
+    got, pending = [], None
+    for i in range(rounds):
+        pair = i * world + rank
+        xyz, bgr = _cloud(pair)
+        h = gather_clouds_async([(pair, torch.from_numpy(xyz), torch.from_numpy(bgr))], dst=0)
+        if pending is not None:
+            got.append(pending.wait())
+        pending = h
+    got.append(pending.wait())
+    if rank == 0:
+        q.put([[(pid, x.numpy().copy(), b.numpy().copy()) for pid, x, b in res] for res in got])
+    else:
+        assert all(r is None for r in got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gathers_stay_in_order():
+    world, rounds = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async, args=(r, world, port, rounds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res) == rounds
+    for i, rnd in enumerate(res):
+        assert [pid for pid, _, _ in rnd] == [i * world + r for r in range(world)]
+        for pid, xyz, bgr in rnd:
+            ex, eb = _cloud(pid)
+            assert np.array_equal(xyz, ex) and np.array_equal(bgr, eb)
