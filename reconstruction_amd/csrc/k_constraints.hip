@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64) void k_setb_vert(StageArgs a) {
 //     u[x] = max(bl[x], XL1 - x - 3), u'[x] = min(br[x], XR1 - x) at pixels that have a link from x + 1.
 // One wave per row walks it in 64-column chunks with a segmented wave scan (6 shuffle steps) and a carry.
 // All values stay within +-(10000 + W), so the reference's int16 stores never wrap and the scan is exact.
-__global__ __launch_bounds__(256) void k_setb_horiz(StageArgs a) {
+__global__ __launch_bounds__(256) void k_setb_horiz(StageArgs a, int emit_list) {
     const DirArgs &d = a.d[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int y = d.own.YL + blockIdx.x * 4 + ((int)threadIdx.x >> 6);
@@ -638,6 +638,7 @@ __global__ __launch_bounds__(256) void k_setb_horiz(StageArgs a) {
     for (int k = nchunk - 1; k >= 0; k--) {
         const int x = XL + k * 64 + lane;
         const bool in = x <= XR;
+        bool emit = false;
         const int m = in ? (int)mk[x] : 0;
         const bool link = in && x < XR && mk[x + 1] == 255; // the pixel receives from x + 1
         int tl = in ? (int)bl[x] : 0, tr = in ? (int)br[x] : 0;
@@ -680,11 +681,25 @@ __global__ __launch_bounds__(256) void k_setb_horiz(StageArgs a) {
             }
             bl[x] = (int16_t)A;
             br[x] = (int16_t)B;
+            // Rematch evaluates NCC only where the pixel is masked, still unmatched (.cpp:538) and its interval is
+            // not empty after the window clamp: about 1 % of a level.  Those go to a worklist for k_ncc_sparse.
+            emit = emit_list && m == 255 && (int)d.d16_in[(size_t)y * W + x] == NOMATCH &&
+                   max(A, a.r) <= min(B, W - 1 - a.r);
+        }
+        if (emit_list) { // uniform
+            const unsigned long long mm = __ballot(emit);
+            if (mm) {
+                const int leader = __builtin_ctzll(mm);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(a.ncc_cnt, __popcll(mm));
+                base = __shfl(base, leader);
+                if (emit) a.rf_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)((size_t)y * W + x) | ((uint32_t)blockIdx.z << 31);
+            }
         }
     }
 }
 
-void launch_set_boundary(const StageArgs &a, hipStream_t st) {
+void launch_set_boundary(const StageArgs &a, hipStream_t st, bool emit_list) {
     int rows = 0, cols = 0;
     for (int v = 0; v < a.ndir; v++) {
         rows = max(rows, a.d[v].own.YR - a.d[v].own.YL + 1);
@@ -696,7 +711,9 @@ void launch_set_boundary(const StageArgs &a, hipStream_t st) {
     hipLaunchKernelGGL((k_setb_vert<0, 1>), vgrid, dim3(64), 0, st, a);
     hipLaunchKernelGGL((k_setb_vert<1, 0>), vgrid, dim3(64), 0, st, a);
     hipLaunchKernelGGL((k_setb_vert<1, 1>), vgrid, dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_setb_horiz, dim3((rows + 3) / 4, 1, a.ndir), dim3(256), 0, st, a);
+    // (the vertical sweeps are done with their scratch in rf_list: the horizontal kernel may refill it)
+    if (emit_list) (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_setb_horiz, dim3((rows + 3) / 4, 1, a.ndir), dim3(256), 0, st, a, emit_list ? 1 : 0);
 }
 
 // ---------------------------------------------------------------- MedianFilter (1 iteration)

@@ -499,10 +499,67 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
     }
 }
 
+// Rematch (mode 2): the worklist of launch_set_boundary holds the ~1 % of the pixels that are evaluated at all, a
+// few candidates each.  One lane per pixel, windows straight from the BGRX images (L1 / L2 resident rows): staging
+// rows in LDS per 256-pixel workgroup, as k_ncc_dot4 does, would be paid by nearly every workgroup for one or two
+// active lanes.
+template <int R>
+__global__ __launch_bounds__(256) void k_ncc_sparse(StageArgs a) {
+    constexpr int WS = 2 * R + 1, G = NCC_G, NB = G + WS - 1;
+    constexpr int n = WS * WS * 3;
+    const int count = *a.ncc_cnt;
+    const int W = a.W;
+    for (int item = blockIdx.x * 256 + threadIdx.x; item < count; item += gridDim.x * 256) {
+        const uint32_t ent = a.rf_list[item];
+        const DirArgs &d = a.d[ent >> 31];
+        const size_t pix = ent & 0x7fffffffu;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        const int L = max((int)d.BL[pix], R), Rr = min((int)d.BR[pix], W - 1 - R);
+        const int Sa = d.S1_own[pix];
+        const long long va = (long long)n * d.S2_own[pix] - (long long)Sa * Sa;
+        double bv = -1.0;
+        int bc = -1;
+        for (int c0 = L; c0 <= Rr; c0 += G) {
+            uint32_t acc[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) acc[g] = 0u;
+#pragma unroll 1
+            for (int j = 0; j < WS; j++) {
+                const uint32_t *arow = d.img4_own + (size_t)(y - R + j) * W + x - R;
+                const uint32_t *brow = d.img4_oth + (size_t)(y - R + j) * W;
+                uint32_t av[WS], bw[NB];
+#pragma unroll
+                for (int m = 0; m < WS; m++) av[m] = arow[m];
+#pragma unroll
+                for (int t = 0; t < NB; t++) bw[t] = brow[min(c0 - R + t, W - 1)]; // clamped columns belong to c > Rr only
+#pragma unroll
+                for (int m = 0; m < WS; m++)
+#pragma unroll
+                    for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_udot4(av[m], bw[g + m], acc[g], false);
+            }
+            uint8_t mk[G];
+            int32_t s1[G], s2[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const size_t o = (size_t)y * W + min(c0 + g, Rr);
+                mk[g] = d.mask_oth[o];
+                s1[g] = d.S1_oth[o];
+                s2[g] = d.S2_oth[o];
+            }
+            ncc_score_group<R>(acc, c0, Rr, mk, s1, s2, Sa, va, bv, bc);
+        }
+        if (bc != -1) d.d16_out[pix] = (int16_t)(bc - x); // .cpp:563-564
+    }
+}
+
 template <int R>
 static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st) {
     constexpr int WS = 2 * R + 1, SA = NCC_TX + 2 * R, SB = NCC_CH + 2 * R + NCC_G + 3;
     const size_t lds = 16 + (size_t)WS * (SA + SB) * 4 + (size_t)(NCC_CH + NCC_G) * 9 + 16;
+    if (mode == 2) { // the worklist was filled by launch_set_boundary
+        hipLaunchKernelGGL(k_ncc_sparse<R>, dim3(2048), dim3(256), 0, st, a);
+        return;
+    }
     (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), st);
     hipLaunchKernelGGL(k_ncc_dot4<R>, grid, dim3(NCC_TX), lds, st, a, mode);
     const size_t ldsw = (size_t)WS * (NCC_TX * NCC_G + 2 * R + NCC_G) * 4;

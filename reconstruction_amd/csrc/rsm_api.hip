@@ -505,7 +505,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
 
         // ---- Rematch (.cpp:80-81): SetBoundary_smooth + NCC on still-unmatched pixels, in place
         const int ps8 = prof_begin(c, ST_REMATCH);
-        launch_set_boundary(a, st);
+        launch_set_boundary(a, st, true);
         launch_ncc_argmax(a, 2, st);
         prof_end(c, ps8, ST_REMATCH, 3, 46.0 * Pk);
 
@@ -930,7 +930,7 @@ extern "C" int rsm_stage_rematch(rsm_ctx *c, const uint8_t *img_own, const uint8
     a.d[0].BL = t.alloc<int16_t>(px);
     a.d[0].BR = t.alloc<int16_t>(px);
     if (!t.ok) return finish(c, t);
-    launch_set_boundary(a, c->stream);
+    launch_set_boundary(a, c->stream, true);
     launch_ncc_argmax(a, 2, c->stream);
     t.down(disp, a.d[0].d16_in, px);
     return finish(c, t);

@@ -67,14 +67,15 @@ void launch_box_sums(const uint32_t *img4, int W, int H, int r, int32_t *tmp1, i
 void launch_next_valid(const double *parent, int Wp, int Hp, int32_t *nv, hipStream_t st);
 void launch_hl_interval(const StageArgs &a, hipStream_t st);
 // mode 0: lowest level (interval = other margin), 1: interval arrays BL/BR into NOMATCH-filled out,
-// 2: rematch (only pixels whose d16_in is NOMATCH; in place)
+// 2: rematch (only pixels whose d16_in is NOMATCH; in place; the pixels come from launch_set_boundary(.., true))
 void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st);
 
 void launch_smooth(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out
 void launch_order(const StageArgs &a, hipStream_t st);         // d16_in in place
 void launch_uniq_s16(int16_t *p, const int16_t *q, int W, int H, Mg own, Mg oth, hipStream_t st);
 void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, hipStream_t st);
-void launch_set_boundary(const StageArgs &a, hipStream_t st);  // d16_in, mask_own -> BL, BR
+// d16_in, mask_own -> BL, BR; emit_list: also fill rf_list / ncc_cnt with the pixels Rematch has to evaluate
+void launch_set_boundary(const StageArgs &a, hipStream_t st, bool emit_list = false);
 void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out (pre-filled NOMATCH)
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
