@@ -635,6 +635,8 @@ __global__ __launch_bounds__(256) void k_setb_horiz(StageArgs a, int emit_list) 
         carryR = __shfl(VR, 63);
     }
     // ---- right -> left (each lane re-reads the columns it wrote itself above)
+    uint32_t *rowlist = a.rf_list + ((size_t)blockIdx.z * a.H + y) * W; // emit_list: this row's Rematch pixels
+    int nemit = 0;
     for (int k = nchunk - 1; k >= 0; k--) {
         const int x = XL + k * 64 + lane;
         const bool in = x <= XR;
@@ -682,21 +684,17 @@ __global__ __launch_bounds__(256) void k_setb_horiz(StageArgs a, int emit_list) 
             bl[x] = (int16_t)A;
             br[x] = (int16_t)B;
             // Rematch evaluates NCC only where the pixel is masked, still unmatched (.cpp:538) and its interval is
-            // not empty after the window clamp: about 1 % of a level.  Those go to a worklist for k_ncc_sparse.
+            // not empty after the window clamp: about 1 % of a level.  Those go to per-row lists for k_ncc_sparse.
             emit = emit_list && m == 255 && (int)d.d16_in[(size_t)y * W + x] == NOMATCH &&
                    max(A, a.r) <= min(B, W - 1 - a.r);
         }
-        if (emit_list) { // uniform
+        if (emit_list) { // uniform: the row's own list, no atomics (a shared counter would see ~30 appends per row)
             const unsigned long long mm = __ballot(emit);
-            if (mm) {
-                const int leader = __builtin_ctzll(mm);
-                int base = 0;
-                if (lane == leader) base = atomicAdd(a.ncc_cnt, __popcll(mm));
-                base = __shfl(base, leader);
-                if (emit) a.rf_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)((size_t)y * W + x) | ((uint32_t)blockIdx.z << 31);
-            }
+            if (emit) rowlist[nemit + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)((size_t)y * W + x);
+            nemit += __popcll(mm);
         }
     }
+    if (emit_list && lane == 0) a.ncc_cnt[16 + blockIdx.z * a.H + y] = nemit;
 }
 
 void launch_set_boundary(const StageArgs &a, hipStream_t st, bool emit_list) {
@@ -712,7 +710,7 @@ void launch_set_boundary(const StageArgs &a, hipStream_t st, bool emit_list) {
     hipLaunchKernelGGL((k_setb_vert<1, 0>), vgrid, dim3(64), 0, st, a);
     hipLaunchKernelGGL((k_setb_vert<1, 1>), vgrid, dim3(64), 0, st, a);
     // (the vertical sweeps are done with their scratch in rf_list: the horizontal kernel may refill it)
-    if (emit_list) (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), st);
+    if (emit_list) (void)hipMemsetAsync(a.ncc_cnt + 16, 0, sizeof(int) * 2 * a.H, st); // rows outside a margin stay empty
     hipLaunchKernelGGL(k_setb_horiz, dim3((rows + 3) / 4, 1, a.ndir), dim3(256), 0, st, a, emit_list ? 1 : 0);
 }
 

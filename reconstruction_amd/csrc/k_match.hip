@@ -499,20 +499,21 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
     }
 }
 
-// Rematch (mode 2): the worklist of launch_set_boundary holds the ~1 % of the pixels that are evaluated at all, a
-// few candidates each.  One lane per pixel, windows straight from the BGRX images (L1 / L2 resident rows): staging
+// Rematch (mode 2): the per-row lists of launch_set_boundary hold the ~1 % of the pixels that are evaluated at all,
+// a few candidates each.  One wave per row list, one lane per pixel, windows straight from the BGRX images (L1 / L2 resident rows): staging
 // rows in LDS per 256-pixel workgroup, as k_ncc_dot4 does, would be paid by nearly every workgroup for one or two
 // active lanes.
 template <int R>
 __global__ __launch_bounds__(256) void k_ncc_sparse(StageArgs a) {
     constexpr int WS = 2 * R + 1, G = NCC_G, NB = G + WS - 1;
     constexpr int n = WS * WS * 3;
-    const int count = *a.ncc_cnt;
-    const int W = a.W;
-    for (int item = blockIdx.x * 256 + threadIdx.x; item < count; item += gridDim.x * 256) {
-        const uint32_t ent = a.rf_list[item];
-        const DirArgs &d = a.d[ent >> 31];
-        const size_t pix = ent & 0x7fffffffu;
+    const int W = a.W, H = a.H;
+    const int lane = threadIdx.x & 63;
+    // one wave per (direction, row) list written by k_setb_horiz
+    for (int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6); row < a.ndir * H; row += gridDim.x * 4)
+    for (int item = lane, count = a.ncc_cnt[16 + row]; item < count; item += 64) {
+        const DirArgs &d = a.d[row / H];
+        const size_t pix = a.rf_list[(size_t)row * W + item];
         const int y = (int)(pix / W), x = (int)(pix % W);
         const int L = max((int)d.BL[pix], R), Rr = min((int)d.BR[pix], W - 1 - R);
         const int Sa = d.S1_own[pix];

@@ -247,7 +247,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         DALLOC(c, c->rf_pwp[v], 2 * px);
         DALLOC(c, c->rf_delta[v], 2 * px);
     }
-    DALLOC(c, c->rf_cnt, 16);
+    DALLOC(c, c->rf_cnt, 16 + 2 * (size_t)in->height); // [0]: wide-pixel count; [16 + dir * H + y]: Rematch pixels of a row
     DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->d_j1, 4096);
@@ -764,7 +764,7 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     b.mo = t.up(mask_own, px);
     b.mt = t.up(mask_oth, px);
     b.wl = t.alloc<uint32_t>(std::max(px + 64, SETB_SCRATCH(W))); // NCC worklist / SetBoundary scratch
-    b.wc = t.alloc<int32_t>(16);
+    b.wc = t.alloc<int32_t>(16 + 2 * (size_t)H);
     b.i4o = t.alloc<uint32_t>(px);
     b.i4t = t.alloc<uint32_t>(px);
     b.S1o = t.alloc<int32_t>(px);
