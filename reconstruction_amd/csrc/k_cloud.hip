@@ -72,15 +72,22 @@ __device__ __forceinline__ bool eroded_is_255(const int32_t *__restrict__ prefix
             for (int bx = bx0; bx <= bx1; bx++) bad |= blk[by * nbx + bx];
         if (!bad) return true;
     }
-    for (int i = 0; i < ksize; i++) {
-        const int yy = y + i - ay;
-        if (yy < 0 || yy >= H) continue;
-        const int a = j1[i], b = j2[i];
-        if (b <= a) continue;
-        const int lo = max(x + a - ax, 0), hi = min(x + b - 1 - ax, W - 1);
-        if (lo > hi) continue;
-        const int32_t *p = prefix + (size_t)yy * (W + 1);
-        if (p[hi + 1] - p[lo] != 0) return false;
+    // no early exit inside a batch: with one the span loads of consecutive rows could not be in flight together,
+    // and the loop would cost ksize dependent memory round trips
+    for (int i0 = 0; i0 < ksize; i0 += 8) {
+        int bad = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = min(i0 + u, ksize - 1);
+            const int yy = y + i - ay;
+            const int a = j1[i], b = j2[i];
+            const int lo = max(x + a - ax, 0), hi = min(x + b - 1 - ax, W - 1);
+            const bool use = yy >= 0 && yy < H && b > a && lo <= hi;
+            const int32_t *p = prefix + (size_t)(use ? yy : y) * (W + 1);
+            const int dcount = p[(use ? hi : x) + 1] - p[use ? lo : x];
+            bad |= use ? dcount : 0;
+        }
+        if (bad) return false;
     }
     return true;
 }
@@ -132,6 +139,19 @@ __global__ __launch_bounds__(256) void k_cloud(CloudArgs c) {
     __shared__ int s_w[4];
     __shared__ long long s_base;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (PASS == 0) { // flags + the row's count: no ordering needed yet, so no barrier per 256-pixel chunk
+        int cnt = 0;
+        for (int x = c.own.XL + tid; x <= c.own.XR; x += 256) {
+            const bool f = cloud_flag(c, x, y);
+            c.flags[(size_t)y * c.W + x] = f;
+            cnt += f;
+        }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) s_w[wid] = cnt;
+        __syncthreads();
+        if (tid == 0) c.row_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        return;
+    }
     if (tid == 0) s_base = (PASS == 1) ? (long long)c.row_offset[blockIdx.x] : 0ll;
     __syncthreads();
     double q03 = 0, q13 = 0, qz = 0, qw = 0, q32 = 0;
