@@ -386,7 +386,6 @@ __global__ void k_uniq(T *__restrict__ P, const T *__restrict__ Q, int W, int H,
     const int XL = own.XL, XR = own.XR, XL1 = oth.XL, XR1 = oth.XR;
     const long long total = (long long)W * H;
     T *p = P + (size_t)y * W;
-    const T *q = Q + (size_t)y * W;
     unsigned long long cin = 1ull; // p[XL-1] is never modified: "alive" as far as the chain goes
     CT prev_last = (XL - 1 >= 0) ? (CT)p[XL - 1] : (CT)NOMATCH;
     for (int x0 = XL; x0 <= XR; x0 += 64) {
@@ -401,12 +400,21 @@ __global__ void k_uniq(T *__restrict__ P, const T *__restrict__ Q, int W, int H,
         if (valid) {
             const int bL = max((int)(raw + 0.5) + x - 1, XL1); // .cpp:482 (C truncation)
             const int bR = min(bL + 2, XR1);
+            // all four loads at once (a short-circuit loop would make them dependent round trips)
+            const long long rowo = (long long)y * W;
+            CT qq[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const long long fi = rowo + bL + u; // bL + u <= bR is inside the row; beyond it the value is unused
+                qq[u] = (bL + u <= bR && fi >= 0 && fi < total) ? (CT)Q[fi] : (CT)NOMATCH;
+            }
+            const long long fi = rowo + bL + 1; // flat-buffer emulation of q[bL+1]
+            const CT qv = (fi >= 0 && fi < total) ? (CT)Q[fi] : (CT)NOMATCH;
             bool direct = false;
-            for (int i = bL; i <= bR; i++) direct = direct || close2<CT>((CT)q[i], raw);
+#pragma unroll
+            for (int u = 0; u < 3; u++) direct = direct || (bL + u <= bR && close2<CT>(qq[u], raw));
             if (direct) g = true;
             else {
-                const long long fi = (long long)y * W + bL + 1; // flat-buffer emulation of q[bL+1]
-                const CT qv = (fi >= 0 && fi < total) ? (CT)Q[fi] : (CT)NOMATCH;
                 g = close2<CT>(qv, pp1);
                 h = close2<CT>(qv, pm1);
             }
