@@ -36,25 +36,29 @@ __global__ void k_smooth(StageArgs a) {
     auto differ = [](int p, int q) -> int { return abs(p - q) > 1; };
     int T = 0, F = 0;
     const bool vc = dc != NOMATCH;
+    // the neighbourhood is loaded whether or not (X,Y) is valid: together with the centre, not after it
+    const int e = val(X + 1, Y), sw = val(X - 1, Y + 1), s = val(X, Y + 1), se = val(X + 1, Y + 1);
+    const int w = val(X - 1, Y), ne = val(X + 1, Y - 1), nn = val(X, Y - 1), nw = val(X - 1, Y - 1);
     if (vc) {
         // (X,Y) as source (it is inside M): E, SW, S totals; E, SW, S, SE differs
-        const int e = val(X + 1, Y), sw = val(X - 1, Y + 1), s = val(X, Y + 1), se = val(X + 1, Y + 1);
         if (e != NOMATCH) { T++; F += differ(dc, e); }
         if (sw != NOMATCH) { T++; F += differ(dc, sw); }
         if (s != NOMATCH) { T++; F += differ(dc, s); }
         if (se != NOMATCH) { F += differ(dc, se); }
         // (X,Y) as target of W (its E), NE (its SW), N (its S), NW (its SE: differ only)
-        const int w = val(X - 1, Y), ne = val(X + 1, Y - 1), nn = val(X, Y - 1), nw = val(X - 1, Y - 1);
         if (w != NOMATCH && in_margin(M, X - 1, Y)) { T++; F += differ(w, dc); }
         if (ne != NOMATCH && in_margin(M, X + 1, Y - 1)) { T++; F += differ(ne, dc); }
         if (nn != NOMATCH && in_margin(M, X, Y - 1)) { T++; F += differ(nn, dc); }
         if (nw != NOMATCH && in_margin(M, X - 1, Y - 1)) { F += differ(nw, dc); }
     }
-    // slip terms (independent of the validity of (X,Y))
-    if (in_margin(M, 2 * X, Y) && val(2 * X, Y) != NOMATCH && val(2 * X + 1, Y + 1) != NOMATCH) T++;
-    if (in_margin(M, 2 * X - 2, Y - 1) && val(2 * X - 2, Y - 1) != NOMATCH && val(2 * X - 1, Y) != NOMATCH) T++;
-    if (in_margin(M, 2 * X + 1, Y) && val(2 * X + 1, Y) != NOMATCH && val(2 * X + 2, Y + 1) != NOMATCH) F++;
-    if (in_margin(M, 2 * X - 1, Y - 1) && val(2 * X - 1, Y - 1) != NOMATCH && val(2 * X, Y) != NOMATCH) F++;
+    // slip terms (independent of the validity of (X,Y)); the eight loads are issued together -- behind short-circuit
+    // conditions they would be dependent memory round trips
+    const int s0 = val(2 * X, Y), s1 = val(2 * X + 1, Y + 1), s2 = val(2 * X - 2, Y - 1), s3 = val(2 * X - 1, Y);
+    const int s4 = val(2 * X + 1, Y), s5 = val(2 * X + 2, Y + 1), s6 = val(2 * X - 1, Y - 1);
+    T += (int)(in_margin(M, 2 * X, Y) && s0 != NOMATCH && s1 != NOMATCH);
+    T += (int)(in_margin(M, 2 * X - 2, Y - 1) && s2 != NOMATCH && s3 != NOMATCH);
+    F += (int)(in_margin(M, 2 * X + 1, Y) && s4 != NOMATCH && s5 != NOMATCH);
+    F += (int)(in_margin(M, 2 * X - 1, Y - 1) && s6 != NOMATCH && s0 != NOMATCH);
     T &= 255; // the reference counters are uchar
     F &= 255;
     d.d16_out[pix] = (T == 0 || (F << 1) > T) ? (int16_t)NOMATCH : dc;
@@ -729,30 +733,39 @@ __global__ void k_median(StageArgs a) {
     const int y = d.own.YL + blockIdx.y;
     if (x > d.own.XR || y > d.own.YR) return;
     const int W = a.W;
-    if (d.mask_own[(size_t)y * W + x] != 255) return; // output stays NOMATCH (.cpp:772,788)
     const int16_t *D = d.d16_in;
-    int u[6], k = 0;
-    for (int i = x - 1; i < x + 1; i++) // .cpp:792: columns x-1 and x only
-        for (int j = -1; j <= 1; j++) {
-            const int v = D[(size_t)(y + j) * W + i];
-            if (v != NOMATCH) u[k++] = v;
-        }
-    const int c = D[(size_t)y * W + x];
+    // mask and the six samples (.cpp:792: columns x-1 and x only) in one round trip
+    const int m = d.mask_own[(size_t)y * W + x];
+    int u[6];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) u[i * 3 + j] = D[(size_t)(y + j - 1) * W + x - 1 + i];
+    if (m != 255) return; // output stays NOMATCH (.cpp:772,788)
+    const int c = u[4];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        k += u[i] != NOMATCH;
+        if (u[i] == NOMATCH) u[i] = 0x7fffffff; // sorts behind the k valid samples
+    }
     int out = NOMATCH;
     const bool take = (c == NOMATCH) ? (k >= 4) : (k > 2);
     if (take) {
-        for (int i = 1; i < k; i++) { // insertion sort, k <= 6
-            const int v = u[i];
-            int j = i - 1;
-            while (j >= 0 && u[j] > v) {
-                u[j + 1] = u[j];
-                j--;
-            }
-            u[j + 1] = v;
-        }
-        const int half = k / 2;
-        // arma::median: odd -> middle; even -> lo + (hi - lo)/2 (op_mean::robust_mean, integer division)
-        out = (k & 1) ? u[half] : (u[half - 1] + (u[half] - u[half - 1]) / 2);
+        // 12-exchange sorting network for 6 keys (registers only; the reference sorts the k valid ones)
+#define MED_CE(A, B)                 \
+    {                                \
+        const int lo_ = min(u[A], u[B]); \
+        u[B] = max(u[A], u[B]);      \
+        u[A] = lo_;                  \
+    }
+        MED_CE(0, 5) MED_CE(1, 3) MED_CE(2, 4) MED_CE(1, 2) MED_CE(3, 4) MED_CE(0, 3)
+        MED_CE(2, 5) MED_CE(0, 1) MED_CE(2, 3) MED_CE(4, 5) MED_CE(1, 2) MED_CE(3, 4)
+#undef MED_CE
+        // arma::median: odd -> middle; even -> lo + (hi - lo)/2 (op_mean::robust_mean, integer division); k = 3..6
+        const int lo = (k <= 4) ? u[1] : u[2]; // k = 3: the middle, 4: the lower middle, 5: the middle, 6: the lower middle
+        const int hi = (k == 6) ? u[3] : u[2]; // the upper middle of an even k
+        out = (k & 1) ? lo : lo + (hi - lo) / 2;
     }
     d.d16_out[(size_t)y * W + x] = (int16_t)out;
 }
