@@ -19,17 +19,13 @@ __device__ __forceinline__ bool in_margin(const Mg &m, int x, int y) {
 __global__ void k_smooth(StageArgs a) {
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W, H = a.H;
-    const int X = blockIdx.x * blockDim.x + threadIdx.x;
-    const int Y = blockIdx.y;
-    if (X >= W || Y >= H) return;
+    const Mg M = d.own;
+    const int X = M.XL + blockIdx.x * blockDim.x + threadIdx.x; // the margin only: outside it the map is copied as it is
+    const int Y = M.YL + blockIdx.y;
+    if (X > M.XR || Y > M.YR) return;
     const int16_t *D = d.d16_in;
     const size_t pix = (size_t)Y * W + X;
     const int16_t dc = D[pix];
-    const Mg M = d.own;
-    if (!in_margin(M, X, Y)) {
-        d.d16_out[pix] = dc;
-        return;
-    }
     auto val = [&](int x, int y) -> int {
         return (x >= 0 && x < W && y >= 0 && y < H) ? (int)D[(size_t)y * W + x] : NOMATCH;
     };
@@ -65,8 +61,14 @@ __global__ void k_smooth(StageArgs a) {
 }
 
 void launch_smooth(const StageArgs &a, hipStream_t st) {
-    dim3 grid((a.W + 255) / 256, a.H, a.ndir);
-    hipLaunchKernelGGL(k_smooth, grid, dim3(256), 0, st, a);
+    int rows = 0, cols = 0;
+    for (int v = 0; v < a.ndir; v++) {
+        (void)hipMemcpyAsync(a.d[v].d16_out, a.d[v].d16_in, (size_t)a.W * a.H * sizeof(int16_t), hipMemcpyDeviceToDevice, st);
+        rows = max(rows, a.d[v].own.YR - a.d[v].own.YL + 1);
+        cols = max(cols, a.d[v].own.XR - a.d[v].own.XL + 1);
+    }
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(k_smooth, dim3((cols + 255) / 256, rows, a.ndir), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------- OrderConstraint
