@@ -174,9 +174,49 @@ void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long 
 // S1(x,y) = sum of the (2r+1)x(2r+1)x3 bytes centred on (x,y); S2 = sum of their squares.
 // Defined where the window fits; 0 elsewhere. Separable: horizontal then vertical.
 // Horizontal pass on the BGRX copy: one aligned dword per pixel, v_sad_u8 sums its three bytes (X = 0) and
-// v_dot4_u32_u8 with itself their squares.
-__global__ void k_box_h(const uint32_t *__restrict__ img4, int W, int H, int r, int32_t *__restrict__ h1,
+// v_dot4_u32_u8 with itself their squares.  A thread produces BH_P consecutive pixels with a sliding window: every
+// dword is loaded and reduced once per thread (BH_P + 2R of them instead of BH_P * (2R + 1)).
+#define BH_P 4
+template <int R>
+__global__ void k_box_h(const uint32_t *__restrict__ img4, int W, int H, int32_t *__restrict__ h1,
                         int32_t *__restrict__ h2) {
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * BH_P;
+    const int y = blockIdx.y;
+    if (x0 >= W) return;
+    const uint32_t *row = img4 + (size_t)y * W;
+    constexpr int NW = BH_P + 2 * R; // dwords x0 - R .. x0 + BH_P - 1 + R
+    int e1[NW], e2[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        const int col = x0 - R + i;
+        const uint32_t v = (col >= 0 && col < W) ? row[col] : 0u;
+        e1[i] = (int)__builtin_amdgcn_sad_u8(v, 0u, 0u);
+        e2[i] = (int)__builtin_amdgcn_udot4(v, v, 0u, false);
+    }
+    int s1 = 0, s2 = 0;
+#pragma unroll
+    for (int i = 0; i <= 2 * R; i++) {
+        s1 += e1[i];
+        s2 += e2[i];
+    }
+#pragma unroll
+    for (int p = 0; p < BH_P; p++) {
+        const int x = x0 + p;
+        if (x < W) {
+            const bool ok = x - R >= 0 && x + R < W;
+            h1[(size_t)y * W + x] = ok ? s1 : 0;
+            h2[(size_t)y * W + x] = ok ? s2 : 0;
+        }
+        if (p + 1 < BH_P) { // slide: dword p leaves, dword p + 2R + 1 enters
+            s1 += e1[p + 2 * R + 1] - e1[p];
+            s2 += e2[p + 2 * R + 1] - e2[p];
+        }
+    }
+}
+
+// any radius (validate() allows up to 15): one pixel per thread
+__global__ void k_box_h_any(const uint32_t *__restrict__ img4, int W, int H, int r, int32_t *__restrict__ h1,
+                            int32_t *__restrict__ h2) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
@@ -227,7 +267,17 @@ __global__ void k_box_v(const int32_t *__restrict__ h1, const int32_t *__restric
 
 void launch_box_sums(const uint32_t *img4, int W, int H, int r, int32_t *tmp1, int32_t *tmp2, int32_t *S1,
                      int32_t *S2, hipStream_t st) {
-    hipLaunchKernelGGL(k_box_h, dim3((W + 255) / 256, H), dim3(256), 0, st, img4, W, H, r, tmp1, tmp2);
+    const dim3 gh((W + 256 * BH_P - 1) / (256 * BH_P), H);
+    switch (r) {
+    case 1: hipLaunchKernelGGL(k_box_h<1>, gh, dim3(256), 0, st, img4, W, H, tmp1, tmp2); break;
+    case 2: hipLaunchKernelGGL(k_box_h<2>, gh, dim3(256), 0, st, img4, W, H, tmp1, tmp2); break;
+    case 3: hipLaunchKernelGGL(k_box_h<3>, gh, dim3(256), 0, st, img4, W, H, tmp1, tmp2); break;
+    case 4: hipLaunchKernelGGL(k_box_h<4>, gh, dim3(256), 0, st, img4, W, H, tmp1, tmp2); break;
+    case 5: hipLaunchKernelGGL(k_box_h<5>, gh, dim3(256), 0, st, img4, W, H, tmp1, tmp2); break;
+    case 6: hipLaunchKernelGGL(k_box_h<6>, gh, dim3(256), 0, st, img4, W, H, tmp1, tmp2); break;
+    case 7: hipLaunchKernelGGL(k_box_h<7>, gh, dim3(256), 0, st, img4, W, H, tmp1, tmp2); break;
+    default: hipLaunchKernelGGL(k_box_h_any, dim3((W + 255) / 256, H), dim3(256), 0, st, img4, W, H, r, tmp1, tmp2); break;
+    }
     hipLaunchKernelGGL(k_box_v, dim3((W + 255) / 256, (H + BV_ROWS - 1) / BV_ROWS), dim3(256), 0, st, tmp1, tmp2, W, H, r, S1, S2);
 }
 
