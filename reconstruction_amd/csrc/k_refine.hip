@@ -224,7 +224,7 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
 
 // First sweep of a level: every cache entry is empty, so instead of a worklist the kernel walks the whole
 // interior (and also does the mode 0 copy-through).
-__global__ __launch_bounds__(256) void k_refine_first(StageArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_refine_first(StageArgs a) {
     const int W = a.W, H = a.H;
     const DirArgs &d = a.d[blockIdx.z];
     const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
