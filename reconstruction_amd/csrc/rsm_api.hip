@@ -50,6 +50,8 @@ struct EvPair {
 struct rsm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // side stream: per-level BGRX copies and window sums (they depend on the images only)
+    hipEvent_t ev_pyr = nullptr, ev_prep[RSM_MAX_LEVELS]{};
     std::string err;
 
     // resident pair
@@ -64,8 +66,8 @@ struct rsm_ctx {
     size_t cap_px = 0;
     std::vector<void *> allocs;
     int *d_margins = nullptr; // N*2*4 ints
-    int32_t *S1[2]{}, *S2[2]{}, *tmp1 = nullptr, *tmp2 = nullptr;
-    uint32_t *img4[2]{};
+    int32_t *S1[RSM_MAX_LEVELS][2]{}, *S2[RSM_MAX_LEVELS][2]{}, *tmp1 = nullptr, *tmp2 = nullptr; // per level and view
+    uint32_t *img4[RSM_MAX_LEVELS][2]{};
     int16_t *d16a[2]{}, *d16b[2]{}, *BL[2]{}, *BR[2]{};
     double *f64[3][2]{};
     int32_t *nv[2]{};
@@ -155,15 +157,23 @@ extern "C" int rsm_create(rsm_ctx **out, int hip_device) {
     if (hip_device < 0 || hip_device >= ndev) return RSM_E_INVALID;
     rsm_ctx *c = new rsm_ctx();
     c->device = hip_device;
-    if (hipSetDevice(hip_device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(hip_device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return RSM_E_HIP;
     }
+    for (int k = 0; k < RSM_MAX_LEVELS; k++)
+        if (hipEventCreateWithFlags(&c->ev_prep[k], hipEventDisableTiming) != hipSuccess) {
+            delete c;
+            return RSM_E_HIP;
+        }
     *out = c;
     return RSM_OK;
 }
 
 static void free_workspace(rsm_ctx *c) {
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (void *p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
     c->cap_px = 0;
@@ -179,6 +189,9 @@ extern "C" void rsm_destroy(rsm_ctx *c) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
+    (void)hipEventDestroy(c->ev_pyr);
+    for (int k = 0; k < RSM_MAX_LEVELS; k++) (void)hipEventDestroy(c->ev_prep[k]);
+    (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -228,15 +241,15 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         for (int v = 0; v < 2; v++) {
             DALLOC(c, c->img[k][v], (size_t)c->Wk[k] * c->Hk[k] * 3);
             DALLOC(c, c->msk[k][v], (size_t)c->Wk[k] * c->Hk[k]);
+            DALLOC(c, c->S1[k][v], (size_t)c->Wk[k] * c->Hk[k]);
+            DALLOC(c, c->S2[k][v], (size_t)c->Wk[k] * c->Hk[k]);
+            DALLOC(c, c->img4[k][v], (size_t)c->Wk[k] * c->Hk[k]);
         }
     }
     DALLOC(c, c->d_margins, RSM_MAX_LEVELS * 2 * 4);
     DALLOC(c, c->tmp1, px);
     DALLOC(c, c->tmp2, px);
     for (int v = 0; v < 2; v++) {
-        DALLOC(c, c->S1[v], px);
-        DALLOC(c, c->img4[v], px);
-        DALLOC(c, c->S2[v], px);
         DALLOC(c, c->d16a[v], px);
         DALLOC(c, c->d16b[v], px);
         DALLOC(c, c->BL[v], px);
@@ -382,14 +395,14 @@ static StageArgs level_args(rsm_ctx *c, int k) {
         const int o = 1 - v;
         d.img_own = c->img[k][v];
         d.img_oth = c->img[k][o];
-        d.img4_own = c->img4[v];
-        d.img4_oth = c->img4[o];
+        d.img4_own = c->img4[k][v];
+        d.img4_oth = c->img4[k][o];
         d.mask_own = c->msk[k][v];
         d.mask_oth = c->msk[k][o];
-        d.S1_own = c->S1[v];
-        d.S2_own = c->S2[v];
-        d.S1_oth = c->S1[o];
-        d.S2_oth = c->S2[o];
+        d.S1_own = c->S1[k][v];
+        d.S2_own = c->S2[k][v];
+        d.S1_oth = c->S1[k][o];
+        d.S2_oth = c->S2[k][o];
         d.own = c->mg[k][v];
         d.oth = c->mg[k][o];
         d.BL = c->BL[v];
@@ -427,6 +440,17 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             launch_pyr_down(c->msk[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 1, c->msk[k][v], st);
         }
     prof_end(c, ps1, ST_PYRAMID, 4 * (N - 1), 14.0 * P_top_full);
+    // BGRX copies and NCC window sums of every level depend on the images only: the side stream makes them while the
+    // small levels (launch-latency bound, the GPU mostly idle) are matched; level k waits for ev_prep[k]
+    HIPCHK(c, hipEventRecord(c->ev_pyr, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_pyr, 0));
+    for (int k = 0; k < N; k++) {
+        for (int v = 0; v < 2; v++) {
+            launch_bgr_to_bgrx(c->img[k][v], c->Wk[k], c->Hk[k], c->img4[k][v], c->stream2);
+            launch_box_sums(c->img4[k][v], c->Wk[k], c->Hk[k], r, c->tmp1, c->tmp2, c->S1[k][v], c->S2[k][v], c->stream2);
+        }
+        HIPCHK(c, hipEventRecord(c->ev_prep[k], c->stream2));
+    }
 
     // FindMargin for every level and view (.cpp:51-52): depends on the masks only
     const int ps2 = prof_begin(c, ST_MARGIN);
@@ -455,11 +479,8 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         if (degenerate(c->mg[k][0]) || degenerate(c->mg[k][1]))
             return set_err(c, RSM_E_DEGENERATE_MARGIN, "level %d: YL>=YR || XL>=XR", k);
 
-        const int ps3 = prof_begin(c, ST_BOXSUM);
-        for (int v = 0; v < 2; v++) {
-            launch_bgr_to_bgrx(c->img[k][v], W, H, c->img4[v], st);
-            launch_box_sums(c->img4[v], W, H, r, c->tmp1, c->tmp2, c->S1[v], c->S2[v], st);
-        }
+        const int ps3 = prof_begin(c, ST_BOXSUM); // what the main stream still has to wait for
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_prep[k], 0));
         prof_end(c, ps3, ST_BOXSUM, 6, 0);
 
         // ---- initial match (.cpp:53-62) -> d16a
