@@ -231,18 +231,21 @@ __global__ __launch_bounds__(256) void k_row_scan(const int32_t *__restrict__ cn
     if (tid == 0) *total = s_base;
 }
 
+// blk[CLOUD_BLOCKS(W, H)]: the coarse bad-block map of `prefix` (quick accept of the erosion test)
+void launch_bad_blocks(const int32_t *prefix, int W, int H, uint8_t *blk, hipStream_t st) {
+    const int nbx = (W + EB - 1) / EB, nby = (H + EB - 1) / EB;
+    hipLaunchKernelGGL(k_bad_blocks, dim3((nbx * nby + 255) / 256), dim3(256), 0, st, prefix, W, H, nbx, nby, blk);
+}
+
 void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *img, int W, int H, int ksize,
                   const int *d_j1, const int *d_j2, const double *q16_scaled, const double *R, const double *T,
-                  Mg own, uint8_t *flags, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints, double *xyz,
-                  uint8_t *bgr, int64_t max_points, hipStream_t st) {
+                  Mg own, uint8_t *flags, const uint8_t *blk, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints,
+                  double *xyz, uint8_t *bgr, int64_t max_points, hipStream_t st) {
     const int rows = own.YR - own.YL + 1;
     if (rows <= 0 || own.XR < own.XL) {
         (void)hipMemsetAsync(d_npoints, 0, sizeof(int64_t), st);
         return;
     }
-    uint8_t *blk = flags + (size_t)W * H; // flags holds W*H + CLOUD_BLOCKS(W, H) bytes
-    const int nbx = (W + EB - 1) / EB, nby = (H + EB - 1) / EB;
-    hipLaunchKernelGGL(k_bad_blocks, dim3((nbx * nby + 255) / 256), dim3(256), 0, st, bad_prefix, W, H, nbx, nby, blk);
     CloudArgs c{disp, bad_prefix, img, W, H, ksize, d_j1, d_j2, q16_scaled, R, T, own, flags, blk,
                 row_count, row_offset, d_npoints, xyz, bgr, max_points};
     hipLaunchKernelGGL(k_cloud<0>, dim3(rows), dim3(256), 0, st, c);

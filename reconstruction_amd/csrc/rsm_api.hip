@@ -78,6 +78,8 @@ struct rsm_ctx {
     int32_t *prefix = nullptr;
     int *d_j1 = nullptr, *d_j2 = nullptr;   // structuring-element spans: Rectify's mask erosion
     int *d_cj1 = nullptr, *d_cj2 = nullptr; // ... and DisparityToCloud's (uploaded with the pair)
+    uint8_t *blk = nullptr;                 // coarse bad-block map of the top-level mask (cloud erosion)
+    hipEvent_t ev_cloudprep = nullptr;
     int32_t *row_count = nullptr;
     int64_t *row_offset = nullptr;
     int64_t *d_npoints = nullptr;
@@ -159,7 +161,8 @@ extern "C" int rsm_create(rsm_ctx **out, int hip_device) {
     c->device = hip_device;
     if (hipSetDevice(hip_device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_cloudprep, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return RSM_E_HIP;
     }
@@ -190,6 +193,7 @@ extern "C" void rsm_destroy(rsm_ctx *c) {
         (void)hipEventDestroy(e.b);
     }
     (void)hipEventDestroy(c->ev_pyr);
+    (void)hipEventDestroy(c->ev_cloudprep);
     for (int k = 0; k < RSM_MAX_LEVELS; k++) (void)hipEventDestroy(c->ev_prep[k]);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
@@ -263,6 +267,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->rf_cnt, 16 + 2 * (size_t)in->height); // [0]: wide-pixel count; [16 + dir * H + y]: Rematch pixels of a row
     DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
+    DALLOC(c, c->blk, CLOUD_BLOCKS(in->width, in->height));
     DALLOC(c, c->d_j1, 4096);
     DALLOC(c, c->d_j2, 4096);
     DALLOC(c, c->d_cj1, 4096);
@@ -432,18 +437,14 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     }
     const double P_top_full = (double)c->Wk[N - 1] * c->Hk[N - 1];
 
-    // ConstructPyrm, .cpp:1040-1053 (top level = uploaded images)
-    const int ps1 = prof_begin(c, ST_PYRAMID);
-    for (int k = N - 2; k >= 0; k--)
-        for (int v = 0; v < 2; v++) {
-            launch_pyr_down(c->img[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 3, c->img[k][v], st);
-            launch_pyr_down(c->msk[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 1, c->msk[k][v], st);
-        }
-    prof_end(c, ps1, ST_PYRAMID, 4 * (N - 1), 14.0 * P_top_full);
-    // BGRX copies and NCC window sums of every level depend on the images only: the side stream makes them while the
-    // small levels (launch-latency bound, the GPU mostly idle) are matched; level k waits for ev_prep[k]
-    HIPCHK(c, hipEventRecord(c->ev_pyr, st));
+    // ConstructPyrm, .cpp:1040-1053 (top level = uploaded images).  The main stream needs the masks (margins) first;
+    // everything that depends on the images or the top mask only goes to the side stream and is made while the small
+    // levels (launch-latency bound, the GPU mostly idle) are matched: the image pyramid, every level's BGRX copy and
+    // NCC window sums (level k waits for ev_prep[k]), and the cloud's bad-pixel prefix + block map (ev_cloudprep).
+    HIPCHK(c, hipEventRecord(c->ev_pyr, st)); // everything enqueued before this run
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_pyr, 0));
+    for (int k = N - 2; k >= 0; k--)
+        for (int v = 0; v < 2; v++) launch_pyr_down(c->img[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 3, c->img[k][v], c->stream2);
     for (int k = 0; k < N; k++) {
         for (int v = 0; v < 2; v++) {
             launch_bgr_to_bgrx(c->img[k][v], c->Wk[k], c->Hk[k], c->img4[k][v], c->stream2);
@@ -451,6 +452,13 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         }
         HIPCHK(c, hipEventRecord(c->ev_prep[k], c->stream2));
     }
+    launch_bad_prefix(c->msk[N - 1][0], c->Wk[N - 1], c->Hk[N - 1], c->prefix, c->stream2);
+    launch_bad_blocks(c->prefix, c->Wk[N - 1], c->Hk[N - 1], c->blk, c->stream2);
+    HIPCHK(c, hipEventRecord(c->ev_cloudprep, c->stream2));
+    const int ps1 = prof_begin(c, ST_PYRAMID);
+    for (int k = N - 2; k >= 0; k--)
+        for (int v = 0; v < 2; v++) launch_pyr_down(c->msk[k + 1][v], c->Wk[k + 1], c->Hk[k + 1], 1, c->msk[k][v], st);
+    prof_end(c, ps1, ST_PYRAMID, 2 * (N - 1), 14.0 * P_top_full);
 
     // FindMargin for every level and view (.cpp:51-52): depends on the masks only
     const int ps2 = prof_begin(c, ST_MARGIN);
@@ -600,9 +608,9 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         const int k = N - 1, W = c->Wk[k], H = c->Hk[k];
         const int ps14 = prof_begin(c, ST_CLOUD);
         const int ksize = (int)ceil(0.02 * H); // .cpp:703; spans, Q, R, T: upload_cloud_params
-        launch_bad_prefix(c->msk[k][0], W, H, c->prefix, st);
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_cloudprep, 0));
         launch_cloud(c->f64[par][0], c->prefix, c->img[k][0], W, H, ksize, c->d_cj1, c->d_cj2, c->d_q, c->d_R, c->d_T,
-                     c->mg[k][0], (uint8_t *)c->d16a[0], c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
+                     c->mg[k][0], (uint8_t *)c->d16a[0], c->blk, c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
         const Mg &m = c->mg[k][0];
         prof_end(c, ps14, ST_CLOUD, 4, 28.0 * (double)(m.XR - m.XL + 1) * (m.YR - m.YL + 1));
     }
@@ -1041,7 +1049,8 @@ extern "C" int rsm_stage_cloud(rsm_ctx *c, const double *disp, const uint8_t *ma
     launch_bad_prefix(dm, W, H, pre, c->stream);
     uint8_t *fl = t.alloc<uint8_t>(px + CLOUD_BLOCKS(W, H));
     if (!t.ok) return finish(c, t);
-    launch_cloud(dd, pre, di, W, H, ksize, d1, d2, dq, dR, dT, to_mg(*own), fl, rc, ro, dn, dx, db, cap, c->stream);
+    launch_bad_blocks(pre, W, H, fl + px, c->stream);
+    launch_cloud(dd, pre, di, W, H, ksize, d1, d2, dq, dR, dT, to_mg(*own), fl, fl + px, rc, ro, dn, dx, db, cap, c->stream);
     int64_t n = 0;
     t.down(&n, (const int64_t *)dn, 1);
     *n_points = n;

@@ -81,15 +81,17 @@ void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
-// cloud: returns nothing; *d_npoints (device int64) receives the point count; `flags` = W*H + CLOUD_BLOCKS(W,H) bytes
+// cloud: returns nothing; *d_npoints (device int64) receives the point count; `flags` = W*H bytes of scratch,
+// `blk` = launch_bad_blocks' map (CLOUD_BLOCKS(W,H) bytes)
 #define CLOUD_BLOCKS(W, H) ((size_t)(((W) + 31) / 32) * (size_t)(((H) + 31) / 32))
 void launch_bad_prefix(const uint8_t *mask, int W, int H, int32_t *prefix, hipStream_t st);
 void launch_erode_binary(const int32_t *prefix, int W, int H, int ksize, const int *d_j1, const int *d_j2,
                          uint8_t *dst255, hipStream_t st);
+void launch_bad_blocks(const int32_t *prefix, int W, int H, uint8_t *blk, hipStream_t st);
 void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *img, int W, int H, int ksize,
                   const int *d_j1, const int *d_j2, const double *q16_scaled, const double *R,
-                  const double *T, Mg own, uint8_t *flags, int32_t *row_count, int64_t *row_offset, int64_t *d_npoints,
-                  double *xyz, uint8_t *bgr, int64_t max_points, hipStream_t st);
+                  const double *T, Mg own, uint8_t *flags, const uint8_t *blk, int32_t *row_count, int64_t *row_offset,
+                  int64_t *d_npoints, double *xyz, uint8_t *bgr, int64_t max_points, hipStream_t st);
 void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long long *d_count, hipStream_t st);
 
 // Rectify (k_rectify.hip)
