@@ -110,7 +110,8 @@ int rsm_set_option(rsm_ctx *ctx, const char *name, long long value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Per-stage device time of the last rsm_run_pair, measured with hipEvents on the ctx stream.
- * Enable before the run. Stage names: rsm_profile_stage_name(i), i < rsm_profile_stage_count(). */
+ * Enable before the run (on = 1: every stage and every 8th launch of the dominant kernel; on = 2: the latter only).
+ * Stage names: rsm_profile_stage_name(i), i < rsm_profile_stage_count(). */
 int rsm_profile_enable(rsm_ctx *ctx, int on);
 int rsm_profile_stage_count(void);
 const char *rsm_profile_stage_name(int stage);

@@ -237,7 +237,8 @@ class Context:
 
     # ---- measurement -----------------------------------------------------------------------------
     def profile_enable(self, on=True):
-        self._chk(self._lib.rsm_profile_enable(self._h, int(bool(on))))
+        """True / 1: events around every stage and every 8th launch of the dominant kernel; 2: the latter only."""
+        self._chk(self._lib.rsm_profile_enable(self._h, int(on)))
 
     def profile_get(self):
         n = self._lib.rsm_profile_stage_count()

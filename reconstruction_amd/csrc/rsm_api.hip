@@ -98,6 +98,7 @@ struct rsm_ctx {
 
     // profiling
     bool profile = false;
+    bool profile_stages = false;
     std::vector<EvPair> evpool;
     size_t ev_used = 0;
     double prof_ms[ST_COUNT]{};
@@ -344,7 +345,7 @@ static int prof_slot(rsm_ctx *c, int stage) { // next event pair of the pool
     return (int)c->ev_used++;
 }
 static int prof_begin(rsm_ctx *c, int stage) {
-    if (!c->profile) return -1;
+    if (!c->profile || !c->profile_stages) return -1;
     const int s = prof_slot(c, stage);
     (void)hipEventRecord(c->evpool[s].a, c->stream);
     return s;
@@ -366,6 +367,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
 extern "C" int rsm_profile_enable(rsm_ctx *c, int on) {
     if (!c) return RSM_E_INVALID;
     c->profile = on != 0;
+    c->profile_stages = on == 1; // 2: only the dominant kernel's launches are bracketed
     return RSM_OK;
 }
 extern "C" int rsm_profile_stage_count(void) { return ST_COUNT; }
