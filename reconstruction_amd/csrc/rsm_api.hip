@@ -69,6 +69,7 @@ struct rsm_ctx {
     int32_t *S1[RSM_MAX_LEVELS][2]{}, *S2[RSM_MAX_LEVELS][2]{}, *tmp1 = nullptr, *tmp2 = nullptr; // per level and view
     uint32_t *img4[RSM_MAX_LEVELS][2]{};
     int16_t *d16a[2]{}, *d16b[2]{}, *BL[2]{}, *BR[2]{};
+    int16_t *d16i[RSM_MAX_LEVELS][2]{}, *d16m[RSM_MAX_LEVELS][2]{}; // per level: initial-match / median outputs, pre-filled NOMATCH
     double *f64[3][2]{};
     int32_t *nv[2]{};
     int16_t *rf_key[2]{};
@@ -249,6 +250,8 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
             DALLOC(c, c->S1[k][v], (size_t)c->Wk[k] * c->Hk[k]);
             DALLOC(c, c->S2[k][v], (size_t)c->Wk[k] * c->Hk[k]);
             DALLOC(c, c->img4[k][v], (size_t)c->Wk[k] * c->Hk[k]);
+            DALLOC(c, c->d16i[k][v], (size_t)c->Wk[k] * c->Hk[k]);
+            DALLOC(c, c->d16m[k][v], (size_t)c->Wk[k] * c->Hk[k]);
         }
     }
     DALLOC(c, c->d_margins, RSM_MAX_LEVELS * 2 * 4);
@@ -451,6 +454,9 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         for (int v = 0; v < 2; v++) {
             launch_bgr_to_bgrx(c->img[k][v], c->Wk[k], c->Hk[k], c->img4[k][v], c->stream2);
             launch_box_sums(c->img4[k][v], c->Wk[k], c->Hk[k], r, c->tmp1, c->tmp2, c->S1[k][v], c->S2[k][v], c->stream2);
+            // the maps the initial match and the median filter write into start as NOMATCH everywhere (.cpp:772)
+            launch_fill_i16(c->d16i[k][v], (size_t)c->Wk[k] * c->Hk[k], (int16_t)NOMATCH, c->stream2);
+            launch_fill_i16(c->d16m[k][v], (size_t)c->Wk[k] * c->Hk[k], (int16_t)NOMATCH, c->stream2);
         }
         HIPCHK(c, hipEventRecord(c->ev_prep[k], c->stream2));
     }
@@ -481,7 +487,6 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     int par = 0; // index of the fp64 buffer holding the previous level's disparity (this is `disparity[]`)
     for (int k = 0; k < N; k++) {
         const int W = c->Wk[k], H = c->Hk[k];
-        const size_t px = (size_t)W * H;
         StageArgs a = level_args(c, k);
         const double Pk = 0.5 * ((double)(a.d[0].own.XR - a.d[0].own.XL + 1) * (a.d[0].own.YR - a.d[0].own.YL + 1) +
                                  (double)(a.d[1].own.XR - a.d[1].own.XL + 1) * (a.d[1].own.YR - a.d[1].own.YL + 1));
@@ -493,12 +498,11 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_prep[k], 0));
         prof_end(c, ps3, ST_BOXSUM, 6, 0);
 
-        // ---- initial match (.cpp:53-62) -> d16a
+        // ---- initial match (.cpp:53-62) -> d16i[k] (NOMATCH-filled by the side stream)
         const int ps4 = prof_begin(c, ST_INITIAL_MATCH);
         for (int v = 0; v < 2; v++) {
-            launch_fill_i16(c->d16a[v], px, (int16_t)NOMATCH, st);
-            a.d[v].d16_in = c->d16a[v];
-            a.d[v].d16_out = c->d16a[v];
+            a.d[v].d16_in = c->d16i[k][v];
+            a.d[v].d16_out = c->d16i[k][v];
         }
         if (k == 0) {
             launch_ncc_argmax(a, 0, st);
@@ -512,10 +516,10 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         }
         prof_end(c, ps4, ST_INITIAL_MATCH, k == 0 ? 3 : 6, 24.0 * Pk);
 
-        // ---- SmoothConstraint (.cpp:66-67): d16a -> d16b
+        // ---- SmoothConstraint (.cpp:66-67): d16i[k] -> d16b
         const int ps5 = prof_begin(c, ST_SMOOTH);
         for (int v = 0; v < 2; v++) {
-            a.d[v].d16_in = c->d16a[v];
+            a.d[v].d16_in = c->d16i[k][v];
             a.d[v].d16_out = c->d16b[v];
         }
         launch_smooth(a, st);
@@ -547,22 +551,21 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
         prof_end(c, ps9, ST_UNIQ16, 3, 18.0 * Pk);
 
-        // ---- MedianFilter (.cpp:89-90): d16b -> d16a (pre-filled NOMATCH, .cpp:772)
+        // ---- MedianFilter (.cpp:89-90): d16b -> d16m[k] (pre-filled NOMATCH, .cpp:772)
         const int ps10 = prof_begin(c, ST_MEDIAN);
         for (int v = 0; v < 2; v++) {
-            launch_fill_i16(c->d16a[v], px, (int16_t)NOMATCH, st);
             a.d[v].d16_in = c->d16b[v];
-            a.d[v].d16_out = c->d16a[v];
+            a.d[v].d16_out = c->d16m[k][v];
         }
         launch_median(a, st);
         prof_end(c, ps10, ST_MEDIAN, 3, 10.0 * Pk);
 
-        // ---- DisparityRefine (.cpp:95-98): int16 d16a -> fp64, 30 + 30k Jacobi sweeps
+        // ---- DisparityRefine (.cpp:95-98): int16 d16m[k] -> fp64, 30 + 30k Jacobi sweeps
         const int iters = 30 + k * 30;
         const int ia = (par + 1) % 3, ib = (par + 2) % 3;
         const int ps11 = prof_begin(c, ST_REFINE_INIT);
         for (int v = 0; v < 2; v++) {
-            a.d[v].d16_in = c->d16a[v];
+            a.d[v].d16_in = c->d16m[k][v];
             a.d[v].f64_a = c->f64[ia][v];
             a.d[v].f64_b = c->f64[ib][v];
         }
