@@ -724,7 +724,6 @@ void launch_set_boundary(const StageArgs &a, hipStream_t st, bool emit_list) {
     hipLaunchKernelGGL((k_setb_vert<1, 0>), vgrid, dim3(64), 0, st, a);
     hipLaunchKernelGGL((k_setb_vert<1, 1>), vgrid, dim3(64), 0, st, a);
     // (the vertical sweeps are done with their scratch in rf_list: the horizontal kernel may refill it)
-    if (emit_list) (void)hipMemsetAsync(a.ncc_cnt + 16, 0, sizeof(int) * 2 * a.H, st); // rows outside a margin stay empty
     hipLaunchKernelGGL(k_setb_horiz, dim3((rows + 3) / 4, 1, a.ndir), dim3(256), 0, st, a, emit_list ? 1 : 0);
 }
 

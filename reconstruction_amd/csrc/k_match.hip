@@ -16,12 +16,13 @@
 
 // ---------------------------------------------------------------- next valid parent column
 // nv[row][t] = smallest i > t with parent[row][i] != NOMATCH, or INT_MAX. One wave per parent row.
-__global__ void k_next_valid(const double *__restrict__ parent, int Wp, int Hp, int32_t *__restrict__ nv) {
+__global__ void k_next_valid(const double *__restrict__ parent0, const double *__restrict__ parent1, int Wp, int Hp,
+                             int32_t *__restrict__ nv0, int32_t *__restrict__ nv1) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= Hp) return;
-    const double *p = parent + (size_t)row * Wp;
-    int32_t *o = nv + (size_t)row * Wp;
+    const double *p = (blockIdx.y ? parent1 : parent0) + (size_t)row * Wp;
+    int32_t *o = (blockIdx.y ? nv1 : nv0) + (size_t)row * Wp;
     int carry = 0x7fffffff;
     const int nchunks = (Wp + 63) >> 6;
     for (int c = nchunks - 1; c >= 0; c--) {
@@ -36,7 +37,10 @@ __global__ void k_next_valid(const double *__restrict__ parent, int Wp, int Hp, 
 }
 
 void launch_next_valid(const double *parent, int Wp, int Hp, int32_t *nv, hipStream_t st) {
-    hipLaunchKernelGGL(k_next_valid, dim3((Hp + 3) / 4), dim3(256), 0, st, parent, Wp, Hp, nv);
+    hipLaunchKernelGGL(k_next_valid, dim3((Hp + 3) / 4, 1), dim3(256), 0, st, parent, parent, Wp, Hp, nv, nv);
+}
+void launch_next_valid2(const double *parent0, const double *parent1, int Wp, int Hp, int32_t *nv0, int32_t *nv1, hipStream_t st) {
+    hipLaunchKernelGGL(k_next_valid, dim3((Hp + 3) / 4, 2), dim3(256), 0, st, parent0, parent1, Wp, Hp, nv0, nv1);
 }
 
 // ---------------------------------------------------------------- HighLevel candidate intervals
@@ -509,10 +513,13 @@ __global__ __launch_bounds__(256) void k_ncc_sparse(StageArgs a) {
     constexpr int n = WS * WS * 3;
     const int W = a.W, H = a.H;
     const int lane = threadIdx.x & 63;
-    // one wave per (direction, row) list written by k_setb_horiz
-    for (int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6); row < a.ndir * H; row += gridDim.x * 4)
+    // one wave per (direction, margin row) list written by k_setb_horiz (which sets the count of every margin row)
+    for (int idx = blockIdx.x * 4 + ((int)threadIdx.x >> 6); idx < a.ndir * H; idx += gridDim.x * 4) {
+        const int dir = idx / H, yy = a.d[dir].own.YL + idx % H;
+        if (yy > a.d[dir].own.YR) continue; // wave-uniform
+        const int row = dir * H + yy;
     for (int item = lane, count = a.ncc_cnt[16 + row]; item < count; item += 64) {
-        const DirArgs &d = a.d[row / H];
+        const DirArgs &d = a.d[dir];
         const size_t pix = a.rf_list[(size_t)row * W + item];
         const int y = (int)(pix / W), x = (int)(pix % W);
         const int L = max((int)d.BL[pix], R), Rr = min((int)d.BR[pix], W - 1 - R);
@@ -551,6 +558,7 @@ __global__ __launch_bounds__(256) void k_ncc_sparse(StageArgs a) {
         }
         if (bc != -1) d.d16_out[pix] = (int16_t)(bc - x); // .cpp:563-564
     }
+    }
 }
 
 template <int R>
@@ -561,7 +569,7 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
         hipLaunchKernelGGL(k_ncc_sparse<R>, dim3(2048), dim3(256), 0, st, a);
         return;
     }
-    (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), st);
+    // *a.ncc_cnt (wide-pixel count) is zero on entry: the caller hands every launch a fresh counter
     hipLaunchKernelGGL(k_ncc_dot4<R>, grid, dim3(NCC_TX), lds, st, a, mode);
     const size_t ldsw = (size_t)WS * (NCC_TX * NCC_G + 2 * R + NCC_G) * 4;
     hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), ldsw, st, a, mode);

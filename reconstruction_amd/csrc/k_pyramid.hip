@@ -77,11 +77,11 @@ __global__ void k_margin_init(int *out4, int W, int H, int r) {
 // FM_ROWS rows y in [r, H-r) per block (one wave per row at a time); columns [r, W-r).  Few blocks, so that the
 // four global atomics per block do not pile up on one address (~88 same-address atomics per microsecond).
 #define FM_ROWS 16
-__global__ __launch_bounds__(256) void k_find_margin(const uint8_t *__restrict__ mask, int W, int H, int r, int *out4) {
+__device__ __forceinline__ void find_margin_body(const uint8_t *__restrict__ mask, int W, int H, int r, int *out4, int bx) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int lo = 0x7fffffff, hi = -1, ylo = 0x7fffffff, yhi = -1;
     for (int k = wid; k < FM_ROWS; k += 4) {
-        const int y = r + blockIdx.x * FM_ROWS + k;
+        const int y = r + bx * FM_ROWS + k;
         if (y >= H - r) break;
         const uint8_t *p = mask + (size_t)y * W;
         int rlo = 0x7fffffff, rhi = -1;
@@ -142,11 +142,47 @@ __global__ __launch_bounds__(256) void k_find_margin(const uint8_t *__restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void k_find_margin(const uint8_t *__restrict__ mask, int W, int H, int r, int *out4) {
+    find_margin_body(mask, W, H, r, out4, blockIdx.x);
+}
+// all levels and views of a pair in one launch: blockIdx.y selects the image
+#define FM_BATCH 24 // images per launch (2 views x RSM_MAX_LEVELS)
+struct MarginBatch {
+    const uint8_t *mask[FM_BATCH];
+    int W[FM_BATCH], H[FM_BATCH];
+};
+__global__ __launch_bounds__(256) void k_find_margin_batch(MarginBatch b, int r, int *out4) {
+    const int i = blockIdx.y;
+    if ((int)blockIdx.x * FM_ROWS >= b.H[i] - 2 * r) return; // uniform: smaller levels need fewer blocks
+    find_margin_body(b.mask[i], b.W[i], b.H[i], r, out4 + 4 * i, blockIdx.x);
+}
+
 void launch_find_margin(const uint8_t *mask, int W, int H, int r, int *out4, hipStream_t st) {
     hipLaunchKernelGGL(k_margin_init, dim3(1), dim3(1), 0, st, out4, W, H, r);
     const int rows = H - 2 * r;
     if (rows <= 0 || W - 2 * r <= 0) return;
     hipLaunchKernelGGL(k_find_margin, dim3((rows + FM_ROWS - 1) / FM_ROWS), dim3(256), 0, st, mask, W, H, r, out4);
+}
+
+// n images (masks[i], Ws[i] x Hs[i]); out4[4 * i ..] receives {XL, XR, YL, YR}; h_init: 4 * n ints of host scratch that
+// must stay valid until the stream has consumed the copy
+void launch_find_margin_batch(int n, const uint8_t *const *masks, const int *Ws, const int *Hs, int r, int *out4, int *h_init,
+                              hipStream_t st) {
+    MarginBatch b{};
+    int maxrows = 0;
+    for (int i = 0; i < n; i++) {
+        b.mask[i] = masks[i];
+        b.W[i] = Ws[i];
+        b.H[i] = Hs[i];
+        h_init[4 * i + 0] = Ws[i] - 1 - r; // inverted defaults (.cpp:1014-1017)
+        h_init[4 * i + 1] = r;
+        h_init[4 * i + 2] = Hs[i] - 1 - r;
+        h_init[4 * i + 3] = r;
+        if (Ws[i] - 2 * r > 0) maxrows = max(maxrows, Hs[i] - 2 * r);
+    }
+    (void)hipMemcpyAsync(out4, h_init, sizeof(int) * 4 * n, hipMemcpyHostToDevice, st);
+    if (maxrows <= 0) return;
+    hipLaunchKernelGGL(k_find_margin_batch, dim3((maxrows + FM_ROWS - 1) / FM_ROWS, n), dim3(256), 0, st, b, r, out4);
 }
 
 // masked pixels inside a margin (V_top of the metric): rows strided over a fixed number of blocks, one atomic each

@@ -61,6 +61,7 @@ struct rsm_ctx {
     int Wk[RSM_MAX_LEVELS]{}, Hk[RSM_MAX_LEVELS]{};
     uint8_t *img[RSM_MAX_LEVELS][2]{}, *msk[RSM_MAX_LEVELS][2]{};
     Mg mg[RSM_MAX_LEVELS][2]{};
+    int h_margin_init[RSM_MAX_LEVELS * 2 * 4]{}; // host source of the margins' initial values (async copy)
 
     // workspace (sized for the top level)
     size_t cap_px = 0;
@@ -268,7 +269,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         DALLOC(c, c->rf_pwp[v], 2 * px);
         DALLOC(c, c->rf_delta[v], 2 * px);
     }
-    DALLOC(c, c->rf_cnt, 16 + 2 * (size_t)in->height); // [0]: wide-pixel count; [16 + dir * H + y]: Rematch pixels of a row
+    DALLOC(c, c->rf_cnt, 32 + 2 * (size_t)in->height); // level k uses rf_cnt + k: [0] wide-pixel count, [16 + dir * H + y] Rematch pixels of a row
     DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->blk, CLOUD_BLOCKS(in->width, in->height));
@@ -397,7 +398,7 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.offset = c->in.offset;
     a.ws = c->in.ws;
     a.rf_list = c->rf_list;
-    a.ncc_cnt = c->rf_cnt;
+    a.ncc_cnt = c->rf_cnt + k; // a counter per level, zeroed together at the start of the run
     a.rf_stride = c->cap_px;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
     for (int v = 0; v < 2; v++) {
@@ -470,10 +471,19 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
 
     // FindMargin for every level and view (.cpp:51-52): depends on the masks only
     const int ps2 = prof_begin(c, ST_MARGIN);
-    for (int k = 0; k < N; k++)
-        for (int v = 0; v < 2; v++)
-            launch_find_margin(c->msk[k][v], c->Wk[k], c->Hk[k], r, c->d_margins + (k * 2 + v) * 4, st);
-    prof_end(c, ps2, ST_MARGIN, 4 * N, 0);
+    {
+        const uint8_t *masks[RSM_MAX_LEVELS * 2];
+        int Ws[RSM_MAX_LEVELS * 2], Hs[RSM_MAX_LEVELS * 2];
+        for (int k = 0; k < N; k++)
+            for (int v = 0; v < 2; v++) {
+                masks[k * 2 + v] = c->msk[k][v];
+                Ws[k * 2 + v] = c->Wk[k];
+                Hs[k * 2 + v] = c->Hk[k];
+            }
+        launch_find_margin_batch(2 * N, masks, Ws, Hs, r, c->d_margins, c->h_margin_init, st);
+        HIPCHK(c, hipMemsetAsync(c->rf_cnt, 0, sizeof(int) * 16, st)); // the levels' wide-pixel counters
+    }
+    prof_end(c, ps2, ST_MARGIN, 1, 0);
     int hm[RSM_MAX_LEVELS * 2 * 4];
     HIPCHK(c, hipMemcpyAsync(hm, c->d_margins, sizeof(int) * N * 2 * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -507,10 +517,8 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         if (k == 0) {
             launch_ncc_argmax(a, 0, st);
         } else {
-            for (int v = 0; v < 2; v++) {
-                a.d[v].parent = c->f64[par][v];
-                launch_next_valid(c->f64[par][v], a.Wp, a.Hp, c->nv[v], st);
-            }
+            for (int v = 0; v < 2; v++) a.d[v].parent = c->f64[par][v];
+            launch_next_valid2(c->f64[par][0], c->f64[par][1], a.Wp, a.Hp, c->nv[0], c->nv[1], st);
             launch_hl_interval(a, st);
             launch_ncc_argmax(a, 1, st);
         }
@@ -799,6 +807,7 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     b.mt = t.up(mask_oth, px);
     b.wl = t.alloc<uint32_t>(std::max(px + 64, SETB_SCRATCH(W))); // NCC worklist / SetBoundary scratch
     b.wc = t.alloc<int32_t>(16 + 2 * (size_t)H);
+    if (b.wc) (void)hipMemsetAsync(b.wc, 0, sizeof(int), c->stream); // wide-pixel counter of the NCC launch
     b.i4o = t.alloc<uint32_t>(px);
     b.i4t = t.alloc<uint32_t>(px);
     b.S1o = t.alloc<int32_t>(px);
@@ -1256,12 +1265,15 @@ extern "C" int rsm_bench_ncc(rsm_ctx *c, int W, int H, int r, int cands, int ite
     if (!t.ok) return finish(c, t);
     a.d[0].d16_in = a.d[0].d16_out = dd;
     launch_fill_i16(dd, px, (int16_t)NOMATCH, c->stream);
-    launch_ncc_argmax(a, 1, c->stream); // warm-up
+    launch_ncc_argmax(a, 1, c->stream); // warm-up (setup_match zeroed the counter)
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; i++) launch_ncc_argmax(a, 1, c->stream);
+    for (int i = 0; i < iters; i++) {
+        (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), c->stream); // fresh wide-pixel counter per launch
+        launch_ncc_argmax(a, 1, c->stream);
+    }
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));
     float ms = 0;

@@ -50,7 +50,7 @@ struct StageArgs {
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
-    int32_t *ncc_cnt;  // NCC: number of wide pixels in rf_list
+    int32_t *ncc_cnt;  // NCC: [0] number of wide pixels in rf_list (zero before an initial-match launch), [16 + dir * H + y] Rematch pixels of a row
 };
 
 // ---- launchers (each enqueues on `st`, no sync) ----------------------------------------------
@@ -60,11 +60,14 @@ void launch_fill_i32(int32_t *p, size_t n, int32_t v, hipStream_t st);
 void launch_pyr_down(const uint8_t *src, int W, int H, int C, uint8_t *dst, hipStream_t st);
 // out4 = {XL, XR, YL, YR} initialised by the kernel launcher (inverted defaults, .cpp:1014-1017)
 void launch_find_margin(const uint8_t *mask, int W, int H, int r, int *out4, hipStream_t st);
+void launch_find_margin_batch(int n, const uint8_t *const *masks, const int *Ws, const int *Hs, int r, int *out4, int *h_init,
+                              hipStream_t st);
 void launch_bgr_to_bgrx(const uint8_t *img, int W, int H, uint32_t *out, hipStream_t st);
 void launch_box_sums(const uint32_t *img4, int W, int H, int r, int32_t *tmp1, int32_t *tmp2,
                      int32_t *S1, int32_t *S2, hipStream_t st);
 
 void launch_next_valid(const double *parent, int Wp, int Hp, int32_t *nv, hipStream_t st);
+void launch_next_valid2(const double *parent0, const double *parent1, int Wp, int Hp, int32_t *nv0, int32_t *nv1, hipStream_t st);
 void launch_hl_interval(const StageArgs &a, hipStream_t st);
 // mode 0: lowest level (interval = other margin), 1: interval arrays BL/BR into NOMATCH-filled out,
 // 2: rematch (only pixels whose d16_in is NOMATCH; in place; the pixels come from launch_set_boundary(.., true))
