@@ -60,10 +60,11 @@ __global__ void k_smooth(StageArgs a) {
     d.d16_out[pix] = (T == 0 || (F << 1) > T) ? (int16_t)NOMATCH : dc;
 }
 
-void launch_smooth(const StageArgs &a, hipStream_t st) {
+void launch_smooth(const StageArgs &a, hipStream_t st, bool copy_outside) {
     int rows = 0, cols = 0;
     for (int v = 0; v < a.ndir; v++) {
-        (void)hipMemcpyAsync(a.d[v].d16_out, a.d[v].d16_in, (size_t)a.W * a.H * sizeof(int16_t), hipMemcpyDeviceToDevice, st);
+        if (copy_outside) // the caller may know that both maps already agree outside the margin (NOMATCH there)
+            (void)hipMemcpyAsync(a.d[v].d16_out, a.d[v].d16_in, (size_t)a.W * a.H * sizeof(int16_t), hipMemcpyDeviceToDevice, st);
         rows = max(rows, a.d[v].own.YR - a.d[v].own.YL + 1);
         cols = max(cols, a.d[v].own.XR - a.d[v].own.XL + 1);
     }

@@ -69,8 +69,8 @@ struct rsm_ctx {
     int *d_margins = nullptr; // N*2*4 ints
     int32_t *S1[RSM_MAX_LEVELS][2]{}, *S2[RSM_MAX_LEVELS][2]{}, *tmp1 = nullptr, *tmp2 = nullptr; // per level and view
     uint32_t *img4[RSM_MAX_LEVELS][2]{};
-    int16_t *d16a[2]{}, *d16b[2]{}, *BL[2]{}, *BR[2]{};
-    int16_t *d16i[RSM_MAX_LEVELS][2]{}, *d16m[RSM_MAX_LEVELS][2]{}; // per level: initial-match / median outputs, pre-filled NOMATCH
+    int16_t *d16a[2]{}, *BL[2]{}, *BR[2]{}; // d16a: scratch (cloud flags, Rectify's mask temp)
+    int16_t *d16i[RSM_MAX_LEVELS][2]{}, *d16s[RSM_MAX_LEVELS][2]{}, *d16m[RSM_MAX_LEVELS][2]{}; // per level: initial-match / constraint-stage / median maps, pre-filled NOMATCH
     double *f64[3][2]{};
     int32_t *nv[2]{};
     int16_t *rf_key[2]{};
@@ -253,6 +253,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
             DALLOC(c, c->img4[k][v], (size_t)c->Wk[k] * c->Hk[k]);
             DALLOC(c, c->d16i[k][v], (size_t)c->Wk[k] * c->Hk[k]);
             DALLOC(c, c->d16m[k][v], (size_t)c->Wk[k] * c->Hk[k]);
+            DALLOC(c, c->d16s[k][v], (size_t)c->Wk[k] * c->Hk[k]);
         }
     }
     DALLOC(c, c->d_margins, RSM_MAX_LEVELS * 2 * 4);
@@ -260,7 +261,6 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->tmp2, px);
     for (int v = 0; v < 2; v++) {
         DALLOC(c, c->d16a[v], px);
-        DALLOC(c, c->d16b[v], px);
         DALLOC(c, c->BL[v], px);
         DALLOC(c, c->BR[v], px);
         for (int i = 0; i < 3; i++) DALLOC(c, c->f64[i][v], px);
@@ -458,6 +458,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             // the maps the initial match and the median filter write into start as NOMATCH everywhere (.cpp:772)
             launch_fill_i16(c->d16i[k][v], (size_t)c->Wk[k] * c->Hk[k], (int16_t)NOMATCH, c->stream2);
             launch_fill_i16(c->d16m[k][v], (size_t)c->Wk[k] * c->Hk[k], (int16_t)NOMATCH, c->stream2);
+            launch_fill_i16(c->d16s[k][v], (size_t)c->Wk[k] * c->Hk[k], (int16_t)NOMATCH, c->stream2);
         }
         HIPCHK(c, hipEventRecord(c->ev_prep[k], c->stream2));
     }
@@ -524,26 +525,26 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         }
         prof_end(c, ps4, ST_INITIAL_MATCH, k == 0 ? 3 : 6, 24.0 * Pk);
 
-        // ---- SmoothConstraint (.cpp:66-67): d16i[k] -> d16b
+        // ---- SmoothConstraint (.cpp:66-67): d16i[k] -> d16s[k] (both NOMATCH outside the margins: no copy)
         const int ps5 = prof_begin(c, ST_SMOOTH);
         for (int v = 0; v < 2; v++) {
             a.d[v].d16_in = c->d16i[k][v];
-            a.d[v].d16_out = c->d16b[v];
+            a.d[v].d16_out = c->d16s[k][v];
         }
-        launch_smooth(a, st);
+        launch_smooth(a, st, false);
         prof_end(c, ps5, ST_SMOOTH, 1, 8.0 * Pk);
 
-        // ---- OrderConstraint (.cpp:71-72): d16b in place
+        // ---- OrderConstraint (.cpp:71-72): d16s[k] in place
         const int ps6 = prof_begin(c, ST_ORDER);
-        for (int v = 0; v < 2; v++) a.d[v].d16_in = a.d[v].d16_out = c->d16b[v];
+        for (int v = 0; v < 2; v++) a.d[v].d16_in = a.d[v].d16_out = c->d16s[k][v];
         launch_order(a, st);
         prof_end(c, ps6, ST_ORDER, 1, 8.0 * Pk);
 
         // ---- UniquenessContraint<short> (.cpp:75)
         const int ps7 = prof_begin(c, ST_UNIQ16);
-        launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
-        launch_uniq_s16(c->d16b[1], c->d16b[0], W, H, c->mg[k][1], c->mg[k][0], st);
-        launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
+        launch_uniq_s16(c->d16s[k][0], c->d16s[k][1], W, H, c->mg[k][0], c->mg[k][1], st);
+        launch_uniq_s16(c->d16s[k][1], c->d16s[k][0], W, H, c->mg[k][1], c->mg[k][0], st);
+        launch_uniq_s16(c->d16s[k][0], c->d16s[k][1], W, H, c->mg[k][0], c->mg[k][1], st);
         prof_end(c, ps7, ST_UNIQ16, 3, 18.0 * Pk);
 
         // ---- Rematch (.cpp:80-81): SetBoundary_smooth + NCC on still-unmatched pixels, in place
@@ -554,15 +555,15 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
 
         // ---- UniquenessContraint<short> (.cpp:86)
         const int ps9 = prof_begin(c, ST_UNIQ16);
-        launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
-        launch_uniq_s16(c->d16b[1], c->d16b[0], W, H, c->mg[k][1], c->mg[k][0], st);
-        launch_uniq_s16(c->d16b[0], c->d16b[1], W, H, c->mg[k][0], c->mg[k][1], st);
+        launch_uniq_s16(c->d16s[k][0], c->d16s[k][1], W, H, c->mg[k][0], c->mg[k][1], st);
+        launch_uniq_s16(c->d16s[k][1], c->d16s[k][0], W, H, c->mg[k][1], c->mg[k][0], st);
+        launch_uniq_s16(c->d16s[k][0], c->d16s[k][1], W, H, c->mg[k][0], c->mg[k][1], st);
         prof_end(c, ps9, ST_UNIQ16, 3, 18.0 * Pk);
 
-        // ---- MedianFilter (.cpp:89-90): d16b -> d16m[k] (pre-filled NOMATCH, .cpp:772)
+        // ---- MedianFilter (.cpp:89-90): d16s[k] -> d16m[k] (pre-filled NOMATCH, .cpp:772)
         const int ps10 = prof_begin(c, ST_MEDIAN);
         for (int v = 0; v < 2; v++) {
-            a.d[v].d16_in = c->d16b[v];
+            a.d[v].d16_in = c->d16s[k][v];
             a.d[v].d16_out = c->d16m[k][v];
         }
         launch_median(a, st);

@@ -73,7 +73,7 @@ void launch_hl_interval(const StageArgs &a, hipStream_t st);
 // 2: rematch (only pixels whose d16_in is NOMATCH; in place; the pixels come from launch_set_boundary(.., true))
 void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st);
 
-void launch_smooth(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out
+void launch_smooth(const StageArgs &a, hipStream_t st, bool copy_outside = true); // d16_in -> d16_out
 void launch_order(const StageArgs &a, hipStream_t st);         // d16_in in place
 void launch_uniq_s16(int16_t *p, const int16_t *q, int W, int H, Mg own, Mg oth, hipStream_t st);
 void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, hipStream_t st);
