@@ -1,0 +1,107 @@
+"""Edge cases of the restructured kernels (segment / chunk / component boundaries) against the oracle, through the C ABI.
+All integer work: bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from reconstruction_amd import synth
+
+pytestmark = pytest.mark.gpu
+NOMATCH = -10000
+
+
+def _maps(seed, H, W, p_nomatch=0.3, lo=-3, hi=4, p_mask=0.9):
+    rng = np.random.default_rng(seed)
+    d = rng.integers(lo, hi, size=(H, W)).astype(np.int16)
+    d[rng.random((H, W)) < p_nomatch] = NOMATCH
+    mask = np.where(rng.random((H, W)) < p_mask, 255, rng.integers(0, 255, size=(H, W))).astype(np.uint8)
+    return d, mask
+
+
+# margin heights around the 32 row segments of the vertical sweeps (empty segments, one-row segments, ragged last one)
+# and widths around the 64-column chunks of the horizontal scans
+@pytest.mark.parametrize("rows,cols", [(2, 70), (3, 64), (6, 65), (31, 63), (32, 128), (33, 129), (40, 200), (97, 321)])
+def test_set_boundary_segment_and_chunk_edges(ctx, rows, cols):
+    H, W = rows + 9, cols + 11
+    for seed, pn in ((1, 0.2), (2, 0.8), (3, 0.0)):
+        d, m = _maps(rows * 1000 + cols + seed, H, W, p_nomatch=pn)
+        if seed == 3:
+            m[:] = 255          # long unbroken runs: the scans' carries cross every chunk / segment
+            d[:] = NOMATCH
+            d[H // 2, 5 + cols // 2] = 3
+        own = (4, 4 + rows - 1, 5, 5 + cols - 1, cols, rows)
+        oth = (3, H - 3, 7, W - 4, W - 10, H - 5)
+        s1, BLg, BRg = ctx.set_boundary_smooth(d, m, own, oth)
+        s2, BLo, BRo = orc.set_boundary_smooth(d, m, own, oth)
+        assert s1 == s2 == 0
+        sel = np.zeros((H, W), bool)
+        sel[own[0]:own[1] + 1, own[2]:own[3] + 1] = True
+        assert np.array_equal(BLg[sel], BLo[sel]), (rows, cols, seed)
+        assert np.array_equal(BRg[sel], BRo[sel]), (rows, cols, seed)
+
+
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 128, 129, 500])
+def test_order_constraint_component_shapes(ctx, n):
+    """Rows with exactly n valid pixels: sorted (no component), one outlier tying everything together (a component
+    longer than the lane-per-component limit), many small components, and a flat run with ties."""
+    W, H = n + 40, 12
+    rng = np.random.default_rng(n)
+    d = np.full((H, W), NOMATCH, np.int16)
+    xs = np.arange(10, 10 + n)
+    d[2, xs] = 3                                   # m = x + 3: strictly increasing
+    d[3, xs] = 3
+    d[3, xs[0]] = min(n + 20, 600)                 # one far-reaching outlier at the start
+    d[4, xs] = 3
+    d[4, xs[-1]] = -min(n + 20, 600)               # ... and one at the end (crosses everything before it)
+    d[5, xs] = (rng.integers(0, 2, n) * 3).astype(np.int16)        # small local inversions
+    d[6, xs] = (-xs + xs[0]).astype(np.int16)                       # m constant: no strict inversion at all
+    d[7, xs] = (-xs + xs[0] + rng.integers(0, 3, n)).astype(np.int16)  # nearly flat: ties and crossings everywhere
+    d[8, xs[::2]] = rng.integers(-8, 9, len(xs[::2])).astype(np.int16)  # holes between valid pixels
+    own = (1, H - 2, 4, W - 5, W - 8, H - 2)
+    a, b = ctx.order_constraint(d, own), orc.order_constraint(d, own)
+    assert np.array_equal(a, b), [(y, int((a[y] != b[y]).sum())) for y in range(H) if (a[y] != b[y]).any()]
+
+
+def test_smooth_and_median_at_margin_borders(ctx):
+    for seed in range(3):
+        H, W = 37, 151
+        d, m = _maps(700 + seed, H, W, p_nomatch=0.25)
+        # FindMargin keeps every margin at least MatchBlockRadius >= 1 pixels inside the image (.cpp:1011-1038)
+        for own in ((1, H - 2, 1, W - 2, W - 2, H - 2), (2, H - 3, 3, W - 4, W - 6, H - 4), (5, 9, 70, 80, 11, 5)):
+            assert np.array_equal(ctx.median_filter(d, m, own), orc.median_filter(d, m, own)), own
+            assert np.array_equal(ctx.smooth_constraint(d, own), orc.smooth_constraint(d, own)), own
+
+
+def test_rematch_sparse_path_random(ctx):
+    """Rematch on a map with many holes: the per-row lists, the sparse NCC kernel and intervals of every width."""
+    cfg = synth.config_small(160, 96, 2, radius=2, pair=11)
+    img, msk = cfg.image, cfg.mask
+    r = 2
+    H, W = msk[0].shape
+    mg0 = orc.find_margin(msk[0], r).astuple()
+    mg1 = orc.find_margin(msk[1], r).astuple()
+    rng = np.random.default_rng(5)
+    for pn in (0.02, 0.3, 0.9):
+        d = rng.integers(-6, 7, size=(H, W)).astype(np.int16)
+        d[rng.random((H, W)) < pn] = NOMATCH
+        so, do = orc.rematch(img[0], img[1], msk[0], msk[1], r, mg0, mg1, d)
+        sg, dg = ctx.rematch(img[0], img[1], msk[0], msk[1], r, mg0, mg1, d)
+        assert so == sg == 0
+        assert np.array_equal(dg, do), (pn, int((dg != do).sum()))
+
+
+@pytest.mark.parametrize("ksize", [1, 2, 5, 8, 9, 17, 40])
+def test_cloud_erosion_with_holes(ctx, ksize):
+    """Binary erosion test of DisparityToCloud on a mask with holes and border contact (batches of 8 span rows, the
+    clean-block quick accept)."""
+    rng = np.random.default_rng(ksize)
+    H, W = 90, 140
+    m = np.full((H, W), 255, np.uint8)
+    m[:3] = 0
+    m[:, -2:] = 7
+    for _ in range(6):
+        y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+        m[y:y + int(rng.integers(1, 9)), x:x + int(rng.integers(1, 9))] = int(rng.integers(0, 255))
+    e = orc.erode_ellipse(m, ksize)
+    g = ctx.erode_ellipse_is255(m, ksize)
+    assert np.array_equal(g == 255, e == 255)
