@@ -105,3 +105,27 @@ def test_cloud_erosion_with_holes(ctx, ksize):
     e = orc.erode_ellipse(m, ksize)
     g = ctx.erode_ellipse_is255(m, ksize)
     assert np.array_equal(g == 255, e == 255)
+
+
+# ---- DisparityRefine: margins around the kernel's 256-column x 4-row workgroups, random textures ------------------
+@pytest.mark.parametrize("rows,cols,iters", [(3, 5, 7), (4, 9, 30), (6, 258, 12), (7, 255, 9), (11, 300, 30), (33, 64, 60)])
+def test_refine_block_edges(ctx, rows, cols, iters):
+    """Margins whose interior is 1 x 3 pixels up to just over one workgroup: every pixel count of the last row group,
+    pixels with a single valid neighbour pair (modes 1 / 2), isolated ones (mode 0), both disparity signs.
+    fp64: the stated 1e-5 relative tolerance of test_gpu_parity (identical operation order, device exp / sqrt)."""
+    H, W = rows + 6, cols + 8
+    rng = np.random.default_rng(rows * 100 + cols)
+    base = rng.integers(0, 256, size=(H, W + 8, 3)).astype(np.uint8)
+    img0 = np.ascontiguousarray(base[:, 4:W + 4])
+    img1 = np.ascontiguousarray(base[:, 2:W + 2])      # view 1 = view 0 shifted by 2: a real minimum near d = -2 / +2
+    for sign in (+1, -1):
+        d = (sign * 2 + rng.integers(-1, 2, size=(H, W))).astype(np.int16)
+        d[rng.random((H, W)) < 0.25] = NOMATCH
+        own = (3, 3 + rows - 1, 4, 4 + cols - 1, cols, rows)
+        a = ctx.disparity_refine(d, img0, img1, iters, 0.03, own)
+        b = orc.disparity_refine(d, img0, img1, iters, 0.03, own)
+        na, nb = a == NOMATCH, b == NOMATCH
+        assert np.array_equal(na, nb)
+        v = ~na
+        err = np.abs(a[v] - b[v]) / np.maximum(1.0, np.abs(b[v]))
+        assert err.size == 0 or err.max() <= 1e-5, (rows, cols, sign, float(err.max()))
