@@ -102,3 +102,34 @@ def test_mirror_rectifies_from_raw_inputs(ctx, raw):
     assert np.array_equal(sm.Q, o["Q"]) and np.array_equal(data.cam[0][1].P, o["P"][1])
     assert np.array_equal(data.cam[0][0].mask, o["mask"][0]) and data.cam[0][0].bound is not None
     assert sm.last_result.n_points > 1000
+
+
+def test_cli_config_to_ply(ctx, tmp_path):
+    """python -m reconstruction_amd config.yml: configuration + calibration + image files -> Rectify -> MatchAllLayer ->
+    PLY of the cloud, the reference's main() (main.cpp:5-23) without CloudOptimization::run."""
+    from PIL import Image
+    from reconstruction_amd import config as cfgmod
+    from reconstruction_amd.__main__ import main
+    raw = synth.make_raw_pair(baseline=-150.0)
+    root = str(tmp_path) + "/"
+    (tmp_path / "mask").mkdir()
+    for j in range(2):
+        Image.fromarray(raw["image"][j][:, :, ::-1]).save(root + "0001_Cam%d.png" % j)   # files are RGB, arrays BGR
+        Image.fromarray(raw["mask"][j]).save(root + "mask/0001_Cam%d.png" % j)
+    cfgmod.dump_opencv_yaml(root + "calib_camera.yml", {"intrinsic-0": raw["K"][0], "extrinsic-0": raw["E"][0],
+                                                         "intrinsic-1": raw["K"][1], "extrinsic-1": raw["E"][1]})
+    cfgmod.dump_opencv_yaml(root + "config.yml", {
+        "filepath": root, "outfilename": root + "out", "isoutput": 0, "camera_calib_name": "calib_camera.yml",
+        "PyrmNum": raw["pyr_levels"], "LowestLevelWidth": raw["lowest"][0], "LowestLevelHeight": raw["lowest"][1],
+        "imagelist": ["0001_Cam%d.png" % j for j in range(2)], "masklist": ["mask\\0001_Cam%d.png" % j for j in range(2)],
+        "camID": np.array([[0, 1]], np.uint8)})
+    assert main([root + "config.yml"]) == 0
+    head = open(root + "out.ply", "rb").read(400).decode("latin1")
+    assert head.startswith("ply") and "element vertex" in head
+    n = int(head.split("element vertex")[1].split()[0])
+    o = orc.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"])
+    W, H = o["mask"][0].shape[1], o["mask"][0].shape[0]
+    cfg = synth.PairConfig(width=W, height=H, pyr_levels=raw["pyr_levels"], radius=2, ws=0.03, offset=2,
+                           origin_width=raw["origin"][0], image=o["image"], mask=o["mask"], Q=o["Q"],
+                           R_final=o["R_final"], T_final=o["T_final"])
+    assert n == orc.match_pair(cfg)["n_points"] and n > 1000

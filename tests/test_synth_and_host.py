@@ -104,3 +104,12 @@ def test_config_and_calibration_loader(tmp_path):
     import pytest
     with pytest.raises(FileNotFoundError):
         cfgmod.load_config(root + "nope.yml")
+
+
+def test_cli_reports_a_missing_configuration_like_the_reference(tmp_path, capsys):
+    """python -m reconstruction_amd: 'cannot open file ...' and a non-zero exit (CReconstruction.cpp:9-13), before
+    anything touches the GPU."""
+    from reconstruction_amd.__main__ import main
+    rc = main([str(tmp_path / "nope.yml")])
+    assert rc != 0
+    assert "cannot open file" in capsys.readouterr().out
