@@ -176,6 +176,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_refine_sweep<1> (DisparityRefine Jacobi sweep, top level)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         # the same launch priced on its MEASURED HBM bytes (PMC): how close the kernel runs to the
+                         # memory system's rate, as opposed to how many of those bytes the algorithm needs
+                         "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
+                         "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_ms > 0 else None,
                          "avg_launch_ms": round(avg_ms, 5), "launches_timed_per_step": launches // args.steps,
                          "launches_per_step": stage_prof["refine_sweep_top"]["launches"] - 1,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
