@@ -341,3 +341,16 @@ def rectify_pair(K, E, origin_size, lowest_size, N, imgs, msks):
                            int(lowest_size[0]), int(lowest_size[1]), int(N), arr(imgs), arr(msks), arr(rimg), arr(rmsk),
                            _p(Q), _p(Rf), _p(Tf), arr(P))
     return dict(image=rimg, mask=rmsk, Q=Q, R_final=Rf, T_final=Tf, P=P)
+
+
+def exp_neg(t: float) -> float:
+    """The specified exp(-t) of the refine weights (stereo_oracle.c: orc_exp_neg)."""
+    L = lib()
+    L.orc_exp_neg.restype = C.c_double
+    L.orc_exp_neg.argtypes = [C.c_double]
+    return float(L.orc_exp_neg(float(t)))
+
+
+def set_exp_mode(libm: int) -> None:
+    """1: the refine weights use the host libm's exp instead of the specified one (sensitivity experiments only)."""
+    lib().orc_set_exp_mode(int(libm))

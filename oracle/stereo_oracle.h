@@ -18,6 +18,8 @@
  *   - Everything else (stages that allocate cv::Mat, pyrDown, erode): PARITY
  *     UNPINNED -- restated line by line from the source, checked only by
  *     known-answer tests derivable from the code.
+ *   - DisparityRefine's exp() is evaluated by a fully specified routine shared with the GPU kernels (orc_exp_neg;
+ *     the C runtime's exp the reference calls is not bit-specified), see stereo_oracle.c.
  */
 #ifndef STEREO_ORACLE_H
 #define STEREO_ORACLE_H
@@ -137,6 +139,10 @@ void orc_remap_linear_u8(const uint8_t *src, int Ws, int Hs, int C, const int16_
 void orc_rectify_pair(const double *K0, const double *K1, const double *E0, const double *E1, int originW, int originH,
                       int lowW, int lowH, int N, const uint8_t *const img[2], const uint8_t *const msk[2],
                       uint8_t *rimg[2], uint8_t *rmsk[2], double *Q, double *R_final, double *T_final, double *Pout[2]);
+
+/* the fully specified exp(-t) of the refine weights (see stereo_oracle.c); mode 1 = host libm instead */
+double orc_exp_neg(double t);
+void orc_set_exp_mode(int libm);
 
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

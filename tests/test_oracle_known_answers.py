@@ -149,3 +149,21 @@ def test_truncation_asymmetry_for_negative_disparities():
         return float(np.mean(d[ok] - cfg.true_disparity[ok]))
     assert abs(bias(pos, 0)) < 0.3
     assert bias(neg, 1) < -0.5
+
+
+def test_specified_exp_is_a_faithful_exp():
+    """orc_exp_neg (the fully specified exp(-t) the oracle and the GPU kernels share): within 1 ulp of the host libm on
+    a dense sample incl. the subnormal range, exact at 0, 0 beyond the underflow threshold."""
+    import math
+    import struct
+    rng = np.random.default_rng(0)
+    ts = np.concatenate([rng.random(60000) * 2, rng.random(30000) * 40, rng.random(20000) * 800,
+                         10.0 ** rng.uniform(-12, 0, 10000), np.arange(0, 130, 1.0),
+                         [0.0, 1e-9, 0.34657359027997264, 0.3465735902799727, 708.3, 709.0, 710.0, 745.0, 745.13, 745.2]])
+    worst = 0
+    for t in ts:
+        a, b = orc.exp_neg(float(t)), math.exp(-float(t))
+        ia, ib = struct.unpack("<q", struct.pack("<d", a))[0], struct.unpack("<q", struct.pack("<d", b))[0]
+        worst = max(worst, abs(ia - ib))
+    assert worst <= 1
+    assert orc.exp_neg(0.0) == 1.0 and orc.exp_neg(746.0) == 0.0 and orc.exp_neg(1e300) == 0.0
