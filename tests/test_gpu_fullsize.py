@@ -1,6 +1,6 @@
-"""Full-size (BASELINE.json C2: 4096x3072, 5 levels, 11x11 NCC) checks on the GPU path through properties that
-need no CPU oracle run (the oracle would take ~20 minutes at this size): a pure integer-shift scene, exact
-repeatability, margin / count invariants, cloud geometry."""
+"""Full-size (BASELINE.json C2: 4096x3072, 5 levels, 11x11 NCC) checks on the GPU path: size-independent properties (a
+pure integer-shift scene, exact repeatability, margin / count invariants, cloud geometry) and -- about 45 s of oracle time
+on the box's host cores -- the bench workload itself against the whole-pair CPU oracle, bit for bit."""
 import numpy as np
 import pytest
 
@@ -98,3 +98,20 @@ def test_fullsize_c2_workload_invariants(ctx):
         x1 = x0 + cfg.true_disparity[ys[sel], np.clip(np.rint(x1).astype(np.int64), 0, W - 1)]
     err = np.abs(d0[ys[sel], xs[sel]] - (x1 - x0))
     assert np.median(err) < 0.5 and np.percentile(err, 95) < 1.5, (np.median(err), np.percentile(err, 95))
+
+
+def test_fullsize_c2_equals_the_oracle_bit_for_bit(ctx):
+    """The bench workload itself (C2: 4096x3072, 5 levels, 11x11 NCC, 420 refine sweeps per direction) against the whole-
+    pair CPU oracle: margins, V_top, both fp64 disparity maps and the cloud's order and colours identical, XYZ to 1e-12.
+    About a minute of oracle time on the box's host cores."""
+    from oracle import oracle as orc
+    cfg = synth.config_c2(pair=0)
+    ref = orc.match_pair(cfg)
+    res = ctx.match_pair(cfg)
+    assert res.margin == ref["margin"] and res.v_top == ref["v_top"] == 5767168
+    for v in range(2):
+        assert np.array_equal(res.disparity[v], ref["disparity"][v]), (v, int((res.disparity[v] != ref["disparity"][v]).sum()))
+    assert res.n_points == ref["n_points"] and np.array_equal(res.bgr, ref["bgr"])
+    fin = np.isfinite(ref["xyz"])
+    assert np.array_equal(np.isfinite(res.xyz), fin)
+    assert np.allclose(res.xyz[fin], ref["xyz"][fin], rtol=1e-12, atol=1e-9)
