@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W, H = a.H;
     const int x = d.own.XL + 1 + blockIdx.x * 256 + (int)threadIdx.x;
-    const int y0 = d.own.YL + 1 + blockIdx.y * RF_PPT;
-    const int ylast = d.own.YR - 1;
+    const int y0 = max(d.own.YL + 1, a.row_lo) + blockIdx.y * RF_PPT; // rows [row_lo, row_hi) of the interior
+    const int ylast = min(d.own.YR - 1, a.row_hi - 1);
     if (y0 > ylast) return; // uniform
     const bool colok = x <= d.own.XR - 1;
     const int xs = colok ? x : d.own.XL + 1; // out-of-range lanes shadow a valid column (no stores)
@@ -405,11 +405,17 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     }
 }
 
-// One sweep f64_a -> f64_b (a.flag2 = sweep index, a.flag = top level); ev0 / ev1 (optional) bracket the launch.
+// One sweep f64_a -> f64_b (a.flag2 = sweep index, a.flag = top level) over the interior rows [a.row_lo, a.row_hi)
+// (the first sweep always covers the whole interior); ev0 / ev1 (optional) bracket the launch.
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int rows = 0, cols = 0;
     for (int v = 0; v < a.ndir; v++) {
-        rows = max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
+        int lo = a.d[v].own.YL + 1, hi = a.d[v].own.YR; // interior rows [lo, hi)
+        if (a.flag2 != 0) {
+            lo = max(lo, a.row_lo);
+            hi = min(hi, a.row_hi);
+        }
+        rows = max(rows, hi - lo);
         cols = max(cols, a.d[v].own.XR - a.d[v].own.XL - 1);
     }
     if (rows <= 0 || cols <= 0) return;

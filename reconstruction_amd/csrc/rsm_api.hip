@@ -10,6 +10,7 @@
 
 #include <algorithm>
 
+#include <limits.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -97,6 +98,8 @@ struct rsm_ctx {
 
     // options (rsm_set_option)
     int opt_ncc_bytes = 0;
+    int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
+    int opt_refine_band_rows = 0; // > 0: band height in rows, overrides refine_band_mb (tests)
 
     // profiling
     bool profile = false;
@@ -364,6 +367,8 @@ static void prof_end(rsm_ctx *c, int slot, int stage, int launches, double bytes
 extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
+    else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
+    else if (!strcmp(name, "refine_band_rows")) c->opt_refine_band_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
     return RSM_OK;
 }
@@ -400,6 +405,8 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.rf_list = c->rf_list;
     a.ncc_cnt = c->rf_cnt + k; // a counter per level, zeroed together at the start of the run
     a.rf_stride = c->cap_px;
+    a.row_lo = 0;
+    a.row_hi = INT_MAX;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
     for (int v = 0; v < 2; v++) {
         DirArgs &d = a.d[v];
@@ -427,6 +434,85 @@ static StageArgs level_args(rsm_ctx *c, int k) {
 }
 
 static bool degenerate(const Mg &m) { return m.YL >= m.YR || m.XL >= m.XR; } // .cpp:827
+
+// DisparityRefine's Jacobi sweeps (.cpp:590-678): sweep t reads A (t even) or B (t odd) and writes the other.
+//
+// Band schedule (options refine_band_mb / refine_band_rows; off by default).  A sweep streams 52 B per pixel (state
+// in and out + the data-term cache entries) and a level's sweeps re-stream the same arrays 30..150 times, 0.3-0.6 GB
+// per sweep at the large levels.  The sweeps can be time-skewed over bands of rows: band j performs ALL sweeps
+// 1..iters-1 on itself before band j+1 starts, its row window sliding up one row per sweep, rows
+// [Y0 + j*B - u, Y0 + (j+1)*B - u) at step u.  A Jacobi update of row y in sweep t needs rows y-1..y+1 of sweep
+// t-1: row y+1 lies in the same band's previous window, row y-1 at the window's upper edge in band j-1, which has
+// finished; and nothing a later launch still needs is overwritten (the two ping-pong buffers hold sweep t-1 / t
+// of exactly the rows the sliding window covers).  So the values are those of whole-frame sweeps, bit for bit
+// (tests/test_gpu_parity.py::test_refine_band_schedule_is_bit_identical) while a band's working set stays in the
+// 256 MB Infinity Cache.  MEASURED (C2, round 2): no gain -- 48 / 96 / 144 / 192 MB bands run the level in 30.2 /
+// 23.1 / 20.2 / 19.4 ms against 19.1 ms whole-frame.  tests/micro/wsbw.hip shows why: a working set that fits the
+// Infinity Cache streams at 6.0-6.5 TB/s (read) against 5.3 TB/s from HBM -- the fabric between the XCD L2s and
+// the memory side is the limit either way -- and the shorter launches lose more than that 15 percent.
+static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double *const bufB[2], int iters,
+                         hipStream_t st, bool top) {
+    int launches = 0;
+    auto bind = [&](int t) {
+        for (int v = 0; v < a.ndir; v++) {
+            a.d[v].f64_a = (t & 1) ? bufB[v] : bufA[v];
+            a.d[v].f64_b = (t & 1) ? bufA[v] : bufB[v];
+        }
+        a.flag2 = t;
+    };
+    auto launch = [&](int lo, int hi) {
+        a.row_lo = lo;
+        a.row_hi = hi;
+        if (c && c->profile && top && (launches & 7) == 4) { // every 8th launch of the dominant kernel
+            const int es = prof_slot(c, ST_REFINE_LIGHT_TOP);
+            launch_refine_sweep(a, st, c->evpool[es].a, c->evpool[es].b);
+            double bytes = 0; // 16 B per interior pixel of the window (fp64 read + write per sweep)
+            for (int v = 0; v < a.ndir; v++) {
+                const int r0 = std::max(a.d[v].own.YL + 1, lo), r1 = std::min(a.d[v].own.YR, hi);
+                if (r1 > r0) bytes += 16.0 * (r1 - r0) * (a.d[v].own.XR - a.d[v].own.XL + 1);
+            }
+            c->prof_launches[ST_REFINE_LIGHT_TOP] += 1;
+            c->prof_bytes[ST_REFINE_LIGHT_TOP] += bytes;
+        } else {
+            launch_refine_sweep(a, st);
+        }
+        launches++;
+    };
+    if (iters <= 0) return 0;
+    int Y0 = INT_MAX, Y1 = INT_MIN; // interior rows [Y0, Y1) over the directions
+    double row_bytes = 0;
+    for (int v = 0; v < a.ndir; v++) {
+        Y0 = std::min(Y0, a.d[v].own.YL + 1);
+        Y1 = std::max(Y1, a.d[v].own.YR);
+        row_bytes += 52.0 * (a.d[v].own.XR - a.d[v].own.XL + 1);
+    }
+    bind(0);
+    a.row_lo = 0;
+    a.row_hi = INT_MAX;
+    launch_refine_sweep(a, st); // k_refine_first: whole interior
+    launches++;
+    const int nsw = iters - 1;
+    int B = 0;
+    if (c && c->opt_refine_band_rows > 0) B = c->opt_refine_band_rows;
+    else if (c && c->opt_refine_band_mb > 0) B = std::max(4 * RF_PPT, (int)((double)c->opt_refine_band_mb * 1048576.0 / row_bytes) & ~(RF_PPT - 1));
+    if (B <= 0 || B >= Y1 - Y0 || nsw < 2) { // whole-frame sweeps
+        for (int t = 1; t < iters; t++) {
+            bind(t);
+            launch(0, INT_MAX);
+        }
+    } else {
+        for (int j = 0; Y0 + j * B - (nsw - 1) < Y1; j++)
+            for (int u = 0; u < nsw; u++) {
+                const int lo = std::max(Y0 + j * B - u, Y0), hi = std::min(Y0 + (j + 1) * B - u, Y1);
+                if (lo >= hi) continue;
+                bind(u + 1);
+                launch(lo, hi);
+            }
+    }
+    a.row_lo = 0;
+    a.row_hi = INT_MAX;
+    return launches;
+}
 
 extern "C" int rsm_run_pair(rsm_ctx *c) {
     if (!c) return RSM_E_INVALID;
@@ -582,31 +668,11 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         prof_end(c, ps11, ST_REFINE_INIT, 1, 12.0 * Pk);
         const int st_sweep = (k == N - 1) ? ST_REFINE_SWEEP_TOP : ST_REFINE_SWEEP;
         const int ps12 = prof_begin(c, st_sweep);
-        int cur = ia, nxt = ib;
         a.flag = (k == N - 1);
-        for (int v = 0; v < 2; v++) {
-            a.d[v].f64_a = c->f64[cur][v];
-            a.d[v].f64_b = c->f64[nxt][v];
-        }
-        for (int it = 0; it < iters; it++) {
-            for (int v = 0; v < 2; v++) {
-                a.d[v].f64_a = c->f64[cur][v];
-                a.d[v].f64_b = c->f64[nxt][v];
-            }
-            a.flag2 = it;
-            if (c->profile && k == N - 1 && (it & 7) == 4) { // every 8th launch of the dominant kernel
-                const int es = prof_slot(c, ST_REFINE_LIGHT_TOP);
-                launch_refine_sweep(a, st, c->evpool[es].a, c->evpool[es].b);
-                c->prof_launches[ST_REFINE_LIGHT_TOP] += 1;
-                c->prof_bytes[ST_REFINE_LIGHT_TOP] += 32.0 * Pk;
-            } else {
-                launch_refine_sweep(a, st);
-            }
-            const int t = cur;
-            cur = nxt;
-            nxt = t;
-        }
-        prof_end(c, ps12, st_sweep, iters, 32.0 * Pk * iters); // one launch per sweep
+        double *bufA[2] = {c->f64[ia][0], c->f64[ia][1]}, *bufB[2] = {c->f64[ib][0], c->f64[ib][1]};
+        const int nlaunch = refine_sweeps(c, a, bufA, bufB, iters, st, k == N - 1);
+        const int cur = (iters & 1) ? ib : ia; // sweep t reads (t even ? ia : ib) and writes the other
+        prof_end(c, ps12, st_sweep, nlaunch, 32.0 * Pk * iters);
 
         // ---- UniquenessContraint<double> (.cpp:109) on the refined maps (now in f64[cur])
         const int ps13 = prof_begin(c, ST_UNIQ64);
@@ -826,6 +892,8 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
 StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, const rsm_boundary *oth) {
     StageArgs a{};
     a.opt_ncc_bytes = c->opt_ncc_bytes;
+    a.row_lo = 0;
+    a.row_hi = INT_MAX;
     a.ndir = 1;
     a.W = W;
     a.H = H;
@@ -1022,13 +1090,9 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.img4_own = i4o;
     d.img4_oth = i4t;
     launch_refine_init(a, c->stream);
-    for (int it = 0; it < iterations; it++) {
-        a.flag2 = it;
-        launch_refine_sweep(a, c->stream);
-        double *x = d.f64_a;
-        d.f64_a = d.f64_b;
-        d.f64_b = x;
-    }
+    double *bufA[2] = {A, nullptr}, *bufB[2] = {B, nullptr};
+    refine_sweeps(c, a, bufA, bufB, iterations, c->stream, false);
+    d.f64_a = (iterations & 1) ? B : A; // the buffer the last sweep wrote
     t.down(disp_out, (const double *)d.f64_a, px);
     return finish(c, t);
 }

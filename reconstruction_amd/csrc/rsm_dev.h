@@ -47,6 +47,7 @@ struct StageArgs {
     double ws;   // m_ws
     int flag;    // stage-specific
     int flag2;   // refine: sweep index
+    int row_lo, row_hi; // refine sweep: only rows [row_lo, row_hi) of the interior are updated (band schedule, k_refine.hip)
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch

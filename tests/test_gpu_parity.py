@@ -340,3 +340,25 @@ def test_libm_exp_sensitivity(ctx):
     print("libm exp: max rel after 20 sweeps %.2e, after %d sweeps %.2e (%d of %d pixels above 1e-9)"
           % (e20.max(), q["iters"], e.max(), int((e > 1e-9).sum()), int(ok.sum())))
     assert e20.max() < 1e-12 and e.max() < 0.1
+
+
+@pytest.mark.parametrize("rows", [5, 16, 23, 64])
+def test_refine_band_schedule_is_bit_identical(ctx, rows):
+    """DisparityRefine's sweeps run time-skewed over bands of rows so that a band stays in the Infinity Cache
+    (rsm_api.hip: refine_sweeps).  Whatever the band height -- including heights that are no multiple of the
+    4-row thread tile and bands shorter than the number of sweeps -- the result is the whole-frame Jacobi
+    iteration of CStereoMatching.cpp:590-678, bit for bit."""
+    cfg, rec, fin = stages("s512x384_5levels")
+    ctx.set_option("refine_band_rows", rows)
+    try:
+        for q in rec:
+            if q["stage"] != "refine" or q["level"] < 2:
+                continue
+            k, v = q["level"], q["v"]
+            g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], q["iters"], cfg.ws, q["mg"][v])
+            assert np.array_equal(g, q["out"]), diff_report("banded refine rows=%d L%d v%d" % (rows, k, v), g, q["out"])
+        res = ctx.match_pair(cfg)
+        for v in range(2):
+            assert np.array_equal(res.disparity[v], fin["disparity"][v])
+    finally:
+        ctx.set_option("refine_band_rows", 0)
