@@ -9,7 +9,13 @@
 //   score = (n*Sab - Sa*Sb) / sqrt((n*Saa - Sa^2) * (n*Sbb - Sb^2)),   zero variance -> 0
 // with Sa,Saa,Sb,Sbb from the per-level tables (k_pyramid.hip) and Sab accumulated in int32
 // from LDS-staged rows of both views; one fp64 divide+sqrt per candidate; strict '>' from -1
-// in ascending column order, exactly as the reference.
+// in ascending column order.  That integer form is the FILTER: its value is within a few ulp of the true
+// score, the reference's within ~n ulp of it (fixed-order fp64 sums), so whenever the winner is not ahead of
+// every other candidate (and of the initial -1) by NCC_TIE_TOL the reference's last-bit rounding may pick
+// another column.  Such pixels are appended to a tie list and re-evaluated by k_ncc_exact, a
+// reference-order fp64 restatement of WindowToVec + arma::dot (CManageData.cpp:81-90, op_dot_meat.hpp:20-55),
+// which overwrites their result: the chosen column is the reference's on few-level, saturated and periodic
+// textures too (tests/test_gpu_ncc_ties.py).
 #include "rsm_dev.h"
 
 #include <stdlib.h>
@@ -107,6 +113,55 @@ void launch_hl_interval(const StageArgs &a, hipStream_t st) {
 // ---------------------------------------------------------------- NCC interval argmax
 #define NCC_TX 256  // pixels of one row per block
 #define NCC_CH 384  // candidate columns staged per pass
+// |integer-form score - reference fp64 score| < 1e-12 for every radius <= 15 (n <= 2883 terms of relative 1.1e-16);
+// two candidates closer than this in integer form are decided by k_ncc_exact
+#define NCC_TIE_TOL 1e-11
+
+// Running best of the strict '>' scan (.cpp:213) over integer-form scores.  `exact`: the score is the reference's to
+// the last bit (a zero-variance window scores exactly 0 there too: u = 0 everywhere, CManageData.cpp:86-89, and the
+// initial -1 is a constant); a (near) tie between two such scores needs no second opinion.
+struct NccBest {
+    double v;
+    int c;
+    bool exact;
+    bool tie;
+};
+__device__ __forceinline__ void ncc_offer(NccBest &b, double sc, int c, bool exact) {
+    if (fabs(sc - b.v) <= NCC_TIE_TOL && !(exact && b.exact)) b.tie = true;
+    if (sc > b.v) { // .cpp:213
+        b.v = sc;
+        b.c = c;
+        b.exact = exact;
+    }
+}
+// Filter score (n Sab - Sa Sb) / sqrt(va vb) of one candidate, va = n Saa - Sa^2 > 0 of the own window given as a
+// double.  Every integer here is below 2^53, so the fp64 products and differences are exact; 1/sqrt is the
+// hardware estimate plus one Newton step (relative error ~2e-16) -- four times cheaper than a correctly rounded
+// sqrt and divide, and the filter only has to be within NCC_TIE_TOL / 2 of the reference's score.
+// Zero variance on either side -> exactly 0, as in the reference; *exact tells the caller so.
+__device__ __forceinline__ double ncc_filter_score(double nd, uint32_t Sab, double Sa, double va, int Sb, int Sbb, bool *exact) {
+    const double sb = (double)Sb;
+    const double vb = nd * (double)Sbb - sb * sb;
+    const double num = nd * (double)Sab - Sa * sb;
+    const double p = va * vb;
+    const bool nz = va > 0.0 && vb > 0.0;
+    double r = __builtin_amdgcn_rsq(nz ? p : 1.0);
+    const double e = __builtin_fma(-(p * r), r, 1.0);
+    r = __builtin_fma(0.5 * r, e, r);
+    *exact = !nz;
+    return nz ? num * r : 0.0;
+}
+// appends the pixels of this wave whose scan saw a (near) tie to the tie list of k_ncc_exact
+__device__ __forceinline__ void ncc_tie_append(const StageArgs &a, int cnt_slot, bool tie, uint32_t entry) {
+    const unsigned long long mm = __ballot(tie);
+    if (mm) {
+        const int lane = threadIdx.x & 63, leader = __builtin_ctzll(mm);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(a.tie_cnt + cnt_slot, __popcll(mm));
+        base = __shfl(base, leader);
+        if (tie) a.tie_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = entry;
+    }
+}
 
 // Generic-radius fallback (byte-wise LDS reads); radii 1..7 use k_ncc_dot4 below.
 __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int strideA, int strideB) {
@@ -171,15 +226,12 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int
             }
         }
     }
-    int Sa = 0, Saa = 0;
-    long long va = 0;
+    double Sa = 0.0, va = 0.0;
     if (active) {
-        Sa = d.S1_own[pix];
-        Saa = d.S2_own[pix];
-        va = (long long)n * Saa - (long long)Sa * Sa;
+        Sa = (double)d.S1_own[pix];
+        va = (double)n * (double)d.S2_own[pix] - Sa * Sa;
     }
-    int best = -1;
-    double bestv = -1.0;
+    NccBest bb{-1.0, -1, true, false};
     const uint8_t *mq = d.mask_oth + (size_t)y * W;
     const int aoff = threadIdx.x * 3;
 
@@ -210,20 +262,14 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int
                     const uint8_t *pb = sB + j * strideB + boff;
                     for (int i = 0; i < ws * 3; i++) Sab += (int)pa[i] * (int)pb[i];
                 }
-                const int Sb = d.S1_oth[(size_t)y * W + c];
-                const int Sbb = d.S2_oth[(size_t)y * W + c];
-                const long long vb = (long long)n * Sbb - (long long)Sb * Sb;
-                const long long num = (long long)n * Sab - (long long)Sa * Sb;
-                double score = 0.0;
-                if (va > 0 && vb > 0) score = (double)num / sqrt((double)va * (double)vb);
-                if (score > bestv) { // .cpp:213
-                    bestv = score;
-                    best = c;
-                }
+                bool ex;
+                const double sc = ncc_filter_score((double)n, (uint32_t)Sab, Sa, va, d.S1_oth[(size_t)y * W + c], d.S2_oth[(size_t)y * W + c], &ex);
+                ncc_offer(bb, sc, c, ex);
             }
         }
     }
-    if (active && best != -1) d.d16_out[pix] = (int16_t)(best - x); // .cpp:219-222 / 301-302 / 563-564
+    if (active && bb.c != -1) d.d16_out[pix] = (int16_t)(bb.c - x); // .cpp:219-222 / 301-302 / 563-564
+    ncc_tie_append(a, mode == 2, active && bb.tie, (uint32_t)pix | ((uint32_t)blockIdx.z << 31));
 }
 
 // ---------------------------------------------------------------- NCC interval argmax, v_dot4_u32_u8
@@ -239,25 +285,18 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int
 #define NCC_G 5
 #define NCC_WIDE 160
 
-// (score, column) of candidate group c0..c0+G-1 given the G accumulated Sab; strict '>' in ascending order
+// offers the candidate group c0..c0+G-1 (their G accumulated Sab) to the running best, ascending columns
 template <int R>
 __device__ __forceinline__ void ncc_score_group(const uint32_t (&acc)[NCC_G], int c0, int cend, const uint8_t *mk,
-                                                const int32_t *s1, const int32_t *s2, int Sa, long long va,
-                                                double &bv, int &bc) {
+                                                const int32_t *s1, const int32_t *s2, double Sa, double va, NccBest &b) {
     constexpr int n = (2 * R + 1) * (2 * R + 1) * 3;
 #pragma unroll
     for (int g = 0; g < NCC_G; g++) {
         const int c = c0 + g;
         if (c > cend || mk[g] != 255) continue; // .cpp:209
-        const int Sb = s1[g];
-        const int Sbb = s2[g];
-        const long long vb = (long long)n * Sbb - (long long)Sb * Sb;
-        const long long num = (long long)n * (long long)acc[g] - (long long)Sa * Sb;
-        const double sc = (va > 0 && vb > 0) ? (double)num / sqrt((double)va * (double)vb) : 0.0;
-        if (sc > bv) { // .cpp:213
-            bv = sc;
-            bc = c;
-        }
+        bool ex;
+        const double sc = ncc_filter_score((double)n, acc[g], Sa, va, s1[g], s2[g], &ex);
+        ncc_offer(b, sc, c, ex);
     }
 }
 
@@ -339,14 +378,12 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
 #pragma unroll
         for (int j = 0; j < WS; j++) sA[j * SA + i] = v[j];
     }
-    int Sa = 0;
-    long long va = 0;
+    double Sa = 0.0, va = 0.0;
     if (narrow) {
-        Sa = d.S1_own[pix];
-        va = (long long)n * d.S2_own[pix] - (long long)Sa * Sa;
+        Sa = (double)d.S1_own[pix];
+        va = (double)n * (double)d.S2_own[pix] - Sa * Sa;
     }
-    int best = -1;
-    double bestv = -1.0;
+    NccBest bb{-1.0, -1, true, false};
     for (int lo = cmin; lo <= cmax; lo += NCC_CH) {
         const int hi = min(lo + NCC_CH - 1, cmax);
         __syncthreads();
@@ -390,11 +427,12 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
 #pragma unroll
                         for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_udot4(av[m], bw[g + m], acc[g], false);
                 }
-                ncc_score_group<R>(acc, c0, c1, sM + bo, sS1 + bo, sS2 + bo, Sa, va, bestv, best);
+                ncc_score_group<R>(acc, c0, c1, sM + bo, sS1 + bo, sS2 + bo, Sa, va, bb);
             }
         }
     }
-    if (narrow && best != -1) d.d16_out[pix] = (int16_t)(best - x); // .cpp:219-222 / 301-302 / 563-564
+    if (narrow && bb.c != -1) d.d16_out[pix] = (int16_t)(bb.c - x); // .cpp:219-222 / 301-302 / 563-564
+    ncc_tie_append(a, 0, narrow && bb.tie, (uint32_t)pix | ((uint32_t)blockIdx.z << 31));
 }
 
 // One workgroup per wide pixel (worklist of k_ncc_dot4), candidates spread over the 256 lanes, NCC_G consecutive
@@ -411,6 +449,7 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
     __shared__ uint32_t sAw[WS * WS];
     __shared__ double s_v[NCC_TX / 64];
     __shared__ int s_c[NCC_TX / 64];
+    __shared__ int s_x[NCC_TX / 64]; // bit 0: exact, bit 1: tie
     const int count = *a.ncc_cnt;
     const int W = a.W;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -431,10 +470,9 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
         Rr = min(Rr, W - 1 - R);
         __syncthreads(); // previous item done with sAw / s_v / s_c / sB
         if (tid < WS * WS) sAw[tid] = d.img4_own[(size_t)(y - R + tid / WS) * W + x - R + tid % WS];
-        const int Sa = d.S1_own[pix];
-        const long long va = (long long)n * d.S2_own[pix] - (long long)Sa * Sa;
-        double bv = -1.0;
-        int bc = 0x7fffffff;
+        const double Sa = (double)d.S1_own[pix];
+        const double va = (double)n * (double)d.S2_own[pix] - Sa * Sa;
+        NccBest bb{-1.0, 0x7fffffff, true, false};
         for (int lo = L; lo <= Rr; lo += CHW) { // uniform
             const int hi = min(lo + CHW - 1, Rr);
             const int ndw = hi - lo + 1 + 2 * R + (G - 1); // columns lo - R .. hi + R (+ group padding)
@@ -475,30 +513,45 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
                     s1[g] = d.S1_oth[o];
                     s2[g] = d.S2_oth[o];
                 }
-                ncc_score_group<R>(acc, c0, Rr, mk, s1, s2, Sa, va, bv, bc);
+                ncc_score_group<R>(acc, c0, Rr, mk, s1, s2, Sa, va, bb);
             }
         }
-        // block argmax; equal scores -> the smaller column (the reference scans ascending with '>')
+        // block argmax; equal scores -> the smaller column (the reference scans ascending with '>'); two lanes'
+        // bests within NCC_TIE_TOL of each other are a tie like two candidates of one lane
+        double bv = bb.v;
+        int bc = bb.c;
+        bool bx = bb.exact, tie = bb.tie;
         for (int o = 32; o > 0; o >>= 1) {
             const double ov = __shfl_xor(bv, o);
             const int oc = __shfl_xor(bc, o);
+            const bool ox = __shfl_xor((int)bx, o) != 0;
+            if (bc != 0x7fffffff && oc != 0x7fffffff && fabs(ov - bv) <= NCC_TIE_TOL && !(ox && bx)) tie = true;
             if (ov > bv || (ov == bv && oc < bc)) {
                 bv = ov;
                 bc = oc;
+                bx = ox;
             }
         }
+        tie = __ballot(tie) != 0ull;
         if (lane == 0) {
             s_v[wid] = bv;
             s_c[wid] = bc;
+            s_x[wid] = (int)bx | ((int)tie << 1);
         }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < NCC_TX / 64; w++)
+            for (int w = 1; w < NCC_TX / 64; w++) {
+                const bool ox = s_x[w] & 1;
+                if (s_x[w] & 2) tie = true;
+                if (bc != 0x7fffffff && s_c[w] != 0x7fffffff && fabs(s_v[w] - bv) <= NCC_TIE_TOL && !(ox && bx)) tie = true;
                 if (s_v[w] > bv || (s_v[w] == bv && s_c[w] < bc)) {
                     bv = s_v[w];
                     bc = s_c[w];
+                    bx = ox;
                 }
+            }
             if (bv > -1.0) d.d16_out[pix] = (int16_t)(bc - x);
+            if (tie) a.tie_list[atomicAdd(a.tie_cnt, 1)] = ent;
         }
     }
 }
@@ -523,10 +576,9 @@ __global__ __launch_bounds__(256) void k_ncc_sparse(StageArgs a) {
         const size_t pix = a.rf_list[(size_t)row * W + item];
         const int y = (int)(pix / W), x = (int)(pix % W);
         const int L = max((int)d.BL[pix], R), Rr = min((int)d.BR[pix], W - 1 - R);
-        const int Sa = d.S1_own[pix];
-        const long long va = (long long)n * d.S2_own[pix] - (long long)Sa * Sa;
-        double bv = -1.0;
-        int bc = -1;
+        const double Sa = (double)d.S1_own[pix];
+        const double va = (double)n * (double)d.S2_own[pix] - Sa * Sa;
+        NccBest bb{-1.0, -1, true, false};
         for (int c0 = L; c0 <= Rr; c0 += G) {
             uint32_t acc[G];
 #pragma unroll
@@ -554,10 +606,106 @@ __global__ __launch_bounds__(256) void k_ncc_sparse(StageArgs a) {
                 s1[g] = d.S1_oth[o];
                 s2[g] = d.S2_oth[o];
             }
-            ncc_score_group<R>(acc, c0, Rr, mk, s1, s2, Sa, va, bv, bc);
+            ncc_score_group<R>(acc, c0, Rr, mk, s1, s2, Sa, va, bb);
         }
-        if (bc != -1) d.d16_out[pix] = (int16_t)(bc - x); // .cpp:563-564
+        if (bb.c != -1) d.d16_out[pix] = (int16_t)(bb.c - x); // .cpp:563-564
+        if (bb.tie) a.tie_list[atomicAdd(a.tie_cnt + 1, 1)] = (uint32_t)pix | ((uint32_t)dir << 31); // rare: no aggregation
     }
+    }
+}
+
+
+// ---------------------------------------------------------------- reference-order re-evaluation of tie pixels
+// One wave per listed pixel redoes the reference's candidate scan (.cpp:202-222 / 268-302 / 535-564) the reference's
+// way: vecL = (a - mean a) / ||a - mean a|| element by element, per candidate mean / norm / dot in fp64 with
+// Armadillo's two-accumulator order (oracle/stereo_oracle.c: orc_window_to_vec, orc_arma_dot), gather order byte
+// column outer, window row inner (CManageData.cpp:84-86).  The candidates are spread over the lanes (each lane scans
+// its own ascending subsequence with '>'), the wave keeps the largest score and, among equal scores, the smallest
+// column -- the first maximum, which is what the sequential strict-'>' scan returns.
+// (a - mean a) / norm takes at most 256 values per pixel: a 256-entry table in LDS replaces the n divisions.
+#define NCX_MAXR 15
+#define NCX_MAXN (3 * (2 * NCX_MAXR + 1) * (2 * NCX_MAXR + 1))
+__global__ __launch_bounds__(256) void k_ncc_exact(StageArgs a, int mode) {
+    __shared__ double sT[4][256];
+    __shared__ uint8_t sWin[4][NCX_MAXN + 13];
+    const int count = a.tie_cnt[mode == 2];
+    const int W = a.W, r = a.r, w = 2 * r + 1, n = 3 * w * w;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = blockIdx.x * 4; base < count; base += gridDim.x * 4) { // block-uniform
+        const int item = base + wid;
+        const bool on = item < count; // wave-uniform
+        const uint32_t ent = a.tie_list[on ? item : base];
+        const DirArgs &d = a.d[ent >> 31];
+        const size_t pix = ent & 0x7fffffffu;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        int L, Rr;
+        if (mode == 0) {
+            L = d.oth.XL;
+            Rr = d.oth.XR;
+        } else {
+            L = d.BL[pix];
+            Rr = d.BR[pix];
+        }
+        L = max(L, r); // windows that would leave the image are skipped (UB in the reference), as in the scan kernels
+        Rr = min(Rr, W - 1 - r);
+        __syncthreads(); // previous round done with sT / sWin
+        // own window in the reference's vector order: k = j * w + i <-> byte column j of window row i
+        for (int k = lane; k < n; k += 64) {
+            const int j = k / w, i = k - j * w;
+            sWin[wid][k] = d.img_own[((size_t)(y - r + i) * W + (x - r)) * 3 + j];
+        }
+        __syncthreads();
+        const double meanL = (double)d.S1_own[pix] / (double)n; // accumulate(u) / n: the byte sum is exact in fp64
+        double acc1 = 0.0, acc2 = 0.0;
+        for (int k = 0; k < n; k++) { // every lane runs the same chain (fn_norm.hpp:99-130)
+            const double u = (double)sWin[wid][k] - meanL;
+            if (k & 1) acc2 += u * u;
+            else acc1 += u * u;
+        }
+        double normL = sqrt(acc1 + acc2);
+        if (normL == 0) normL = 1; // CManageData.cpp:89
+#pragma unroll
+        for (int t = 0; t < 4; t++) sT[wid][lane * 4 + t] = ((double)(lane * 4 + t) - meanL) / normL; // vecL /= normL, .cpp:203
+        __syncthreads();
+        double bv = -1.0; // .cpp:205
+        int bc = 0x7fffffff;
+        if (on) {
+            for (int c = L + lane; c <= Rr; c += 64) {
+                if (d.mask_oth[(size_t)y * W + c] != 255) continue; // .cpp:209
+                const double meanR = (double)d.S1_oth[(size_t)y * W + c] / (double)n;
+                double m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
+                const uint8_t *b0 = d.img_oth + ((size_t)(y - r) * W + (c - r)) * 3;
+                int k = 0;
+                for (int j = 0; j < 3 * w; j++)
+                    for (int i = 0; i < w; i++, k++) {
+                        const double ur = (double)b0[(size_t)i * W * 3 + j] - meanR;
+                        const double vl = sT[wid][sWin[wid][k]];
+                        if (k & 1) {
+                            m2 += ur * ur;
+                            d2 += vl * ur;
+                        } else {
+                            m1 += ur * ur;
+                            d1 += vl * ur;
+                        }
+                    }
+                double normR = sqrt(m1 + m2);
+                if (normR == 0) normR = 1;
+                const double sc = (d1 + d2) / normR; // .cpp:211
+                if (sc > bv) {                       // .cpp:213
+                    bv = sc;
+                    bc = c;
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o);
+            const int oc = __shfl_xor(bc, o);
+            if (ov > bv || (ov == bv && oc < bc)) {
+                bv = ov;
+                bc = oc;
+            }
+        }
+        if (on && lane == 0) d.d16_out[pix] = (bc != 0x7fffffff) ? (int16_t)(bc - x) : (int16_t)NOMATCH;
     }
 }
 
@@ -567,12 +715,16 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
     const size_t lds = 16 + (size_t)WS * (SA + SB) * 4 + (size_t)(NCC_CH + NCC_G) * 9 + 16;
     if (mode == 2) { // the worklist was filled by launch_set_boundary
         hipLaunchKernelGGL(k_ncc_sparse<R>, dim3(2048), dim3(256), 0, st, a);
+        if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(512), dim3(256), 0, st, a, mode);
         return;
     }
     // *a.ncc_cnt (wide-pixel count) is zero on entry: the caller hands every launch a fresh counter
     hipLaunchKernelGGL(k_ncc_dot4<R>, grid, dim3(NCC_TX), lds, st, a, mode);
     const size_t ldsw = (size_t)WS * (NCC_TX * NCC_G + 2 * R + NCC_G) * 4;
+    if (ldsw > 65536) // radii 6 and 7 stage more than the default 64 KB of dynamic LDS per workgroup
+        (void)hipFuncSetAttribute((const void *)k_ncc_wide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
     hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), ldsw, st, a, mode);
+    if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(512), dim3(256), 0, st, a, mode);
 }
 
 void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
@@ -600,4 +752,5 @@ void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
     const int strideB = (((NCC_CH + 2 * a.r) * 3 + 3) & ~3) + 4;
     const size_t lds = 16 + (size_t)ws * strideA + (size_t)ws * strideB;
     hipLaunchKernelGGL(k_ncc_bytes, grid, dim3(NCC_TX), lds, st, a, mode, strideA, strideB);
+    if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(512), dim3(256), 0, st, a, mode);
 }

@@ -77,6 +77,8 @@ struct rsm_ctx {
     int16_t *rf_key[2]{};
     int32_t *rf_cnt = nullptr; // NCC wide-pixel counter
     uint32_t *rf_list = nullptr;
+    uint32_t *tie_list = nullptr; // NCC tie pixels (k_ncc_exact)
+    int32_t *tie_cnt = nullptr;   // [2 * level + (Rematch ? 1 : 0)]
     double *rf_pwp[2]{}, *rf_delta[2]{};
     int32_t *prefix = nullptr;
     int *d_j1 = nullptr, *d_j2 = nullptr;   // structuring-element spans: Rectify's mask erosion
@@ -98,6 +100,7 @@ struct rsm_ctx {
 
     // options (rsm_set_option)
     int opt_ncc_bytes = 0;
+    int opt_no_exact = 0;
     int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
     int opt_refine_band_rows = 0; // > 0: band height in rows, overrides refine_band_mb (tests)
 
@@ -274,6 +277,8 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     }
     DALLOC(c, c->rf_cnt, 32 + 2 * (size_t)in->height); // level k uses rf_cnt + k: [0] wide-pixel count, [16 + dir * H + y] Rematch pixels of a row
     DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
+    DALLOC(c, c->tie_list, 2 * px + 64);
+    DALLOC(c, c->tie_cnt, 2 * RSM_MAX_LEVELS);
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->blk, CLOUD_BLOCKS(in->width, in->height));
     DALLOC(c, c->d_j1, 4096);
@@ -367,6 +372,7 @@ static void prof_end(rsm_ctx *c, int slot, int stage, int launches, double bytes
 extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
+    else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
     else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
     else if (!strcmp(name, "refine_band_rows")) c->opt_refine_band_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
@@ -404,10 +410,13 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.ws = c->in.ws;
     a.rf_list = c->rf_list;
     a.ncc_cnt = c->rf_cnt + k; // a counter per level, zeroed together at the start of the run
+    a.tie_list = c->tie_list;
+    a.tie_cnt = c->tie_cnt + 2 * k;
     a.rf_stride = c->cap_px;
     a.row_lo = 0;
     a.row_hi = INT_MAX;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
+    a.opt_no_exact = c->opt_no_exact;
     for (int v = 0; v < 2; v++) {
         DirArgs &d = a.d[v];
         const int o = 1 - v;
@@ -569,6 +578,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             }
         launch_find_margin_batch(2 * N, masks, Ws, Hs, r, c->d_margins, c->h_margin_init, st);
         HIPCHK(c, hipMemsetAsync(c->rf_cnt, 0, sizeof(int) * 16, st)); // the levels' wide-pixel counters
+        HIPCHK(c, hipMemsetAsync(c->tie_cnt, 0, sizeof(int) * 2 * RSM_MAX_LEVELS, st));
     }
     prof_end(c, ps2, ST_MARGIN, 1, 0);
     int hm[RSM_MAX_LEVELS * 2 * 4];
@@ -863,6 +873,8 @@ struct MatchBufs {
     uint32_t *i4o, *i4t;
     uint32_t *wl; // wide-pixel worklist + counter of the NCC kernels
     int32_t *wc;
+    uint32_t *tl; // tie list + counters (k_ncc_exact)
+    int32_t *tc;
     int32_t *S1o, *S2o, *S1t, *S2t;
 };
 bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_oth, const uint8_t *mask_own,
@@ -875,6 +887,9 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     b.wl = t.alloc<uint32_t>(std::max(px + 64, SETB_SCRATCH(W))); // NCC worklist / SetBoundary scratch
     b.wc = t.alloc<int32_t>(16 + 2 * (size_t)H);
     if (b.wc) (void)hipMemsetAsync(b.wc, 0, sizeof(int), c->stream); // wide-pixel counter of the NCC launch
+    b.tl = t.alloc<uint32_t>(px + 64);
+    b.tc = t.alloc<int32_t>(2);
+    if (b.tc) (void)hipMemsetAsync(b.tc, 0, 2 * sizeof(int), c->stream);
     b.i4o = t.alloc<uint32_t>(px);
     b.i4t = t.alloc<uint32_t>(px);
     b.S1o = t.alloc<int32_t>(px);
@@ -892,6 +907,7 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
 StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, const rsm_boundary *oth) {
     StageArgs a{};
     a.opt_ncc_bytes = c->opt_ncc_bytes;
+    a.opt_no_exact = c->opt_no_exact;
     a.row_lo = 0;
     a.row_hi = INT_MAX;
     a.ndir = 1;
@@ -905,6 +921,8 @@ StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, cons
 void bind_match(StageArgs &a, const MatchBufs &b) {
     a.rf_list = b.wl;
     a.ncc_cnt = b.wc;
+    a.tie_list = b.tl;
+    a.tie_cnt = b.tc;
     DirArgs &d = a.d[0];
     d.img_own = b.io;
     d.img_oth = b.it;
@@ -1337,6 +1355,7 @@ extern "C" int rsm_bench_ncc(rsm_ctx *c, int W, int H, int r, int cands, int ite
     HIPCHK(c, hipEventRecord(e0, c->stream));
     for (int i = 0; i < iters; i++) {
         (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), c->stream); // fresh wide-pixel counter per launch
+        (void)hipMemsetAsync(a.tie_cnt, 0, 2 * sizeof(int), c->stream);
         launch_ncc_argmax(a, 1, c->stream);
     }
     HIPCHK(c, hipEventRecord(e1, c->stream));

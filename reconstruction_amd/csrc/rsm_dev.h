@@ -50,7 +50,10 @@ struct StageArgs {
     int row_lo, row_hi; // refine sweep: only rows [row_lo, row_hi) of the interior are updated (band schedule, k_refine.hip)
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
+    int opt_no_exact;               // skip k_ncc_exact (timing A/B only: ties then follow the integer form)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
+    uint32_t *tie_list; // NCC: pixels (dir << 31 | pixel index) whose scan saw a (near) tie -> k_ncc_exact
+    int32_t *tie_cnt;   // NCC: [0] entries of tie_list after an initial-match launch, [1] after a Rematch launch (zero on entry)
     int32_t *ncc_cnt;  // NCC: [0] number of wide pixels in rf_list (zero before an initial-match launch), [16 + dir * H + y] Rematch pixels of a row
 };
 
