@@ -98,3 +98,18 @@ def diff_report(name, a, b):
         idx = tuple(int(i) for i in idx)
         msg += "\n   at %s: got %s expected %s" % (idx, a[idx], b[idx])
     return msg
+
+
+def libm_exp_stats(res_disp, ref_disp):
+    """HIP result (specified exp) against the oracle run with the HOST libm's exp -- the situation of the reference,
+    whose C runtime's exp has an unspecified last bit (CStereoMatching.cpp:665-666).  Returns per view:
+    (pixels valid in both, NOMATCH-set mismatches, count above 1e-3 relative, max relative error)."""
+    out = []
+    for v in range(2):
+        a, b = np.asarray(res_disp[v]), np.asarray(ref_disp[v])
+        na, nb = a == NOMATCH, b == NOMATCH
+        both = ~na & ~nb
+        rel = np.abs(a[both] - b[both]) / np.maximum(1.0, np.abs(b[both]))
+        out.append(dict(valid=int(both.sum()), nomatch_mismatch=int((na != nb).sum()), above_1e3=int((rel > 1e-3).sum()),
+                        above_1e9=int((rel > 1e-9).sum()), max_rel=float(rel.max()) if rel.size else 0.0))
+    return out

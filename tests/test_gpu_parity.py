@@ -12,7 +12,7 @@ import pytest
 from oracle import oracle as orc
 from reconstruction_amd import synth
 
-from helpers import NOMATCH, cloud_scale, diff_report, oracle_stages
+from helpers import NOMATCH, cloud_scale, diff_report, libm_exp_stats, oracle_stages
 
 pytestmark = pytest.mark.gpu
 
@@ -362,3 +362,25 @@ def test_refine_band_schedule_is_bit_identical(ctx, rows):
             assert np.array_equal(res.disparity[v], fin["disparity"][v])
     finally:
         ctx.set_option("refine_band_rows", 0)
+
+
+def test_whole_pair_against_the_libm_exp_oracle(ctx):
+    """The honest statement of DisparityRefine parity.  Against the oracle with the SPECIFIED exp the HIP path is
+    bit-identical (every other test).  The reference itself calls its C runtime's exp (.cpp:665-666); run the oracle
+    that way (host libm) and the chaotic iteration turns one-ulp differences of exp into visible ones for a small
+    fraction of the pixels.  What holds, and is asserted: the NOMATCH sets and the point count are identical,
+    >= 99.9 % of the pixels agree within north_star's 1e-3 relative, none is off by more than 2e-2."""
+    cfg, rec, fin = stages("s512x384_5levels")
+    res = ctx.match_pair(cfg)
+    orc.set_exp_mode(1)
+    try:
+        ref = orc.match_pair(cfg)
+    finally:
+        orc.set_exp_mode(0)
+    st = libm_exp_stats(res.disparity, ref["disparity"])
+    print("5-level 512x384 vs libm-exp oracle:", st)
+    for s_ in st:
+        assert s_["nomatch_mismatch"] == 0
+        assert s_["above_1e3"] <= 1e-3 * s_["valid"]
+        assert s_["max_rel"] < 2e-2
+    assert res.n_points == ref["n_points"]
