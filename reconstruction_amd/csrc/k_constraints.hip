@@ -370,6 +370,8 @@ void launch_order(const StageArgs &a, hipStream_t st) {
     if (rows <= 0 || maxL <= 0) return;
     maxL = (maxL + 63) & ~63;
     const size_t lds = (size_t)maxL * 6 + ((size_t)maxL / 64 + 1) * 12 + ((size_t)maxL / ORD_BIG + 1) * 4;
+    if (lds > 65536) // margins wider than ~10 k columns: beyond the default 64 KB of dynamic LDS per workgroup
+        (void)hipFuncSetAttribute((const void *)k_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_order, dim3(rows, 1, a.ndir), dim3(64 * ORD_NW), lds, st, a, maxL);
 }
 

@@ -751,6 +751,8 @@ void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
     const int strideA = (((NCC_TX + 2 * a.r) * 3 + 3) & ~3) + 4;
     const int strideB = (((NCC_CH + 2 * a.r) * 3 + 3) & ~3) + 4;
     const size_t lds = 16 + (size_t)ws * strideA + (size_t)ws * strideB;
+    if (lds > 65536) // radius 15
+        (void)hipFuncSetAttribute((const void *)k_ncc_bytes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_ncc_bytes, grid, dim3(NCC_TX), lds, st, a, mode, strideA, strideB);
     if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(512), dim3(256), 0, st, a, mode);
 }

@@ -228,8 +228,9 @@ static int validate(rsm_ctx *c, const rsm_pair_in *in) {
     if (!c || !in) return RSM_E_INVALID;
     if (in->pyr_levels < 1 || in->pyr_levels > RSM_MAX_LEVELS) return set_err(c, RSM_E_INVALID, "pyr_levels");
     if (in->radius < 1 || in->radius > 15) return set_err(c, RSM_E_INVALID, "radius");
-    if (in->width <= 0 || in->height <= 0 || in->width > 32000 || in->height > 32000)
-        return set_err(c, RSM_E_INVALID, "size");
+    // 16384: the widest margin row k_order can hold in a CU's 160 KB of LDS (6.2 B per column), and int16 columns
+    if (in->width <= 0 || in->height <= 0 || in->width > 16384 || in->height > 16384)
+        return set_err(c, RSM_E_INVALID, "size (1..16384)");
     const int top = 1 << (in->pyr_levels - 1);
     if ((in->width % top) || (in->height % top)) return set_err(c, RSM_E_INVALID, "size not divisible by 2^(levels-1)");
     if ((in->width / top) <= 2 * in->radius + 2 || (in->height / top) <= 2 * in->radius + 2)

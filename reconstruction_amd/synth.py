@@ -182,6 +182,20 @@ def config_c3(pair: int = 0) -> PairConfig:
                      name=f"C3_3072x4096_r5_p{pair}")
 
 
+def config_c3_shipped(pair: int = 0) -> PairConfig:
+    """C3': the 10-camera rig at the scale the reference ships (BatchProcess/main.cpp:59-61: lowest level 160x240,
+    4 levels -> 1280x1920), 5x5 NCC (CReconstruction.cpp:17), ellipse mask."""
+    return make_pair(1280, 1920, 4, radius=2, offset=2, pair=pair, mask_kind="ellipse",
+                     name=f"C3s_1280x1920_r2_p{pair}")
+
+
+def config_c5_reduced(pair: int = 0) -> PairConfig:
+    """C5's geometry (15x15 NCC, 4 levels, 256 candidates at the lowest level) on a 2560x768 top level, small
+    enough for the CPU oracle."""
+    return make_pair(2560, 768, 4, radius=7, offset=2, pair=pair, mask_kind="rect", mask_l0_width=256, border_l0=10,
+                     name=f"C5r_2560x768_r7_p{pair}")
+
+
 def config_c5(pair: int = 0) -> PairConfig:
     """C5: synthetic 16-view stress: 4096x3072, 15x15 NCC, 256 disparities at L0, 4 levels."""
     return make_pair(4096, 3072, 4, radius=7, offset=2, pair=pair, mask_kind="rect", mask_l0_width=256,
