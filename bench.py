@@ -39,13 +39,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=["c2", "c2s", "c1", "c3", "c5"])
+    ap.add_argument("--inflight", type=int, default=2, help="pairs in flight per GPU (contexts run concurrently by rsm_run_pairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="rsm_set_option name=value (tuning knobs)")
     ap.add_argument("--stage-events", type=int, default=0, help="1: per-stage events inside the timed region too")
     ap.add_argument("--ncc-bench", action="store_true", help="also report the NCC kernel MDE/s microbenchmark")
     args = ap.parse_args()
 
-    from reconstruction_amd import Context, synth
+    from reconstruction_amd import Context, run_pairs, synth
     from reconstruction_amd.dist import gather_clouds_async
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -69,32 +70,39 @@ def main():
 
     make = {"c2": synth.config_c2, "c2s": synth.config_c2_sample, "c1": synth.config_c1,
             "c3": synth.config_c3, "c5": synth.config_c5}[args.config]
-    cfg = make(pair=rank)  # a differently-seeded pair per rank
-    ctx = Context(local_rank)
-    for o in args.opt:
-        k, v = o.split("=")
-        ctx.set_option(k, int(v))
-    # inputs -> HBM once, outside the timed region (torch owns the staging tensors: plumbing)
+    F = max(1, args.inflight)
     dev = torch.device("cuda", local_rank)
-    t_img = [torch.from_numpy(np.ascontiguousarray(cfg.image[v])).to(dev) for v in range(2)]
-    t_msk = [torch.from_numpy(np.ascontiguousarray(cfg.mask[v])).to(dev) for v in range(2)]
-    torch.cuda.synchronize()
-    ctx.upload_pair_device(cfg, [t.data_ptr() for t in t_img], [t.data_ptr() for t in t_msk])
+    ctxs, cfgs, keep = [], [], []
+    for i in range(F):  # a differently-seeded pair per rank and slot, uploaded once, outside the timed region
+        cfg = make(pair=rank * F + i)
+        c = Context(local_rank)
+        for o in args.opt:
+            k, v = o.split("=")
+            c.set_option(k, int(v))
+        t_img = [torch.from_numpy(np.ascontiguousarray(cfg.image[v])).to(dev) for v in range(2)]
+        t_msk = [torch.from_numpy(np.ascontiguousarray(cfg.mask[v])).to(dev) for v in range(2)]
+        torch.cuda.synchronize()
+        c.upload_pair_device(cfg, [t.data_ptr() for t in t_img], [t.data_ptr() for t in t_msk])
+        ctxs.append(c); cfgs.append(cfg); keep.append((t_img, t_msk))
+    ctx, cfg = ctxs[0], cfgs[0]
 
     # N > 1: the cloud of step i travels to rank 0 (RCCL fan-in) while step i + 1 is being matched -- what a rank
     # with several pairs does in production; every gather completes inside the timed region (drain() below).
     pending = [None]
 
     def step():
-        ctx.run_pair()  # host-synchronous
+        run_pairs(ctxs)  # host-synchronous; the F resident pairs are matched concurrently
         if world > 1:
-            n = ctx.n_points
-            xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
-            bgr = torch.empty((n, 3), dtype=torch.uint8, device=dev)
-            ctx.export_cloud_device(xyz.data_ptr(), bgr.data_ptr(), n)
-            if backend != "nccl":
-                xyz, bgr = xyz.cpu(), bgr.cpu()
-            h = gather_clouds_async([(rank, xyz, bgr)], dst=0)
+            local = []
+            for i, c in enumerate(ctxs):
+                n = c.n_points
+                xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
+                bgr = torch.empty((n, 3), dtype=torch.uint8, device=dev)
+                c.export_cloud_device(xyz.data_ptr(), bgr.data_ptr(), n)
+                if backend != "nccl":
+                    xyz, bgr = xyz.cpu(), bgr.cpu()
+                local.append((rank * F + i, xyz, bgr))
+            h = gather_clouds_async(local, dst=0)
             drain()
             pending[0] = h
 
@@ -114,27 +122,36 @@ def main():
 
     # timed region: only the dominant kernel's launches are bracketed with events (every 8th); the per-stage events
     # cost ~0.35 ms per step, so the stage split comes from one extra, untimed step afterwards
-    ctx.profile_enable(1 if args.stage_events else 2)
+    for c in ctxs:
+        c.profile_enable(1 if args.stage_events else 2)
     prof_acc = {}
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for k, v in ctx.profile_get().items():
-            a = prof_acc.setdefault(k, {"ms": 0.0, "launches": 0, "bytes": 0.0})
-            a["ms"] += v["ms"]; a["launches"] += v["launches"]; a["bytes"] += v["bytes"]
+    if world == 1:
+        # K steps = every context matches its pair K times.  The contexts are not made to meet between steps: as in
+        # rsm_match_pairs (a stream of pairs over a pool of contexts) one pair's launch-bound small levels run under
+        # the other's top-level sweeps, also across step boundaries.
+        run_pairs(ctxs, repeats=args.steps)
+    else:
+        for _ in range(args.steps):
+            step()
     drain()
     fence()
     dt = time.perf_counter() - t0
+    for c in ctxs:
+        for k, v in c.profile_get().items():
+            a = prof_acc.setdefault(k, {"ms": 0.0, "launches": 0, "bytes": 0.0})
+            a["ms"] += v["ms"]; a["launches"] += v["launches"]; a["bytes"] += v["bytes"]
+    for c in ctxs:
+        c.profile_enable(False)
     ctx.profile_enable(1)
-    step()
-    drain()
+    ctx.run_pair()  # the stage split: one pair alone, untimed
     fence()
     stage_prof = ctx.profile_get()
     ctx.profile_enable(False)
 
     res = ctx.download_pair(want_cloud=False, want_disparity=False)
-    v_top = res.v_top
+    v_top = sum(c.download_pair(want_cloud=False, want_disparity=False).v_top for c in ctxs)
     if world > 1:
         t = torch.tensor([dt, float(v_top)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         tmax = t.clone()
@@ -170,8 +187,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg.name, "width": cfg.width, "height": cfg.height, "pyr_levels": cfg.pyr_levels,
-                       "ncc_window": 2 * cfg.radius + 1, "offset": cfg.offset, "pairs_per_gpu": 1,
-                       "v_top_per_pair": int(v_top), "n_points_last": int(res.n_points),
+                       "ncc_window": 2 * cfg.radius + 1, "offset": cfg.offset, "pairs_per_gpu": F, "pairs_in_flight": F,
+                       "v_top_per_pair": int(res.v_top), "n_points_last": int(res.n_points),
                        "parallelism": "pairs sharded 1/GPU + RCCL fan-in gather overlapped with the next pair" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_refine_sweep<1> (DisparityRefine Jacobi sweep, top level)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -180,7 +197,7 @@ def main():
                          # memory system's rate, as opposed to how many of those bytes the algorithm needs
                          "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
                          "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_ms > 0 else None,
-                         "avg_launch_ms": round(avg_ms, 5), "launches_timed_per_step": launches // args.steps,
+                         "avg_launch_ms": round(avg_ms, 5), "launches_timed_per_step": launches // args.steps // F, "concurrent_pairs": F,
                          "launches_per_step": stage_prof["refine_sweep_top"]["launches"] - 1,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_pair_algorithmic_GB": round(total_alg_bytes / 1e9, 3),
@@ -195,7 +212,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -104,12 +104,32 @@ int rsm_result_device(rsm_ctx *ctx, const double **disparity0, const double **di
  * buffers an RCCL gather sends from): up to max_points points, xyz fp64 x3 and/or bgr u8 x3. */
 int rsm_export_cloud_device(rsm_ctx *ctx, double *d_xyz, uint8_t *d_bgr, int64_t max_points);
 
+/* ---- several pairs at once (the pair loop of MatchAllLayer, .cpp:17-33, has no cross-pair data flow) -------- */
+/* rsm_run_pair on n DIFFERENT contexts concurrently (one host thread each; contexts may share a GPU or sit on
+ * different ones).  On one GPU two pairs in flight hide each other's launch-latency-bound small levels and host
+ * syncs.  Returns the first non-zero status. */
+int rsm_run_pairs(rsm_ctx *const *ctxs, int n);
+/* Same, every context running its resident pair `repeats` times back to back without meeting the others in between
+ * (steady-state throughput of a stream of pairs; bench.py). */
+int rsm_run_pairs_repeat(rsm_ctx *const *ctxs, int n, int repeats);
+/* The whole loop body for n_pairs pairs over a pool of contexts: a context takes the next pair from a queue as soon as
+ * it is free (upload, run, download -- one pair's PCIe copies overlap another pair's kernels).  out[p] is filled as
+ * by rsm_match_pair, in pair order, so the caller can replay InsertPoint / filter(CamPair) sequentially afterwards.
+ * status (optional, n_pairs ints) receives each pair's status; a failed pair does not stop the others. */
+int rsm_match_pairs(rsm_ctx *const *ctxs, int n_ctx, const rsm_pair_in *in, rsm_pair_out *out, int n_pairs, int *status);
+/* Same with library-owned contexts: pairs sharded over n_gpus devices of this node (0 = all visible),
+ * pairs_in_flight contexts per device (0 = 2) -- the single-process form of SURVEY 8(e); the one-process-per-GPU form
+ * is rsm_gather_clouds below. */
+int rsm_match_pairs_multi_gpu(const rsm_pair_in *in, int n_pairs, int n_gpus, int pairs_in_flight, rsm_pair_out *out,
+                              int *status);
+
 /* Validation knob (results never change): "ncc_bytes" = 1 forces the generic byte-wise NCC kernel instead of the
  * dot4 one. */
 int rsm_set_option(rsm_ctx *ctx, const char *name, long long value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
-/* Per-stage device time of the last rsm_run_pair, measured with hipEvents on the ctx stream.
+/* Per-stage device time of the rsm_run_pair calls since the last rsm_profile_enable (which zeroes the counters),
+ * measured with hipEvents on the ctx stream.
  * Enable before the run (on = 1: every stage and every 8th launch of the dominant kernel; on = 2: the latter only).
  * Stage names: rsm_profile_stage_name(i), i < rsm_profile_stage_count(). */
 int rsm_profile_enable(rsm_ctx *ctx, int on);

@@ -362,6 +362,57 @@ class Context:
         return xyz[:n.value].copy(), bgr[:n.value].copy()
 
 
+def run_pairs(ctxs, repeats=1):
+    """rsm_run_pairs[_repeat]: rsm_run_pair on several DIFFERENT contexts concurrently (pairs already resident),
+    each context `repeats` times back to back."""
+    lib = _lib.load()
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    st = lib.rsm_run_pairs_repeat(arr, len(ctxs), int(repeats))
+    if st != 0:
+        msgs = [(lib.rsm_last_error(c._h) or b"").decode() for c in ctxs]
+        raise RsmError(st, "; ".join(m for m in msgs if m))
+
+
+def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True):
+    """rsm_match_pairs: the pair loop of MatchAllLayer (.cpp:17-33) for a list of pair configs over a pool of
+    contexts (same or different GPUs), pairs in flight together.  Returns (results in pair order, statuses)."""
+    lib = _lib.load()
+    n = len(cfgs)
+    ins = (PairIn * n)()
+    outs = (PairOut * n)()
+    keep, bufs = [], []
+    for p, cfg in enumerate(cfgs):
+        pin, k = Context._pair_in(cfg)
+        ins[p] = pin
+        keep.append(k)
+        H, W = cfg.height, cfg.width
+        d = [np.zeros((H, W), np.float64), np.zeros((H, W), np.float64)] if want_disparity else [None, None]
+        xyz = np.zeros((W * H, 3), np.float64) if want_cloud else None
+        bgr = np.zeros((W * H, 3), np.uint8) if want_cloud else None
+        if want_disparity:
+            outs[p].disparity[0] = d[0].ctypes.data
+            outs[p].disparity[1] = d[1].ctypes.data
+        if want_cloud:
+            outs[p].max_points = W * H
+            outs[p].xyz = xyz.ctypes.data
+            outs[p].bgr = bgr.ctypes.data
+        bufs.append((d, xyz, bgr))
+    status = (C.c_int * n)()
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    lib.rsm_match_pairs(arr, len(ctxs), ins, outs, n, status)
+    res = []
+    for p in range(n):
+        if status[p] != 0:
+            res.append(None)
+            continue
+        d, xyz, bgr = bufs[p]
+        m = int(outs[p].n_points)
+        res.append(PairResult(disparity=d, margin=[outs[p].margin[0].astuple(), outs[p].margin[1].astuple()], n_points=m,
+                              xyz=xyz[:m].copy() if want_cloud else np.zeros((0, 3)),
+                              bgr=bgr[:m].copy() if want_cloud else np.zeros((0, 3), np.uint8), v_top=int(outs[p].v_top)))
+    return res, list(status)
+
+
 # ---------------------------------------------------------------------------------------------------
 # Mirror of the reference's data / matching classes
 # ---------------------------------------------------------------------------------------------------

@@ -17,7 +17,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -85,6 +88,7 @@ struct rsm_ctx {
     int *d_cj1 = nullptr, *d_cj2 = nullptr; // ... and DisparityToCloud's (uploaded with the pair)
     uint8_t *blk = nullptr;                 // coarse bad-block map of the top-level mask (cloud erosion)
     hipEvent_t ev_cloudprep = nullptr;
+    hipEvent_t ev_heavy = nullptr; // end of this context's last bandwidth-bound section (heavy_begin / heavy_end)
     int32_t *row_count = nullptr;
     int64_t *row_offset = nullptr;
     int64_t *d_npoints = nullptr;
@@ -101,6 +105,7 @@ struct rsm_ctx {
     // options (rsm_set_option)
     int opt_ncc_bytes = 0;
     int opt_no_exact = 0;
+    int opt_heavy_exclusive = 1; // large-level refine sections of contexts sharing a GPU take turns (heavy_begin)
     int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
     int opt_refine_band_rows = 0; // > 0: band height in rows, overrides refine_band_mb (tests)
 
@@ -113,6 +118,42 @@ struct rsm_ctx {
     int64_t prof_launches[ST_COUNT]{};
     double prof_bytes[ST_COUNT]{};
 };
+
+
+// ---- one bandwidth-bound section at a time per GPU ------------------------------------------------------------
+// Contexts that share a GPU (rsm_run_pairs / rsm_match_pairs: several pairs in flight) overlap usefully only where
+// one of them leaves the chip idle: the launch-latency-bound small levels, the row-serial stages, host syncs.  Two
+// pairs' large-level Jacobi sweeps gain nothing from running side by side -- each streams at the fabric's rate
+// alone -- and would only halve each other's speed.  So those sections take turns, ordered on the GPU by events (the host
+// never blocks for it): a section waits for the event that ends the previous context's section; the short mutex
+// only makes "enqueue the section, publish its end event" atomic.
+#define RSM_MAX_DEVICES 64
+static std::mutex g_heavy_mu[RSM_MAX_DEVICES];
+static hipEvent_t g_heavy_last[RSM_MAX_DEVICES];
+static rsm_ctx *g_heavy_owner[RSM_MAX_DEVICES];
+#define HEAVY_MIN_PIXELS 400000.0 // sections smaller than this are launch-bound themselves
+
+static bool heavy_begin(rsm_ctx *c, double pixels) {
+    if (!c->opt_heavy_exclusive || pixels < HEAVY_MIN_PIXELS || c->device >= RSM_MAX_DEVICES) return false;
+    g_heavy_mu[c->device].lock();
+    if (g_heavy_last[c->device] && g_heavy_owner[c->device] != c) (void)hipStreamWaitEvent(c->stream, g_heavy_last[c->device], 0);
+    return true;
+}
+static void heavy_end(rsm_ctx *c, bool held) {
+    if (!held) return;
+    (void)hipEventRecord(c->ev_heavy, c->stream);
+    g_heavy_last[c->device] = c->ev_heavy;
+    g_heavy_owner[c->device] = c;
+    g_heavy_mu[c->device].unlock();
+}
+static void heavy_forget(rsm_ctx *c) { // the context goes away: nobody may wait on its event any more
+    if (c->device >= RSM_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> g(g_heavy_mu[c->device]);
+    if (g_heavy_owner[c->device] == c) {
+        g_heavy_owner[c->device] = nullptr;
+        g_heavy_last[c->device] = nullptr;
+    }
+}
 
 static int set_err(rsm_ctx *c, int code, const char *fmt, ...) {
     if (c) {
@@ -168,10 +209,13 @@ extern "C" int rsm_create(rsm_ctx **out, int hip_device) {
     if (hip_device < 0 || hip_device >= ndev) return RSM_E_INVALID;
     rsm_ctx *c = new rsm_ctx();
     c->device = hip_device;
+    // (stream priorities were measured and dropped: a high-priority main stream next to low-priority sweep streams ran
+    //  two pairs in flight at 164 Mdisp/s instead of 210)
     if (hipSetDevice(hip_device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_cloudprep, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_cloudprep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return RSM_E_HIP;
     }
@@ -203,6 +247,8 @@ extern "C" void rsm_destroy(rsm_ctx *c) {
     }
     (void)hipEventDestroy(c->ev_pyr);
     (void)hipEventDestroy(c->ev_cloudprep);
+    heavy_forget(c);
+    (void)hipEventDestroy(c->ev_heavy);
     for (int k = 0; k < RSM_MAX_LEVELS; k++) (void)hipEventDestroy(c->ev_prep[k]);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
@@ -373,6 +419,7 @@ static void prof_end(rsm_ctx *c, int slot, int stage, int launches, double bytes
 extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
+    else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = value != 0;
     else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
     else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
     else if (!strcmp(name, "refine_band_rows")) c->opt_refine_band_rows = (int)std::max(0LL, std::min(value, 1000000LL));
@@ -384,6 +431,11 @@ extern "C" int rsm_profile_enable(rsm_ctx *c, int on) {
     if (!c) return RSM_E_INVALID;
     c->profile = on != 0;
     c->profile_stages = on == 1; // 2: only the dominant kernel's launches are bracketed
+    for (int i = 0; i < ST_COUNT; i++) { // the counters accumulate over the runs that follow
+        c->prof_ms[i] = 0;
+        c->prof_launches[i] = 0;
+        c->prof_bytes[i] = 0;
+    }
     return RSM_OK;
 }
 extern "C" int rsm_profile_stage_count(void) { return ST_COUNT; }
@@ -532,11 +584,6 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     const int N = c->N, r = c->in.radius;
     c->have_result = false;
     c->ev_used = 0;
-    for (int i = 0; i < ST_COUNT; i++) {
-        c->prof_ms[i] = 0;
-        c->prof_launches[i] = 0;
-        c->prof_bytes[i] = 0;
-    }
     const double P_top_full = (double)c->Wk[N - 1] * c->Hk[N - 1];
 
     // ConstructPyrm, .cpp:1040-1053 (top level = uploaded images).  The main stream needs the masks (margins) first;
@@ -681,7 +728,9 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         const int ps12 = prof_begin(c, st_sweep);
         a.flag = (k == N - 1);
         double *bufA[2] = {c->f64[ia][0], c->f64[ia][1]}, *bufB[2] = {c->f64[ib][0], c->f64[ib][1]};
+        const bool heavy = heavy_begin(c, Pk);
         const int nlaunch = refine_sweeps(c, a, bufA, bufB, iters, st, k == N - 1);
+        heavy_end(c, heavy);
         const int cur = (iters & 1) ? ib : ia; // sweep t reads (t even ? ia : ib) and writes the other
         prof_end(c, ps12, st_sweep, nlaunch, 32.0 * Pk * iters);
 
@@ -777,6 +826,85 @@ extern "C" int rsm_match_pair(rsm_ctx *c, const rsm_pair_in *in, rsm_pair_out *o
     s = rsm_run_pair(c);
     if (s != RSM_OK) return s;
     return rsm_download_pair(c, out);
+}
+
+
+// =================================================================================================
+// Several pairs at once: the pair loop of CStereoMatching::MatchAllLayer (.cpp:17-33) has no cross-pair data flow,
+// so pairs can be in flight together -- on one GPU (a pair's launch-latency-bound small levels and host syncs hide
+// under another pair's top-level sweeps) and across the GPUs of a node (contexts on different devices).
+// One host thread per context; every context keeps its own streams and workspace.
+// =================================================================================================
+extern "C" int rsm_run_pairs(rsm_ctx *const *ctxs, int n) { return rsm_run_pairs_repeat(ctxs, n, 1); }
+
+extern "C" int rsm_run_pairs_repeat(rsm_ctx *const *ctxs, int n, int repeats) {
+    if (!ctxs || n <= 0 || repeats < 1) return RSM_E_INVALID;
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return RSM_E_INVALID;
+        for (int j = 0; j < i; j++)
+            if (ctxs[j] == ctxs[i]) return RSM_E_INVALID; // a context is not re-entrant
+    }
+    std::vector<int> st((size_t)n, RSM_OK);
+    auto loop = [&](int i) { // every context runs its resident pair `repeats` times, free of the others
+        for (int k = 0; k < repeats && st[(size_t)i] == RSM_OK; k++) st[(size_t)i] = rsm_run_pair(ctxs[i]);
+    };
+    std::vector<std::thread> th;
+    th.reserve((size_t)n - 1);
+    for (int i = 1; i < n; i++) th.emplace_back(loop, i);
+    loop(0);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < n; i++)
+        if (st[(size_t)i] != RSM_OK) return st[(size_t)i];
+    return RSM_OK;
+}
+
+extern "C" int rsm_match_pairs(rsm_ctx *const *ctxs, int n_ctx, const rsm_pair_in *in, rsm_pair_out *out, int n_pairs,
+                               int *status) {
+    if (!ctxs || n_ctx <= 0 || n_pairs < 0 || (n_pairs > 0 && (!in || !out))) return RSM_E_INVALID;
+    for (int i = 0; i < n_ctx; i++) {
+        if (!ctxs[i]) return RSM_E_INVALID;
+        for (int j = 0; j < i; j++)
+            if (ctxs[j] == ctxs[i]) return RSM_E_INVALID;
+    }
+    std::atomic<int> next(0);
+    std::vector<int> st((size_t)n_pairs, RSM_OK);
+    // Work queue: a context takes the next pair when it is free, so that upload / download of one pair (PCIe)
+    // overlaps another pair's kernels and uneven pairs balance themselves.  A failed pair (e.g.
+    // RSM_E_DEGENERATE_MARGIN, the reference's exit(0)) does not stop the others.
+    auto worker = [&](rsm_ctx *c) {
+        for (int p = next.fetch_add(1); p < n_pairs; p = next.fetch_add(1)) st[(size_t)p] = rsm_match_pair(c, &in[p], &out[p]);
+    };
+    const int nt = std::min(n_ctx, std::max(n_pairs, 1));
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; i++) th.emplace_back(worker, ctxs[i]);
+    worker(ctxs[0]);
+    for (auto &t : th) t.join();
+    int first = RSM_OK;
+    for (int p = 0; p < n_pairs; p++) {
+        if (status) status[p] = st[(size_t)p];
+        if (first == RSM_OK && st[(size_t)p] != RSM_OK) first = st[(size_t)p];
+    }
+    return first;
+}
+
+extern "C" int rsm_match_pairs_multi_gpu(const rsm_pair_in *in, int n_pairs, int n_gpus, int pairs_in_flight,
+                                         rsm_pair_out *out, int *status) {
+    if (n_pairs < 0 || (n_pairs > 0 && (!in || !out)) || n_gpus < 0 || pairs_in_flight < 0) return RSM_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RSM_E_HIP;
+    if (n_gpus == 0 || n_gpus > ndev) n_gpus = ndev;
+    if (pairs_in_flight == 0) pairs_in_flight = 2;
+    std::vector<rsm_ctx *> ctxs;
+    int s = RSM_OK;
+    // context i lives on GPU i % n_gpus: the queue hands consecutive pairs to different GPUs first
+    for (int i = 0; i < n_gpus * pairs_in_flight && i < std::max(n_pairs, 1) && s == RSM_OK; i++) {
+        rsm_ctx *c = nullptr;
+        s = rsm_create(&c, i % n_gpus);
+        if (s == RSM_OK) ctxs.push_back(c);
+    }
+    if (s == RSM_OK) s = rsm_match_pairs(ctxs.data(), (int)ctxs.size(), in, out, n_pairs, status);
+    for (rsm_ctx *c : ctxs) rsm_destroy(c);
+    return s;
 }
 
 // =================================================================================================

@@ -110,3 +110,41 @@ def test_c5_fullsize_properties(ctx):
     err = np.abs(d0[ys[sel], xs[sel]] - (x1 - x0))
     assert np.median(err) < 0.5 and np.percentile(err, 95) < 1.5, (np.median(err), np.percentile(err, 95))
     assert 0 < res.n_points <= res.v_top and np.isfinite(res.xyz).all()
+
+
+def test_pairs_in_flight_equal_sequential_runs():
+    """rsm_run_pairs / rsm_match_pairs: several pairs in flight on one GPU (two or three contexts, a work queue over
+    pairs of different sizes, one degenerate pair in the middle) give exactly what one context gives pair by pair."""
+    from reconstruction_amd import Context, match_pairs, run_pairs
+    cfgs = [synth.config_small(160, 96, 3, radius=2, pair=1, holes=True),
+            synth.config_small(256, 128, 3, radius=2, pair=5, occlude=True, mask_l0_width=48, border_l0=5),
+            synth.config_small(96, 64, 2, radius=2, pair=0),
+            synth.config_small(288, 160, 3, radius=6, pair=10, mask_l0_width=40, border_l0=9),
+            synth.config_small(160, 96, 2, radius=5, offset=4, pair=2, border_l0=7)]
+    bad = synth.config_small(96, 64, 2, radius=2, pair=0)
+    bad.mask = [np.zeros_like(bad.mask[0]), np.zeros_like(bad.mask[1])]
+    with Context(0) as one:
+        seq = [one.match_pair(c) for c in cfgs]
+    pool = [Context(0) for _ in range(3)]
+    try:
+        allc = cfgs[:2] + [bad] + cfgs[2:]
+        res, status = match_pairs(pool, allc)
+        assert status == [0, 0, -2, 0, 0, 0] and res[2] is None      # RSM_E_DEGENERATE_MARGIN does not stop the others
+        res = res[:2] + res[3:]
+        for a, b in zip(res, seq):
+            assert a.margin == b.margin and a.v_top == b.v_top and a.n_points == b.n_points
+            for v in range(2):
+                assert np.array_equal(a.disparity[v], b.disparity[v])
+            assert np.array_equal(a.xyz, b.xyz, equal_nan=True) and np.array_equal(a.bgr, b.bgr)
+        # resident pairs, run together
+        pool[0].upload_pair(cfgs[0]); pool[1].upload_pair(cfgs[1]); pool[2].upload_pair(cfgs[3])
+        for _ in range(3):
+            run_pairs(pool)
+        for c, b in zip(pool, (seq[0], seq[1], seq[3])):
+            a = c.download_pair()
+            for v in range(2):
+                assert np.array_equal(a.disparity[v], b.disparity[v])
+            assert np.array_equal(a.xyz, b.xyz, equal_nan=True)
+    finally:
+        for c in pool:
+            c.close()
