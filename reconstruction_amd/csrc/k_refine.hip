@@ -405,6 +405,174 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two Jacobi sweeps per launch (option refine_multi_from; OFF by default -- measured slower, see below).
+// A sweep moves 52 B per pixel through the fabric (state in and out, and the lines of both cache ways).  Here a
+// workgroup keeps a tile of the state in LDS across two sweeps: it loads the 20 x 66 input values around its
+// 16 x 62 output pixels, computes sweep t on 18 x 64 (one ring of redundant work: 1.16x), sweep t+1 on its own
+// 16 x 62 from the LDS copy, and writes only that -- per two sweeps the state crosses the fabric once and the
+// second sweep's cache entries mostly come from lines the first one pulled into L2.  Rows are processed in a rolled
+// loop (a wave per row, values from LDS, the entry from global memory), so the data-term routine exists once.
+// Cache misses are served inside the wave (list in LDS, four lanes per entry).  The ring pixels belong to
+// neighbouring workgroups, which may miss on them too: a new entry is therefore never written to the cache during
+// the launch (a reader could see a torn key / pwp / delta triple) but appended to an update list that
+// k_refine_apply scatters afterwards.  Dropping a record (list full, or a second miss on the same way of the same
+// pixel in this launch) is always safe: the cache keeps an older, still consistent entry.
+// Values are those of two single sweeps, bit for bit (tests/test_gpu_parity.py).
+// MEASURED (C2 top level, round 2): 232 us per launch = 116 us per sweep against 107 us for a settled single sweep.
+// PMC: 93.7 M VALU wave-instructions per launch, VALU busy 156 us of chip time -- the halo, the tile bookkeeping and
+// the per-row loop cost more issue slots than the halved traffic returns; variants that stage both cache ways in
+// LDS up front (64 KB per workgroup, 2 workgroups per CU) or update five independent pixels per lane (248 VGPRs)
+// ran at 283-310 us.  The single sweep is VALU-active 60 of its 107 us (36.8 M quad-cycles): the stage sits within
+// 1.8x of its fp64 issue floor and at the fabric's rate for its traffic, so halving the traffic alone cannot halve it.
+#define RM_TW 64
+#define RM_TR 16
+template <int TOP>
+__global__ __launch_bounds__(256) void k_refine_multi(StageArgs a) {
+    __shared__ double tin[RM_TR + 4][RM_TW + 2]; // rows Y0-2 .. Y0+17, columns X0-1 .. X0+64 of the input
+    __shared__ double ts1[RM_TR + 2][RM_TW];     // rows Y0-1 .. Y0+16, columns X0 .. X0+63 after the first sweep
+    __shared__ uint8_t tflag[RM_TR + 2][RM_TW];  // way + 1 of a record the first sweep emitted for the pixel
+    __shared__ uint32_t s_list[4][64];
+    __shared__ double s_res[4][16][2];
+    const DirArgs &d = a.d[blockIdx.z];
+    const int W = a.W, H = a.H;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int X0 = d.own.XL + blockIdx.x * (RM_TW - 2); // lane l <-> column X0 + l; lanes 1..62 are this workgroup's
+    const int Y0 = d.own.YL + 1 + blockIdx.y * RM_TR;   // own rows Y0 .. Y0+15
+    const int xlo = d.own.XL + 1, xhi = d.own.XR - 1, ylo = d.own.YL + 1, yhi = d.own.YR - 1; // the interior
+    if (Y0 > yhi || X0 + 1 > xhi) return; // uniform
+    const double *__restrict__ in = d.f64_a;
+    double *__restrict__ out = d.f64_b;
+    for (int e = threadIdx.x; e < (RM_TR + 4) * (RM_TW + 2); e += 256) {
+        const int i = e / (RM_TW + 2), j = e - i * (RM_TW + 2);
+        const int yy = min(max(Y0 - 2 + i, 0), H - 1), xx = min(max(X0 - 1 + j, 0), W - 1);
+        tin[i][j] = in[(size_t)yy * W + xx];
+    }
+    __syncthreads();
+    const int x = X0 + lane;
+    const int xc = min(x, W - 1);
+    const bool xin = x >= xlo && x <= xhi;
+    const bool xown = xin && lane >= 1 && lane <= RM_TW - 2;
+    const unsigned shard = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7u) & (RF_UPD_SHARDS - 1);
+    int32_t *cnt = a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS + shard;
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        const int nrows = p ? RM_TR : RM_TR + 2;
+#pragma unroll 1
+        for (int r = wid; r < nrows; r += 4) {
+            const int y = p ? Y0 + r : Y0 - 1 + r;
+            double dC, dN, dS, dE, dW;
+            if (p == 0) {
+                const int i = r + 1, j = lane + 1;
+                dC = tin[i][j];
+                dN = tin[i - 1][j];
+                dS = tin[i + 1][j];
+                dE = tin[i][j + 1];
+                dW = tin[i][j - 1];
+            } else {
+                const int i = r + 1;
+                dC = ts1[i][lane];
+                dN = ts1[i - 1][lane];
+                dS = ts1[i + 1][lane];
+                dE = ts1[i][min(lane + 1, RM_TW - 1)];
+                dW = ts1[i][max(lane - 1, 0)];
+            }
+            const bool yin = y >= ylo && y <= yhi;
+            const bool live = yin && (p ? xown : xin) && dC != (double)NOMATCH; // .cpp:613
+            const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                             (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
+            const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
+            const size_t pix = (size_t)min(max(y, 0), H - 1) * W + xc;
+            const size_t cpix = pix + (size_t)(rel & 1) * a.rf_stride;
+            const int crel = d.rf_key[cpix];
+            double pwp = d.rf_pwp[cpix], delta = d.rf_delta[cpix];
+            const bool miss = live && mode != 0 && crel != rel;
+            const unsigned long long mm = __ballot(miss);
+            if (mm) { // wave-uniform
+                const int n = __popcll(mm), pos = __popcll(mm & ((1ull << lane) - 1ull));
+                if (miss) s_list[wid][pos] = (uint32_t)lane | ((uint32_t)(rel & 0xffff) << 16);
+                __builtin_amdgcn_wave_barrier();
+                for (int done = 0; done < n; done += 16) { // four lanes per entry, 16 entries per round
+                    const int e = done + (lane >> 2);
+                    const bool ok = e < n;
+                    const uint32_t en = s_list[wid][ok ? e : done];
+                    const int ex = X0 + (int)(en & 0xffff), er = (int)(int16_t)(en >> 16);
+                    double pq, qq;
+                    refine_data_term_quad(d.img4_own, d.img4_oth, W, H, ex, y, er + ex, lane & 3, pq, qq);
+                    if (ok && (lane & 3) == 0) {
+                        s_res[wid][e - done][0] = pq;
+                        s_res[wid][e - done][1] = qq;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (miss && pos >= done && pos < done + 16) {
+                        pwp = s_res[wid][pos - done][0];
+                        delta = s_res[wid][pos - done][1];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // the new entries of this workgroup's own pixels go to the update list
+                const bool own = miss && xown && y >= Y0 && y < Y0 + RM_TR;
+                const bool emit = own && (p == 0 || tflag[r + 1][lane] != (uint8_t)((rel & 1) + 1));
+                const unsigned long long em = __ballot(emit);
+                if (em) {
+                    const int leader = __builtin_ctzll(em);
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(cnt, __popcll(em));
+                    base = __shfl(base, leader) + __popcll(em & ((1ull << lane) - 1ull));
+                    if (emit && base < a.upd_cap) {
+                        RfUpd u;
+                        u.pix = (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
+                        u.rel = rel;
+                        u.pwp = pwp;
+                        u.delta = delta;
+                        a.upd_list[(size_t)shard * a.upd_cap + base] = u;
+                    }
+                }
+                if (p == 0) tflag[r][lane] = emit ? (uint8_t)((rel & 1) + 1) : (uint8_t)0;
+            } else if (p == 0) {
+                tflag[r][lane] = 0;
+            }
+            const double val = !live ? dC : (mode == 0 ? dC /* .cpp:655 */ : refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws));
+            if (p == 0) ts1[r][lane] = val;
+            else if (live) out[pix] = val;
+        }
+        __syncthreads();
+    }
+}
+
+// scatters the update list of the k_refine_multi launch a.flag3 into the cache and clears the other counter set
+__global__ __launch_bounds__(256) void k_refine_apply(StageArgs a) {
+    const int32_t *cnt = a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS;
+    if (blockIdx.x == 0 && threadIdx.x < RF_UPD_SHARDS) a.upd_cnt[((a.flag3 + 1) & 1) * RF_UPD_SHARDS + threadIdx.x] = 0;
+    for (int sh = blockIdx.y; sh < RF_UPD_SHARDS; sh += gridDim.y) {
+        const int n = min(cnt[sh], a.upd_cap);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const RfUpd u = a.upd_list[(size_t)sh * a.upd_cap + i];
+            const DirArgs &d = a.d[u.pix >> 31];
+            const size_t cpix = (size_t)(u.pix & 0x7fffffffu) + (size_t)(u.rel & 1) * a.rf_stride;
+            d.rf_key[cpix] = (int16_t)u.rel;
+            d.rf_pwp[cpix] = u.pwp;
+            d.rf_delta[cpix] = u.delta;
+        }
+    }
+}
+
+void launch_refine_multi(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    int rows = 0, cols = 0;
+    for (int v = 0; v < a.ndir; v++) {
+        rows = max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
+        cols = max(cols, a.d[v].own.XR - a.d[v].own.XL - 1);
+    }
+    if (rows <= 0 || cols <= 0) return;
+    const dim3 grid((cols + RM_TW - 3) / (RM_TW - 2), (rows + RM_TR - 1) / RM_TR, a.ndir);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    if (a.flag) hipLaunchKernelGGL(k_refine_multi<1>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_refine_multi<0>, grid, dim3(256), 0, st, a);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    hipLaunchKernelGGL(k_refine_apply, dim3(8, RF_UPD_SHARDS), dim3(256), 0, st, a);
+}
+
 // One sweep f64_a -> f64_b (a.flag2 = sweep index, a.flag = top level) over the interior rows [a.row_lo, a.row_hi)
 // (the first sweep always covers the whole interior); ev0 / ev1 (optional) bracket the launch.
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {

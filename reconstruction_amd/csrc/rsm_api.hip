@@ -37,14 +37,15 @@ enum Stage {
     ST_REFINE_INIT,
     ST_REFINE_SWEEP,     // all levels below the top
     ST_REFINE_SWEEP_TOP, // the top level's sweeps (light + worklist kernels)
-    ST_REFINE_LIGHT_TOP, // only the k_refine_sweep<1> launches of the top level (the dominant kernel)
+    ST_REFINE_LIGHT_TOP, // only the k_refine_sweep<1> launches of the top level
+    ST_REFINE_MULTI_TOP, // only the k_refine_multi<1> launches of the top level (two sweeps each; the dominant kernel)
     ST_UNIQ64,
     ST_CLOUD,
     ST_COUNT
 };
 static const char *kStageNames[ST_COUNT] = {"pyramid", "margin", "boxsum", "initial_match", "smooth", "order",
                                             "uniqueness_s16", "rematch", "median", "refine_init",
-                                            "refine_sweep", "refine_sweep_top", "refine_light_top", "uniqueness_f64", "cloud"};
+                                            "refine_sweep", "refine_sweep_top", "refine_light_top", "refine_multi_top", "uniqueness_f64", "cloud"};
 
 struct EvPair {
     hipEvent_t a, b;
@@ -83,6 +84,9 @@ struct rsm_ctx {
     uint32_t *tie_list = nullptr; // NCC tie pixels (k_ncc_exact)
     int32_t *tie_cnt = nullptr;   // [2 * level + (Rematch ? 1 : 0)]
     double *rf_pwp[2]{}, *rf_delta[2]{};
+    RfUpd *upd_list = nullptr; // k_refine_multi's cache updates
+    int32_t *upd_cnt = nullptr;
+    int upd_cap = 0;
     int32_t *prefix = nullptr;
     int *d_j1 = nullptr, *d_j2 = nullptr;   // structuring-element spans: Rectify's mask erosion
     int *d_cj1 = nullptr, *d_cj2 = nullptr; // ... and DisparityToCloud's (uploaded with the pair)
@@ -107,6 +111,8 @@ struct rsm_ctx {
     int opt_no_exact = 0;
     int opt_heavy_exclusive = 1; // large-level refine sections of contexts sharing a GPU take turns (heavy_begin)
     int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
+    int opt_refine_multi_from = 0;  // first sweep of a level that may run in the two-sweeps-per-launch kernel (0: never = default: measured slower, k_refine.hip)
+    int opt_refine_multi_min_px = 400000; // ... at levels with at least this many margin pixels
     int opt_refine_band_rows = 0; // > 0: band height in rows, overrides refine_band_mb (tests)
 
     // profiling
@@ -325,6 +331,9 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->rf_cnt, 32 + 2 * (size_t)in->height); // level k uses rf_cnt + k: [0] wide-pixel count, [16 + dir * H + y] Rematch pixels of a row
     DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
     DALLOC(c, c->tie_list, 2 * px + 64);
+    c->upd_cap = (int)std::min<size_t>(65536, std::max<size_t>(1024, px / 8));
+    DALLOC(c, c->upd_list, (size_t)RF_UPD_SHARDS * c->upd_cap);
+    DALLOC(c, c->upd_cnt, 2 * RF_UPD_SHARDS);
     DALLOC(c, c->tie_cnt, 2 * RSM_MAX_LEVELS);
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->blk, CLOUD_BLOCKS(in->width, in->height));
@@ -421,6 +430,8 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
     else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = value != 0;
     else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
+    else if (!strcmp(name, "refine_multi_from")) c->opt_refine_multi_from = (int)std::max(0LL, std::min(value, 100000LL));
+    else if (!strcmp(name, "refine_multi_min_px")) c->opt_refine_multi_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
     else if (!strcmp(name, "refine_band_rows")) c->opt_refine_band_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
@@ -465,6 +476,9 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.ncc_cnt = c->rf_cnt + k; // a counter per level, zeroed together at the start of the run
     a.tie_list = c->tie_list;
     a.tie_cnt = c->tie_cnt + 2 * k;
+    a.upd_list = c->upd_list;
+    a.upd_cnt = c->upd_cnt;
+    a.upd_cap = c->upd_cap;
     a.rf_stride = c->cap_px;
     a.row_lo = 0;
     a.row_hi = INT_MAX;
@@ -512,67 +526,93 @@ static bool degenerate(const Mg &m) { return m.YL >= m.YR || m.XL >= m.XR; } // 
 // 23.1 / 20.2 / 19.4 ms against 19.1 ms whole-frame.  tests/micro/wsbw.hip shows why: a working set that fits the
 // Infinity Cache streams at 6.0-6.5 TB/s (read) against 5.3 TB/s from HBM -- the fabric between the XCD L2s and
 // the memory side is the limit either way -- and the shorter launches lose more than that 15 percent.
+// Returns the number of sweeps launched; *final_in_B tells which buffer holds the result.
+// Large levels run their settled sweeps two per launch (k_refine_multi, from sweep `refine_multi_from` on: before
+// that too many pixels still miss the data-term cache for its in-wave miss service).
 static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double *const bufB[2], int iters,
-                         hipStream_t st, bool top) {
+                         hipStream_t st, bool top, bool *final_in_B) {
     int launches = 0;
+    bool curB = false; // the current values are in bufA
     auto bind = [&](int t) {
         for (int v = 0; v < a.ndir; v++) {
-            a.d[v].f64_a = (t & 1) ? bufB[v] : bufA[v];
-            a.d[v].f64_b = (t & 1) ? bufA[v] : bufB[v];
+            a.d[v].f64_a = curB ? bufB[v] : bufA[v];
+            a.d[v].f64_b = curB ? bufA[v] : bufB[v];
         }
         a.flag2 = t;
     };
-    auto launch = [&](int lo, int hi) {
+    auto window_bytes = [&](int lo, int hi) { // 16 B per interior pixel of the rows [lo, hi) (fp64 in + out)
+        double bytes = 0;
+        for (int v = 0; v < a.ndir; v++) {
+            const int r0 = std::max(a.d[v].own.YL + 1, lo), r1 = std::min(a.d[v].own.YR, hi);
+            if (r1 > r0) bytes += 16.0 * (r1 - r0) * (a.d[v].own.XR - a.d[v].own.XL + 1);
+        }
+        return bytes;
+    };
+    auto launch = [&](int t, int lo, int hi, bool multi) { // sweep t (and t + 1 if multi) over the rows [lo, hi)
+        bind(t);
         a.row_lo = lo;
         a.row_hi = hi;
-        if (c && c->profile && top && (launches & 7) == 4) { // every 8th launch of the dominant kernel
-            const int es = prof_slot(c, ST_REFINE_LIGHT_TOP);
-            launch_refine_sweep(a, st, c->evpool[es].a, c->evpool[es].b);
-            double bytes = 0; // 16 B per interior pixel of the window (fp64 read + write per sweep)
-            for (int v = 0; v < a.ndir; v++) {
-                const int r0 = std::max(a.d[v].own.YL + 1, lo), r1 = std::min(a.d[v].own.YR, hi);
-                if (r1 > r0) bytes += 16.0 * (r1 - r0) * (a.d[v].own.XR - a.d[v].own.XL + 1);
-            }
-            c->prof_launches[ST_REFINE_LIGHT_TOP] += 1;
-            c->prof_bytes[ST_REFINE_LIGHT_TOP] += bytes;
-        } else {
-            launch_refine_sweep(a, st);
+        const bool timed = c && c->profile && top && (multi ? (launches & 7) == 4 || (launches & 7) == 5 : (launches & 7) == 4);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) { // every 8th sweep of the dominant kernel
+            const int es = prof_slot(c, multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP);
+            e0 = c->evpool[es].a;
+            e1 = c->evpool[es].b;
+            c->prof_launches[multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP] += 1;
+            c->prof_bytes[multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP] += (multi ? 2.0 : 1.0) * window_bytes(lo, hi);
         }
-        launches++;
+        if (multi) launch_refine_multi(a, st, e0, e1);
+        else launch_refine_sweep(a, st, e0, e1);
+        launches += multi ? 2 : 1;
+        curB = !curB;
     };
+    *final_in_B = false;
     if (iters <= 0) return 0;
     int Y0 = INT_MAX, Y1 = INT_MIN; // interior rows [Y0, Y1) over the directions
-    double row_bytes = 0;
+    double row_bytes = 0, px = 0;
     for (int v = 0; v < a.ndir; v++) {
         Y0 = std::min(Y0, a.d[v].own.YL + 1);
         Y1 = std::max(Y1, a.d[v].own.YR);
         row_bytes += 52.0 * (a.d[v].own.XR - a.d[v].own.XL + 1);
+        px += (double)(a.d[v].own.XR - a.d[v].own.XL + 1) * (a.d[v].own.YR - a.d[v].own.YL + 1);
     }
     bind(0);
     a.row_lo = 0;
     a.row_hi = INT_MAX;
     launch_refine_sweep(a, st); // k_refine_first: whole interior
     launches++;
+    curB = true;
     const int nsw = iters - 1;
     int B = 0;
     if (c && c->opt_refine_band_rows > 0) B = c->opt_refine_band_rows;
     else if (c && c->opt_refine_band_mb > 0) B = std::max(4 * RF_PPT, (int)((double)c->opt_refine_band_mb * 1048576.0 / row_bytes) & ~(RF_PPT - 1));
     if (B <= 0 || B >= Y1 - Y0 || nsw < 2) { // whole-frame sweeps
-        for (int t = 1; t < iters; t++) {
-            bind(t);
-            launch(0, INT_MAX);
+        const bool multi = c && c->opt_refine_multi_from > 0 && a.upd_list && px / a.ndir >= c->opt_refine_multi_min_px;
+        if (multi) (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
+        int nmulti = 0;
+        for (int t = 1; t < iters;) {
+            if (multi && t >= c->opt_refine_multi_from && t + 1 < iters) {
+                a.flag3 = nmulti++;
+                launch(t, 0, INT_MAX, true);
+                t += 2;
+            } else {
+                launch(t, 0, INT_MAX, false);
+                t += 1;
+            }
         }
-    } else {
+    } else { // time-skewed bands: sweep u + 1 of band j reads what sweep u wrote, buffers alternate with u
         for (int j = 0; Y0 + j * B - (nsw - 1) < Y1; j++)
             for (int u = 0; u < nsw; u++) {
                 const int lo = std::max(Y0 + j * B - u, Y0), hi = std::min(Y0 + (j + 1) * B - u, Y1);
                 if (lo >= hi) continue;
-                bind(u + 1);
-                launch(lo, hi);
+                curB = (u & 1) == 0; // sweep u + 1 reads B for even u
+                launch(u + 1, lo, hi, false);
             }
+        curB = (iters & 1) != 0;
     }
     a.row_lo = 0;
     a.row_hi = INT_MAX;
+    *final_in_B = curB;
     return launches;
 }
 
@@ -729,9 +769,10 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         a.flag = (k == N - 1);
         double *bufA[2] = {c->f64[ia][0], c->f64[ia][1]}, *bufB[2] = {c->f64[ib][0], c->f64[ib][1]};
         const bool heavy = heavy_begin(c, Pk);
-        const int nlaunch = refine_sweeps(c, a, bufA, bufB, iters, st, k == N - 1);
+        bool inB = false;
+        const int nlaunch = refine_sweeps(c, a, bufA, bufB, iters, st, k == N - 1, &inB);
         heavy_end(c, heavy);
-        const int cur = (iters & 1) ? ib : ia; // sweep t reads (t even ? ia : ib) and writes the other
+        const int cur = inB ? ib : ia;
         prof_end(c, ps12, st_sweep, nlaunch, 32.0 * Pk * iters);
 
         // ---- UniquenessContraint<double> (.cpp:109) on the refined maps (now in f64[cur])
@@ -1228,6 +1269,9 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.rf_pwp = t.alloc<double>(2 * px);
     d.rf_delta = t.alloc<double>(2 * px);
     a.rf_stride = px;
+    a.upd_cap = 4096;
+    a.upd_list = t.alloc<RfUpd>((size_t)RF_UPD_SHARDS * a.upd_cap);
+    a.upd_cnt = t.alloc<int32_t>(2 * RF_UPD_SHARDS);
     if (!t.ok) return finish(c, t);
     if (iterations > RF_MAX_SWEEPS) return set_err(c, RSM_E_INVALID, "iterations");
     d.f64_a = A;
@@ -1238,8 +1282,9 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.img4_oth = i4t;
     launch_refine_init(a, c->stream);
     double *bufA[2] = {A, nullptr}, *bufB[2] = {B, nullptr};
-    refine_sweeps(c, a, bufA, bufB, iterations, c->stream, false);
-    d.f64_a = (iterations & 1) ? B : A; // the buffer the last sweep wrote
+    bool inB = false;
+    refine_sweeps(c, a, bufA, bufB, iterations, c->stream, false, &inB);
+    d.f64_a = inB ? B : A; // the buffer the last sweep wrote
     t.down(disp_out, (const double *)d.f64_a, px);
     return finish(c, t);
 }

@@ -37,6 +37,14 @@ struct DirArgs {
     double *rf_pwp, *rf_delta; // refine cache: data-term weight and offset
 };
 
+// A data-term cache entry computed by k_refine_multi, applied to the cache by k_refine_apply after the launch.
+struct RfUpd {
+    uint32_t pix; // pixel index | direction << 31
+    int32_t rel;  // iMatch - x of the entry (its parity selects the way)
+    double pwp, delta;
+};
+#define RF_UPD_SHARDS 32 // append counters (one counter serialises at ~88 appends per microsecond)
+
 struct StageArgs {
     DirArgs d[2];
     int ndir;    // 1 or 2 (gridDim.z)
@@ -49,6 +57,10 @@ struct StageArgs {
     int flag2;   // refine: sweep index
     int row_lo, row_hi; // refine sweep: only rows [row_lo, row_hi) of the interior are updated (band schedule, k_refine.hip)
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
+    RfUpd *upd_list;   // refine (k_refine_multi): RF_UPD_SHARDS regions of upd_cap records
+    int32_t *upd_cnt;  // [2][RF_UPD_SHARDS]: append counters, the set in use alternates per launch (flag3 & 1)
+    int upd_cap;
+    int flag3;         // refine multi: launch index (counter set)
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int opt_no_exact;               // skip k_ncc_exact (timing A/B only: ties then follow the integer form)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
@@ -87,6 +99,8 @@ void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// TWO sweeps f64_a -> f64_b in one launch (a.flag3 = launch index) + the launch that applies its cache updates
+void launch_refine_multi(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // cloud: returns nothing; *d_npoints (device int64) receives the point count; `flags` = W*H bytes of scratch,
 // `blk` = launch_bad_blocks' map (CLOUD_BLOCKS(W,H) bytes)

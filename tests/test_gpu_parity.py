@@ -384,3 +384,29 @@ def test_whole_pair_against_the_libm_exp_oracle(ctx):
         assert s_["above_1e3"] <= 1e-3 * s_["valid"]
         assert s_["max_rel"] < 2e-2
     assert res.n_points == ref["n_points"]
+
+
+@pytest.mark.parametrize("first", [1, 2, 7, 32])
+def test_refine_two_sweeps_per_launch_is_bit_identical(ctx, first):
+    """k_refine_multi (two Jacobi sweeps per launch on an LDS-resident tile, deferred cache updates) from sweep
+    `first` on -- from the very first cached sweep, where nearly every pixel misses, to the settled regime -- gives
+    the single-sweep result, i.e. the oracle's, bit for bit; odd and even numbers of remaining sweeps."""
+    ctx.set_option("refine_multi_from", first)
+    ctx.set_option("refine_multi_min_px", 0)
+    try:
+        for name in ("s512x384_5levels", "s192x128_ellipse", "s320x160_occluded_neg_r4"):
+            cfg, rec, fin = stages(name)
+            for q in rec:
+                if q["stage"] != "refine":
+                    continue
+                k, v = q["level"], q["v"]
+                for iters in (q["iters"], q["iters"] - 1):
+                    want = q["out"] if iters == q["iters"] else orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
+                    g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
+                    assert np.array_equal(g, want), diff_report("multi from %d %s L%d v%d iters %d" % (first, name, k, v, iters), g, want)
+            res = ctx.match_pair(cfg)
+            for v in range(2):
+                assert np.array_equal(res.disparity[v], fin["disparity"][v])
+    finally:
+        ctx.set_option("refine_multi_from", 0)
+        ctx.set_option("refine_multi_min_px", 400000)
