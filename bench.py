@@ -96,12 +96,11 @@ def main():
             local = []
             for i, c in enumerate(ctxs):
                 n = c.n_points
-                xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
-                bgr = torch.empty((n, 3), dtype=torch.uint8, device=dev)
-                c.export_cloud_device(xyz.data_ptr(), bgr.data_ptr(), n)
+                rec = torch.empty((n, 16), dtype=torch.uint8, device=dev)  # rsm_point16 records: 16 B per point
+                c.pack_cloud16(rec.data_ptr(), n)
                 if backend != "nccl":
-                    xyz, bgr = xyz.cpu(), bgr.cpu()
-                local.append((rank * F + i, xyz, bgr))
+                    rec = rec.cpu()
+                local.append((rank * F + i, rec))
             h = gather_clouds_async(local, dst=0)
             drain()
             pending[0] = h

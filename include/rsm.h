@@ -37,7 +37,8 @@ typedef enum rsm_status {
     RSM_E_DEGENERATE_MARGIN = -2, /* YL>=YR || XL>=XR (reference: exit(0), .cpp:827-830) */
     RSM_E_HIP = -3,               /* HIP runtime error (rsm_last_error() has the text) */
     RSM_E_NOMEM = -4,
-    RSM_E_STATE = -5              /* call order (e.g. run before upload) */
+    RSM_E_STATE = -5,             /* call order (e.g. run before upload) */
+    RSM_E_COMM = -6               /* RCCL missing or failed (rsm_comm_last_error() has the text) */
 } rsm_status;
 
 /* struct Boundary, reconstruction/CManageData.h:10-14 (same field order) */
@@ -122,6 +123,35 @@ int rsm_match_pairs(rsm_ctx *const *ctxs, int n_ctx, const rsm_pair_in *in, rsm_
  * is rsm_gather_clouds below. */
 int rsm_match_pairs_multi_gpu(const rsm_pair_in *in, int n_pairs, int n_gpus, int pairs_in_flight, rsm_pair_out *out,
                               int *status);
+
+/* ---- multi-GPU, one process per GPU: RCCL gather of the per-pair clouds -------------------------- */
+/* The record that travels: what CCloudOptimization::InsertPoint keeps of a point (CloudOptimization/
+ * CCloudOptimization.cpp:61: the fp64 point cast to float) plus the colour of imagePyrm[top][0] (.cpp:756). */
+typedef struct rsm_point16 {
+    float x, y, z;
+    uint8_t b, g, r, pad;
+} rsm_point16;
+/* Packs the cloud of the last rsm_run_pair into 16-byte records in a caller-owned DEVICE buffer (capacity
+ * max_points); *n_points receives the number written.  This is the send buffer of rsm_gather_clouds. */
+int rsm_pack_cloud16(rsm_ctx *ctx, rsm_point16 *d_dst, int64_t max_points, int64_t *n_points);
+
+#define RSM_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
+#define RSM_COMM_MAX_PAIRS 4096 /* pairs per gather */
+typedef struct rsm_comm rsm_comm;
+/* Rank 0 makes the id (ncclGetUniqueId) and hands its bytes to the other ranks by whatever launcher started them
+ * (MPI, a file, torch.distributed's store, ...); then every rank creates its communicator on its GPU. */
+int rsm_comm_unique_id(char id[RSM_COMM_ID_BYTES]);
+int rsm_comm_create(rsm_comm **comm, const char id[RSM_COMM_ID_BYTES], int rank, int world, int hip_device);
+void rsm_comm_destroy(rsm_comm *comm);
+const char *rsm_comm_last_error(const rsm_comm *comm);
+/* Fan-in of the clouds of all pairs to rank `root` -- the replacement of the global `cloud_in += cloud` accumulation
+ * (CCloudOptimization.cpp:61,123) when pairs are sharded one process per GPU.  Every rank passes its n_local clouds
+ * (device buffers of 16-byte records, their pair ids in [0, n_pairs_total) and point counts).  On the root the clouds
+ * of ALL pairs arrive in d_out (device, capacity max_out records) in pair order; out_offsets (host, n_pairs_total + 1)
+ * receives each pair's first record.  Collective: every rank of the communicator calls it. */
+int rsm_gather_clouds(rsm_comm *comm, int root, int n_local, const int *pair_ids, const rsm_point16 *const *d_clouds,
+                      const int64_t *n_points, int n_pairs_total, rsm_point16 *d_out, int64_t max_out,
+                      int64_t *out_offsets);
 
 /* Validation knob (results never change): "ncc_bytes" = 1 forces the generic byte-wise NCC kernel instead of the
  * dot4 one. */

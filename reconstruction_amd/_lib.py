@@ -17,6 +17,7 @@ RSM_E_DEGENERATE_MARGIN = -2
 RSM_E_HIP = -3
 RSM_E_NOMEM = -4
 RSM_E_STATE = -5
+RSM_E_COMM = -6
 NOMATCH = -10000
 
 
@@ -75,6 +76,8 @@ EXPORTS = [
     "rsm_stage_set_boundary", "rsm_stage_rematch", "rsm_stage_median", "rsm_stage_refine", "rsm_stage_cloud",
     "rsm_bench_ncc", "rsm_write_ply", "rsm_rectify_pair", "rsm_stereo_rectify", "rsm_stage_rect_map",
     "rsm_stage_remap", "rsm_stage_erode_gray", "rsm_run_pairs", "rsm_run_pairs_repeat", "rsm_match_pairs", "rsm_match_pairs_multi_gpu",
+    "rsm_pack_cloud16", "rsm_comm_unique_id", "rsm_comm_create", "rsm_comm_destroy", "rsm_comm_last_error",
+    "rsm_gather_clouds",
 ]
 
 _lib = None
@@ -95,5 +98,9 @@ def load():
     lib.rsm_profile_stage_name.restype = C.c_char_p
     lib.rsm_destroy.restype = None
     lib.rsm_destroy.argtypes = [C.c_void_p]
+    lib.rsm_comm_last_error.restype = C.c_char_p
+    lib.rsm_comm_last_error.argtypes = [C.c_void_p]
+    lib.rsm_comm_destroy.restype = None
+    lib.rsm_comm_destroy.argtypes = [C.c_void_p]
     _lib = lib
     return lib

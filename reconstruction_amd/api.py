@@ -228,6 +228,13 @@ class Context:
         self._chk(self._lib.rsm_export_cloud_device(self._h, C.c_void_p(xyz_ptr or None), C.c_void_p(bgr_ptr or None),
                                                     C.c_int64(max_points)))
 
+    def pack_cloud16(self, dst_ptr, max_points) -> int:
+        """rsm_pack_cloud16: the last cloud as 16-byte point records (float xyz + BGR) into a caller-owned device
+        buffer (address); returns the number of records written."""
+        n = C.c_int64()
+        self._chk(self._lib.rsm_pack_cloud16(self._h, C.c_void_p(dst_ptr or None), C.c_int64(max_points), C.byref(n)))
+        return int(n.value)
+
     @property
     def n_points(self):
         return self.result_device()[2]

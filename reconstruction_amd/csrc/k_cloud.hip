@@ -8,6 +8,8 @@
 //   InsertPoint order of the reference.
 #include "rsm_dev.h"
 
+#include <algorithm>
+
 // prefix[y*(W+1) + x] = number of pixels != 255 in row y, columns [0, x)
 __global__ __launch_bounds__(256) void k_bad_prefix(const uint8_t *__restrict__ mask, int W, int H,
                                                     int32_t *__restrict__ prefix) {
@@ -251,4 +253,24 @@ void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *
     hipLaunchKernelGGL(k_cloud<0>, dim3(rows), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(256), 0, st, row_count, rows, row_offset, d_npoints);
     hipLaunchKernelGGL(k_cloud<1>, dim3(rows), dim3(256), 0, st, c);
+}
+
+// ---------------------------------------------------------------- 16-byte point records (the RCCL payload)
+// fp64 xyz -> float as CCloudOptimization::InsertPoint does (CloudOptimization/CCloudOptimization.cpp:61), + BGR.
+__global__ void k_pack_cloud16(const double *__restrict__ xyz, const uint8_t *__restrict__ bgr, int64_t n, uint4 *__restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint4 v;
+        v.x = __float_as_uint((float)xyz[3 * i]);
+        v.y = __float_as_uint((float)xyz[3 * i + 1]);
+        v.z = __float_as_uint((float)xyz[3 * i + 2]);
+        v.w = (uint32_t)bgr[3 * i] | ((uint32_t)bgr[3 * i + 1] << 8) | ((uint32_t)bgr[3 * i + 2] << 16);
+        dst[i] = v;
+    }
+}
+void launch_pack_cloud16(const double *xyz, const uint8_t *bgr, int64_t n, void *dst, hipStream_t st) {
+    if (n <= 0) return;
+    const int64_t blocks = std::min<int64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_pack_cloud16, dim3((unsigned)blocks), dim3(256), 0, st, xyz, bgr, n, (uint4 *)dst);
 }

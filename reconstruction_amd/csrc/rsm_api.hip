@@ -861,6 +861,19 @@ extern "C" int rsm_export_cloud_device(rsm_ctx *c, double *d_xyz, uint8_t *d_bgr
     return RSM_OK;
 }
 
+extern "C" int rsm_pack_cloud16(rsm_ctx *c, rsm_point16 *d_dst, int64_t max_points, int64_t *n_points) {
+    if (!c) return RSM_E_INVALID;
+    if (!c->have_result) return set_err(c, RSM_E_STATE, "no result");
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t n = c->n_points < max_points ? c->n_points : max_points;
+    if (n > (int64_t)c->cap_px) n = (int64_t)c->cap_px;
+    if (n > 0 && !d_dst) return RSM_E_INVALID;
+    launch_pack_cloud16(c->xyz, c->bgr, n, d_dst, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_points) *n_points = n > 0 ? n : 0;
+    return RSM_OK;
+}
+
 extern "C" int rsm_match_pair(rsm_ctx *c, const rsm_pair_in *in, rsm_pair_out *out) {
     int s = rsm_upload_pair(c, in);
     if (s != RSM_OK) return s;

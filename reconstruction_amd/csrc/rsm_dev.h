@@ -113,6 +113,7 @@ void launch_cloud(const double *disp, const int32_t *bad_prefix, const uint8_t *
                   const int *d_j1, const int *d_j2, const double *q16_scaled, const double *R,
                   const double *T, Mg own, uint8_t *flags, const uint8_t *blk, int32_t *row_count, int64_t *row_offset,
                   int64_t *d_npoints, double *xyz, uint8_t *bgr, int64_t max_points, hipStream_t st);
+void launch_pack_cloud16(const double *xyz, const uint8_t *bgr, int64_t n, void *dst16, hipStream_t st);
 void launch_count_masked(const uint8_t *mask, int W, int H, Mg m, unsigned long long *d_count, hipStream_t st);
 
 // Rectify (k_rectify.hip)

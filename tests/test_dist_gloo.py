@@ -32,15 +32,15 @@ def _worker(rank, world, port, n_pairs, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from reconstruction_amd.dist import gather_clouds, shard_pairs
+    from reconstruction_amd.dist import gather_clouds, pack_records, shard_pairs, unpack_records
     mine = shard_pairs(n_pairs, world, rank)
     local = []
     for p in mine:
         xyz, bgr = _cloud(p)
-        local.append((p, torch.from_numpy(xyz), torch.from_numpy(bgr)))
+        local.append((p, pack_records(xyz, bgr)))
     res = gather_clouds(local, dst=0)
     if rank == 0:
-        q.put([(pid, x.numpy().copy(), b.numpy().copy()) for pid, x, b in res])
+        q.put([(pid,) + unpack_records(r) for pid, r in res])
     else:
         assert res is None
     dist.barrier()
@@ -62,7 +62,7 @@ def test_shard_and_gather(world, n_pairs):
     assert [pid for pid, _, _ in res] == list(range(n_pairs))   # pair order, independent of the sharding
     for pid, xyz, bgr in res:
         ex, eb = _cloud(pid)
-        assert np.array_equal(xyz, ex) and np.array_equal(bgr, eb)
+        assert xyz.dtype == np.float32 and np.array_equal(xyz, ex.astype(np.float32)) and np.array_equal(bgr, eb)
 
 
 def test_shard_pairs_is_a_partition():
@@ -76,11 +76,13 @@ def test_shard_pairs_is_a_partition():
 
 
 def test_single_process_gather_is_identity():
-    from reconstruction_amd.dist import gather_clouds
-    loc = [(3, torch.zeros(2, 3, dtype=torch.float64), torch.zeros(2, 3, dtype=torch.uint8)),
-           (1, torch.ones(1, 3, dtype=torch.float64), torch.ones(1, 3, dtype=torch.uint8))]
+    from reconstruction_amd.dist import gather_clouds, pack_records, unpack_records
+    loc = [(3, pack_records(np.zeros((2, 3)), np.zeros((2, 3), np.uint8))),
+           (1, pack_records(np.ones((1, 3)), np.ones((1, 3), np.uint8)))]
     out = gather_clouds(loc)
-    assert [p for p, _, _ in out] == [1, 3]
+    assert [p for p, _ in out] == [1, 3]
+    xyz, bgr = unpack_records(out[0][1])
+    assert xyz.tolist() == [[1.0, 1.0, 1.0]] and bgr.tolist() == [[1, 1, 1]] and out[0][1].shape == (1, 16)
 
 
 def _worker_async(rank, world, port, rounds, q):
@@ -89,18 +91,18 @@ def _worker_async(rank, world, port, rounds, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from reconstruction_amd.dist import gather_clouds_async
+    from reconstruction_amd.dist import gather_clouds_async, pack_records, unpack_records
     got, pending = [], None
     for i in range(rounds):
         pair = i * world + rank
         xyz, bgr = _cloud(pair)
-        h = gather_clouds_async([(pair, torch.from_numpy(xyz), torch.from_numpy(bgr))], dst=0)
+        h = gather_clouds_async([(pair, pack_records(xyz, bgr))], dst=0)
         if pending is not None:
             got.append(pending.wait())
         pending = h
     got.append(pending.wait())
     if rank == 0:
-        q.put([[(pid, x.numpy().copy(), b.numpy().copy()) for pid, x, b in res] for res in got])
+        q.put([[(pid,) + unpack_records(r) for pid, r in res] for res in got])
     else:
         assert all(r is None for r in got)
     dist.barrier()
@@ -124,4 +126,4 @@ def test_pipelined_gathers_stay_in_order():
         assert [pid for pid, _, _ in rnd] == [i * world + r for r in range(world)]
         for pid, xyz, bgr in rnd:
             ex, eb = _cloud(pid)
-            assert np.array_equal(xyz, ex) and np.array_equal(bgr, eb)
+            assert np.array_equal(xyz, ex.astype(np.float32)) and np.array_equal(bgr, eb)
