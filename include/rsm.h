@@ -241,6 +241,25 @@ int rsm_stage_erode_gray(rsm_ctx *ctx, const uint8_t *src, int W, int H, int ksi
  * blue,green,red.  Host-only (no GPU needed). Returns 0 or RSM_E_INVALID. */
 int rsm_write_ply(const char *path, const double *xyz, const uint8_t *bgr, int64_t n_points);
 
+/* ---- per-pair cloud filter (CCloudOptimization::filter, CloudOptimization/CCloudOptimization.cpp:82-121) -- */
+typedef struct rsm_filter_params {
+    int sor_mean_k;        /* m_sor_meank  (CReconstruction.cpp:18: 100) */
+    double sor_std_mul;    /* m_sor_stdThres (1) */
+    double normal_radius;  /* m_mls_radius (2.5): NormalEstimation's search radius, .cpp:107 */
+    float cam_center[3];   /* cam[pair][0].CamCenter (CManageData.cpp:61-62): the normals are turned toward it, .cpp:114-121 */
+} rsm_filter_params;
+/* StatisticalOutlierRemoval + radius-search PCA normals + the turn toward CamCenter on a cloud of n float points
+ * (host buffers; PointXYZ order = InsertPoint order).  kept_index (capacity n) receives the indices of the points
+ * that survive the outlier removal, in order; normals (capacity 4 * n floats) their (nx, ny, nz, curvature).
+ * stats (optional, 4 doubles): mean, stddev, threshold of the mean-neighbour distances, points searched exhaustively. */
+int rsm_filter_cloud(rsm_ctx *ctx, const float *xyz, int64_t n, const rsm_filter_params *params, int32_t *kept_index,
+                     float *normals, int64_t *n_kept, double *stats);
+/* The same on the cloud of the last rsm_run_pair, without leaving the GPU: the surviving points as 16-byte records
+ * (the RCCL payload of rsm_gather_clouds, now without the outliers) and their normals (4 floats each, may be NULL)
+ * in caller-owned DEVICE buffers of capacity max_points. */
+int rsm_filter_last_cloud(rsm_ctx *ctx, const rsm_filter_params *params, rsm_point16 *d_points, float *d_normals,
+                          int64_t max_points, int64_t *n_kept, double *stats);
+
 /* ---- kernel microbenchmark (MDE/s: pixel x candidate NCC evaluations) -------------------- */
 /* Runs the NCC interval-argmax kernel `iters` times on a resident level-sized problem with
  * `cands` candidates per pixel and returns average milliseconds per launch. */

@@ -44,7 +44,7 @@ class PairOut(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(HERE, "liborc.so")
-    srcs = [os.path.join(HERE, f) for f in ("stereo_oracle.c", "rectify_oracle.c", "stereo_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("stereo_oracle.c", "rectify_oracle.c", "cloud_oracle.c", "stereo_oracle.h")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     return so
@@ -354,3 +354,25 @@ def exp_neg(t: float) -> float:
 def set_exp_mode(libm: int) -> None:
     """1: the refine weights use the host libm's exp instead of the specified one (sensitivity experiments only)."""
     lib().orc_set_exp_mode(int(libm))
+
+
+# ---- per-pair cloud filter (CloudOptimization/CCloudOptimization.cpp:82-121; PCL restated, parity unpinned) --------
+def sor_filter(xyz, mean_k=100, std_mul=1.0):
+    """pcl::StatisticalOutlierRemoval: returns (keep bool [n], mean-distance float32 [n], (mean, stddev, threshold))."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    n = len(xyz)
+    keep = np.zeros(n, np.uint8)
+    d = np.zeros(n, np.float32)
+    stats = np.zeros(3, np.float64)
+    lib().orc_sor_filter(_p(xyz), C.c_int64(n), int(mean_k), C.c_double(std_mul), _p(keep), _p(d), _p(stats))
+    return keep.astype(bool), d, tuple(stats)
+
+
+def cloud_normals(xyz, radius, cam_center):
+    """Radius-search PCA normals turned toward the origin (PCL) and then toward cam_center (:114-121): float32 [n,4]
+    (nx, ny, nz, curvature)."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    cc = np.ascontiguousarray(cam_center, np.float32).reshape(3)
+    out = np.zeros((len(xyz), 4), np.float32)
+    lib().orc_cloud_normals(_p(xyz), C.c_int64(len(xyz)), C.c_double(radius), _p(cc), _p(out))
+    return out

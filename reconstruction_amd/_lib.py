@@ -53,6 +53,10 @@ class PairOut(C.Structure):
                 ("xyz", C.c_void_p), ("bgr", C.c_void_p), ("v_top", C.c_int64)]
 
 
+class FilterParams(C.Structure):
+    _fields_ = [("sor_mean_k", C.c_int), ("sor_std_mul", C.c_double), ("normal_radius", C.c_double), ("cam_center", C.c_float * 3)]
+
+
 class RectifyIn(C.Structure):
     _fields_ = [("K", (C.c_double * 9) * 2), ("E", (C.c_double * 12) * 2),
                 ("origin_width", C.c_int), ("origin_height", C.c_int), ("lowest_width", C.c_int),
@@ -77,7 +81,7 @@ EXPORTS = [
     "rsm_bench_ncc", "rsm_write_ply", "rsm_rectify_pair", "rsm_stereo_rectify", "rsm_stage_rect_map",
     "rsm_stage_remap", "rsm_stage_erode_gray", "rsm_run_pairs", "rsm_run_pairs_repeat", "rsm_match_pairs", "rsm_match_pairs_multi_gpu",
     "rsm_pack_cloud16", "rsm_comm_unique_id", "rsm_comm_create", "rsm_comm_destroy", "rsm_comm_last_error",
-    "rsm_gather_clouds",
+    "rsm_gather_clouds", "rsm_filter_cloud", "rsm_filter_last_cloud",
 ]
 
 _lib = None

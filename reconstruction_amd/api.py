@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import Boundary, NOMATCH, PairIn, PairOut, RectifyIn, RectifyOut, RsmError  # noqa: F401
+from ._lib import Boundary, FilterParams, NOMATCH, PairIn, PairOut, RectifyIn, RectifyOut, RsmError  # noqa: F401
 
 
 def _u8(a):
@@ -234,6 +234,39 @@ class Context:
         n = C.c_int64()
         self._chk(self._lib.rsm_pack_cloud16(self._h, C.c_void_p(dst_ptr or None), C.c_int64(max_points), C.byref(n)))
         return int(n.value)
+
+    # ---- per-pair cloud filter (CCloudOptimization::filter, CloudOptimization/CCloudOptimization.cpp:82-121) ----
+    @staticmethod
+    def _filter_params(mean_k, std_mul, normal_radius, cam_center):
+        prm = FilterParams()
+        prm.sor_mean_k, prm.sor_std_mul, prm.normal_radius = int(mean_k), float(std_mul), float(normal_radius)
+        prm.cam_center[:] = [float(v) for v in np.asarray(cam_center, np.float64).ravel()[:3]]
+        return prm
+
+    def filter_cloud(self, xyz, mean_k=100, std_mul=1.0, normal_radius=2.5, cam_center=(0.0, 0.0, 0.0)):
+        """StatisticalOutlierRemoval + radius-search normals turned toward cam_center on a host cloud (n x 3, cast to
+        float32 as InsertPoint does).  Returns (kept_index int32 [m], normals float32 [m,4] = nx, ny, nz, curvature,
+        stats dict)."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = len(xyz)
+        kept = np.zeros(max(n, 1), np.int32)
+        nrm = np.zeros((max(n, 1), 4), np.float32)
+        m = C.c_int64()
+        st = (C.c_double * 4)()
+        prm = self._filter_params(mean_k, std_mul, normal_radius, cam_center)
+        self._chk(self._lib.rsm_filter_cloud(self._h, _p(xyz), C.c_int64(n), C.byref(prm), _p(kept), _p(nrm), C.byref(m), st))
+        return kept[:m.value].copy(), nrm[:m.value].copy(), dict(mean=st[0], stddev=st[1], threshold=st[2], exhaustive=int(st[3]))
+
+    def filter_last_cloud(self, points_ptr, normals_ptr, max_points, mean_k=100, std_mul=1.0, normal_radius=2.5,
+                          cam_center=(0.0, 0.0, 0.0)):
+        """The same on the last run's cloud without leaving the GPU: surviving points as 16-byte records and their
+        normals into caller-owned device buffers (addresses).  Returns (n_kept, stats dict)."""
+        m = C.c_int64()
+        st = (C.c_double * 4)()
+        prm = self._filter_params(mean_k, std_mul, normal_radius, cam_center)
+        self._chk(self._lib.rsm_filter_last_cloud(self._h, C.byref(prm), C.c_void_p(points_ptr or None), C.c_void_p(normals_ptr or None),
+                                                  C.c_int64(max_points), C.byref(m), st))
+        return int(m.value), dict(mean=st[0], stddev=st[1], threshold=st[2], exhaustive=int(st[3]))
 
     @property
     def n_points(self):
@@ -558,3 +591,36 @@ class StereoMatching:
                 if hasattr(sink, "filter"):
                     sink.filter(CamPair)      # .cpp:31
             self.last_result = res
+
+
+class CloudOptimization:
+    """The part of CCloudOptimization (CloudOptimization/CCloudOptimization.cpp) that sits on the stereo path:
+    Init (:40-57: only the per-pair filter's parameters are used), InsertPoint (:59-62), filter(idx) (:64-147: the
+    StatisticalOutlierRemoval + NormalEstimation + normal flip of :82-121 on the GPU; the mesh / texture tooling
+    after :123 is Windows executables and out of scope).  `cloud_normals` accumulates what the reference's global
+    `*cloud_normals += *cloud_normal` (:123) does: per pair (xyz float32 [m,3], normals float32 [m,4])."""
+
+    def __init__(self, ctx: Context | None = None, device: int = 0):
+        self._ctx = ctx or Context(device)
+        self._pts = []
+        self.cloud_normals = []
+        self.stats = []
+
+    def Init(self, sor_meank, sor_stdThres, outrem_neighbor, outrem_radius, mls_radius, ImageData, isdelete_=False):
+        self.m_sor_meank, self.m_sor_stdThres, self.m_mls_radius = sor_meank, sor_stdThres, mls_radius
+        self.m_ImageData = ImageData
+        self.CamCenter = [np.asarray(c[0].CamCenter if c[0].CamCenter is not None else np.zeros(3), np.float32).ravel()
+                          for c in ImageData.cam]
+
+    def InsertPoint(self, p):
+        self._pts.append(np.asarray(p, np.float64).ravel()[:3])
+
+    def InsertPoints(self, xyz, bgr=None):
+        self._pts = [np.asarray(xyz, np.float64).reshape(-1, 3)]
+
+    def filter(self, idx):
+        xyz = (np.concatenate([np.atleast_2d(p) for p in self._pts]) if self._pts else np.zeros((0, 3))).astype(np.float32)
+        kept, nrm, st = self._ctx.filter_cloud(xyz, self.m_sor_meank, self.m_sor_stdThres, self.m_mls_radius, self.CamCenter[idx])
+        self.cloud_normals.append((xyz[kept], nrm))
+        self.stats.append(st)
+        self._pts = []   # cloud_in->clear(), :145

@@ -1483,6 +1483,59 @@ extern "C" int rsm_stage_erode_gray(rsm_ctx *c, const uint8_t *src, int W, int H
     return finish(c, t);
 }
 
+// ---- per-pair cloud filter (CloudOptimization/CCloudOptimization.cpp:82-121) -------------------------------------
+static int filter_params_ok(const rsm_filter_params *p) {
+    return p && p->sor_mean_k >= 1 && p->sor_mean_k <= 100000 && p->normal_radius > 0.0 && p->sor_std_mul == p->sor_std_mul;
+}
+
+extern "C" int rsm_filter_cloud(rsm_ctx *c, const float *xyz, int64_t n, const rsm_filter_params *prm, int32_t *kept_index,
+                                float *normals, int64_t *n_kept, double *stats) {
+    if (!c || n < 0 || (n > 0 && (!xyz || !kept_index)) || !n_kept || !filter_params_ok(prm)) return RSM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_kept = 0;
+    if (n == 0) return RSM_OK;
+    Tmp t(c);
+    float *dx = t.up(xyz, (size_t)3 * n);
+    int32_t *dk = t.alloc<int32_t>((size_t)n);
+    float *df = t.alloc<float>((size_t)3 * n);
+    float4 *dn = normals ? t.alloc<float4>((size_t)n) : nullptr;
+    if (!t.ok) return finish(c, t);
+    const int s = filter_cloud_device(dx, n, prm->sor_mean_k, prm->sor_std_mul, prm->normal_radius, prm->cam_center, dk, df, dn, n_kept,
+                                      stats, c->stream);
+    if (s != RSM_OK) return set_err(c, s, "cloud filter failed");
+    if (*n_kept > 0) {
+        t.down(kept_index, (const int32_t *)dk, (size_t)*n_kept);
+        if (normals) t.down(normals, (const float *)dn, (size_t)4 * *n_kept);
+    }
+    return finish(c, t);
+}
+
+extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, rsm_point16 *d_points, float *d_normals,
+                                     int64_t max_points, int64_t *n_kept, double *stats) {
+    if (!c || !n_kept || !filter_params_ok(prm)) return RSM_E_INVALID;
+    if (!c->have_result) return set_err(c, RSM_E_STATE, "no result");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_kept = 0;
+    const int64_t n = c->n_points;
+    if (n == 0) return RSM_OK;
+    Tmp t(c);
+    float *dx = t.alloc<float>((size_t)3 * n);
+    int32_t *dk = t.alloc<int32_t>((size_t)n);
+    float *df = t.alloc<float>((size_t)3 * n);
+    float4 *dn = d_normals ? t.alloc<float4>((size_t)n) : nullptr;
+    if (!t.ok) return finish(c, t);
+    launch_f64_to_f32x3(c->xyz, n, dx, c->stream); // InsertPoint's cast, CCloudOptimization.cpp:61
+    int64_t m = 0;
+    const int s = filter_cloud_device(dx, n, prm->sor_mean_k, prm->sor_std_mul, prm->normal_radius, prm->cam_center, dk, df, dn, &m, stats,
+                                      c->stream);
+    if (s != RSM_OK) return set_err(c, s, "cloud filter failed");
+    if (m > max_points) return set_err(c, RSM_E_INVALID, "rsm_filter_last_cloud: %lld points survive, capacity %lld", (long long)m, (long long)max_points);
+    if (m > 0 && d_points) launch_pack_filtered16(c->xyz, c->bgr, dk, m, d_points, c->stream);
+    if (m > 0 && d_normals) HIPCHK(c, hipMemcpyAsync(d_normals, dn, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
+    *n_kept = m;
+    return finish(c, t);
+}
+
 // ---- PLY writer (CStereoMatching.cpp:723-729, 754-756) ----------------------------------------------
 extern "C" int rsm_write_ply(const char *path, const double *xyz, const uint8_t *bgr, int64_t n) {
     if (!path || n < 0 || (n > 0 && (!xyz || !bgr))) return RSM_E_INVALID;

@@ -124,3 +124,9 @@ void launch_remap(const uint8_t *src, int Ws, int Hs, int C, const int16_t *map1
 // st: ceil(log2(ksize))+1 planes of W*H bytes of scratch
 void launch_erode_gray(const uint8_t *src, int W, int H, int ksize, const int *d_j1, const int *d_j2, uint8_t *st,
                        uint8_t *dst, hipStream_t st_);
+
+// cloud filter (k_filter.hip): SOR + radius normals on a device cloud of n float xyz points
+int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius, const float cam_center[3],
+                        int32_t *d_kept_index, float *d_fxyz, float4 *d_normals, int64_t *n_kept, double stats[4], hipStream_t st);
+void launch_f64_to_f32x3(const double *src, int64_t n, float *dst, hipStream_t st);
+void launch_pack_filtered16(const double *xyz, const uint8_t *bgr, const int32_t *kept, int64_t m, void *dst16, hipStream_t st);

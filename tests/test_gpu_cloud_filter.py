@@ -1,0 +1,83 @@
+"""the per-pair cloud filter (CCloudOptimization::filter, CloudOptimization/CCloudOptimization.cpp:82-121 --
+StatisticalOutlierRemoval k = 100 / 1 sigma, radius-2.5 normals, turn toward CamCenter) on the GPU against
+oracle/cloud_oracle.c, the brute-force restatement of PCL 1.7.2's published algorithms (parity unpinned: PCL is not in
+the reference tree).  Kept indices, the per-point mean distances' statistics: bit-exact.  Normals: 1e-6 (the device's
+atan2 / cos / sin differ from the host's in the last bits), sign exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from reconstruction_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def surface_cloud(n, seed, extent=60.0, outliers=200, duplicates=50):
+    """A bumpy depth-map-like patch (anisotropic sampling as a perspective camera gives it), far and near outliers,
+    exact duplicates, an isolated cluster smaller than k."""
+    rng = np.random.default_rng(seed)
+    u = rng.random((n, 2)) * [extent, 0.7 * extent] - [extent / 2, 0.35 * extent]
+    z = 600.0 + 6.0 * np.sin(u[:, 0] / 9.0) * np.cos(u[:, 1] / 7.0) + rng.normal(0, 0.03, n)
+    xyz = np.c_[u * (z[:, None] / 600.0), z]
+    idx = rng.choice(n, outliers, replace=False)
+    xyz[idx] += rng.normal(0, 1.0, (outliers, 3)) * rng.choice([0.5, 3.0, 40.0], (outliers, 1))
+    idx = rng.choice(n, duplicates, replace=False)
+    xyz[idx] = xyz[rng.choice(n, duplicates)]
+    xyz[:30] = [200.0, 150.0, 900.0] + rng.normal(0, 0.2, (30, 3))     # an island of 30 < k points
+    return xyz.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,seed,k", [(50000, 1, 100), (6000, 2, 100), (3000, 3, 20)])
+def test_sor_and_normals_equal_the_oracle(ctx, n, seed, k):
+    xyz = surface_cloud(n, seed)
+    cam = np.array([30.0, -20.0, 0.0], np.float32)
+    keep_o, dist_o, (mean_o, std_o, thr_o) = orc.sor_filter(xyz, k, 1.0)
+    kept, nrm, st = ctx.filter_cloud(xyz, k, 1.0, 2.5, cam)
+    assert (st["mean"], st["stddev"], st["threshold"]) == (mean_o, std_o, thr_o)      # same distances, same order of summation
+    assert np.array_equal(kept, np.nonzero(keep_o)[0])
+    assert 0.5 * n < len(kept) < n and st["exhaustive"] >= 30          # the island needs the exhaustive search
+    nrm_o = orc.cloud_normals(xyz[keep_o], 2.5, cam)
+    nan_o = np.isnan(nrm_o[:, 0])
+    assert np.array_equal(np.isnan(nrm[:, 0]), nan_o)
+    ok = ~nan_o
+    # well-conditioned neighbourhoods: 1e-6; the cross-product eigenvector of a nearly isotropic neighbourhood (few
+    # points) is ill-conditioned in the formula itself
+    err = np.abs(nrm[ok, :3] - nrm_o[ok, :3]).max(axis=1)
+    assert (err < 1e-6).mean() > 0.999 and err.max() < 1e-3, (float((err < 1e-6).mean()), float(err.max()))
+    assert np.abs(nrm[ok, 3] - nrm_o[ok, 3]).max() < 1e-6
+    assert np.all(np.einsum("ij,ij->i", nrm[ok, :3], cam[None] - xyz[keep_o][ok]) >= 0)   # turned toward CamCenter
+
+
+def test_filter_of_a_matched_pair_on_device_equals_the_host_entry(ctx):
+    """rsm_filter_last_cloud (the cloud never leaves the GPU; output = the RCCL payload) against rsm_filter_cloud on the
+    downloaded cloud, and the reference-shaped CloudOptimization sink behind StereoMatching.MatchAllLayer."""
+    from reconstruction_amd import Camera, CloudOptimization, ManageData, StereoMatching
+    from reconstruction_amd.dist import unpack_records
+    cfg = synth.config_small(320, 192, 3, radius=2, pair=4, mask_l0_width=60, border_l0=4)
+    res = ctx.match_pair(cfg)
+    assert res.n_points > 20000
+    cam = np.array([0.0, 0.0, 0.0], np.float32)
+    # the synthetic rig's units: ~0.4 per pixel at Z ~ 1000; a radius of 2.5 holds ~100 points
+    kept, nrm, st = ctx.filter_cloud(res.xyz, 100, 1.0, 2.5, cam)
+    rec = torch.empty((res.n_points, 16), dtype=torch.uint8, device="cuda:0")
+    nd = torch.empty((res.n_points, 4), dtype=torch.float32, device="cuda:0")
+    m, st2 = ctx.filter_last_cloud(rec.data_ptr(), nd.data_ptr(), res.n_points, 100, 1.0, 2.5, cam)
+    assert m == len(kept) and st2 == st and 0 < m < res.n_points
+    xyz16, bgr16 = unpack_records(rec[:m])
+    assert np.array_equal(xyz16, res.xyz[kept].astype(np.float32)) and np.array_equal(bgr16, res.bgr[kept])
+    assert np.array_equal(nd[:m].cpu().numpy(), nrm, equal_nan=True)
+    # reference-shaped sink
+    top = 1 << (cfg.pyr_levels - 1)
+    data = ManageData(cam=[[Camera(camID=0, image=cfg.image[0], mask=cfg.mask[0], CamCenter=cam),
+                            Camera(camID=1, image=cfg.image[1], mask=cfg.mask[1], CamCenter=cam)]],
+                      m_PyrmNum=cfg.pyr_levels, m_LowestLevelSize=(cfg.width // top, cfg.height // top),
+                      m_OriginSize=(cfg.width, cfg.height), rectified=[dict(Q=cfg.Q, R_final=cfg.R_final, T_final=cfg.T_final)])
+    opt = CloudOptimization(ctx)
+    opt.Init(100, 1, 50, 2, 2.5, data, False)        # CReconstruction.cpp:18
+    sm = StereoMatching(0)
+    sm.Init(data, opt, 2, 0.03)                       # CReconstruction.cpp:17
+    sm.Verbose = 0
+    sm.MatchAllLayer()
+    fx, fn = opt.cloud_normals[0]
+    assert np.array_equal(fx, res.xyz[kept].astype(np.float32)) and np.array_equal(fn, nrm, equal_nan=True)
