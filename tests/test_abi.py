@@ -69,12 +69,30 @@ def test_header_is_plain_c():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/reconstruction"), reason="reference headers only exist in the build container")
-def test_cpp_adapter_compiles_against_the_reference_headers(tmp_path):
+@pytest.mark.parametrize("pcl", [False, True])
+def test_cpp_adapter_compiles_against_the_reference_headers(tmp_path, pcl):
+    """The cv::Mat-facing shim (include/CStereoMatchingMI355.hpp) against the reference's own vendored headers, with and
+    without IS_PCL (SharedInclude.h defines it; the InsertPoint / filter calls are behind it, CStereoMatching.cpp:30,750).
+    The marshalling itself is plain C++ and is RUN by tests/test_gpu_cpp_adapter.py."""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("the reference checkout exists only in the build container")
     src = tmp_path / "adapter_check.cpp"
     src.write_text('#define __declspec(x)\n#define _Longlong long long\n#include "SharedInclude.h"\n'
+                   + ('' if pcl else '#undef IS_PCL\n') +
                    '#include "CStereoMatching.h"\n#include "CStereoMatchingMI355.hpp"\n'
-                   'bool f(CStereoMatching &sm) { RsmStereoMI355 g(0); return g.MatchPair(sm, 0); }\n')
+                   'bool f(CStereoMatching &sm) { RsmStereoMI355 g(0); return g.MatchPair(sm, 0) && g.LastStatus() == 0; }\n')
     r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-I/root/reference/include",
                         "-I/root/reference/reconstruction", "-I" + os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_mock_adapter_program_builds_and_links(tmp_path):
+    """tests/cpp/mock_adapter.cpp (the traits-based adapter with mock types) compiles with plain g++ and links against
+    the C-ABI library; it is executed on the GPU box."""
+    from reconstruction_amd import _lib
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "mock_adapter.cpp"), "-o", str(tmp_path / "mock_adapter"),
+                        "-L" + os.path.dirname(_lib.LIB_PATH), "-lrsm_mi355", "-Wl,-rpath-link,/opt/rocm/lib",
+                        "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -1,0 +1,66 @@
+"""The C++ glue of include/rsm_stereo_adapter.hpp, executed: tests/cpp/mock_adapter.cpp (mock CStereoMatching /
+CManageData behind the accessor traits, no OpenCV) is built with g++ here on the GPU box, linked against
+librsm_mi355.so, fed three pairs -- the middle one degenerate -- and its InsertPoint stream, bounds, disparity and
+cloud%d.ply (isoutput) are compared with the ctypes path."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from reconstruction_amd import _lib, synth, write_ply
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "mock_adapter")
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mock_adapter.cpp"),
+           "-o", exe, "-L" + os.path.dirname(_lib.LIB_PATH), "-lrsm_mi355", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH),
+           "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_mock_pipeline_through_the_cpp_adapter(ctx, tmp_path):
+    exe = build(tmp_path)
+    kw = dict(width=192, height=128, levels=3, radius=2, offset=2, mask_l0_width=30, border_l0=4)
+    cfgs = [synth.config_small(pair=p, **kw) for p in (1, 2, 4)]
+    bad = 1
+    W, H = kw["width"], kw["height"]
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<9i", len(cfgs), W, H, kw["levels"], kw["radius"], kw["offset"], W, 1, bad))
+        f.write(struct.pack("<d", 0.03))
+        for c in cfgs:
+            f.write(np.asarray(c.Q, np.float64).tobytes() + np.asarray(c.R_final, np.float64).tobytes() + np.asarray(c.T_final, np.float64).tobytes())
+            for a in (c.image[0], c.image[1], c.mask[0], c.mask[1]):
+                f.write(np.ascontiguousarray(a, np.uint8).tobytes())
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, cwd=tmp_path, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    buf = open(tmp_path / "out.bin", "rb").read()
+    off = 0
+    for p, c in enumerate(cfgs):
+        ok, status = struct.unpack_from("<2i", buf, off); off += 8
+        if p == bad:
+            assert (ok, status) == (0, -2)      # RSM_E_DEGENERATE_MARGIN: reported, and the NEXT pair still runs
+            assert "level" in r.stderr
+            continue
+        assert (ok, status) == (1, 0)
+        mg = struct.unpack_from("<12i", buf, off); off += 48
+        n, = struct.unpack_from("<q", buf, off); off += 8
+        farg, = struct.unpack_from("<i", buf, off); off += 4
+        xyz = np.frombuffer(buf, np.float64, 3 * n, off).reshape(n, 3); off += 24 * n
+        d0 = np.frombuffer(buf, np.float64, W * H, off).reshape(H, W); off += 8 * W * H
+        ref = ctx.match_pair(c)
+        assert [tuple(mg[:6]), tuple(mg[6:])] == ref.margin
+        assert n == ref.n_points > 1000 and farg == p          # one InsertPoint per point, then filter(CamPair)
+        assert np.array_equal(xyz, ref.xyz, equal_nan=True) and np.array_equal(d0, ref.disparity[0])
+        # isoutput: the in-call cloud%d.ply of DisparityToCloud (.cpp:707-757)
+        write_ply(tmp_path / "want.ply", ref.xyz, ref.bgr)
+        assert open(tmp_path / ("cloud%d.ply" % p), "rb").read() == open(tmp_path / "want.ply", "rb").read()
+    assert off == len(buf)
