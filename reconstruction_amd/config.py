@@ -127,5 +127,8 @@ def load_config(configfile: str):
             pair.append(cam)
         data.cam.append(pair)
     m0 = imread_gray(filepath + masklist[0].replace("\\", os.sep))                     # :68-69
-    data.m_OriginSize = (m0.shape[1], m0.shape[0]) if m0 is not None else (0, 0)
+    if m0 is None:   # the reference would go on with an empty m_OriginSize and fail inside Rectify; say what is wrong
+        raise ValueError("read image %s error (the first mask gives m_OriginSize, CManageData.cpp:68-69)"
+                         % (filepath + masklist[0]))
+    data.m_OriginSize = (m0.shape[1], m0.shape[0])
     return data, {"filepath": filepath, "config": fs}

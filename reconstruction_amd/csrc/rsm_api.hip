@@ -380,6 +380,7 @@ static int upload_common(rsm_ctx *c, const rsm_pair_in *in, hipMemcpyKind kind) 
     int s = validate(c, in);
     if (s != RSM_OK) return s;
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream2)); // nothing of a previous (possibly failed) run may still be in flight
     s = ensure_workspace(c, in);
     if (s != RSM_OK) return s;
     const int top = c->N - 1;
@@ -677,6 +678,13 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             const int *m = hm + (k * 2 + v) * 4;
             c->mg[k][v] = Mg{m[2], m[3], m[0], m[1]};
         }
+    // Rematch -> SetBoundary_smooth exits on a degenerate margin (.cpp:827-830).  Every level's margin is known now:
+    // decide before any level is enqueued, and leave no side-stream work behind that the next call could collide with
+    for (int k = 0; k < N; k++)
+        if (degenerate(c->mg[k][0]) || degenerate(c->mg[k][1])) {
+            (void)hipStreamSynchronize(c->stream2);
+            return set_err(c, RSM_E_DEGENERATE_MARGIN, "level %d: YL>=YR || XL>=XR", k);
+        }
     launch_count_masked(c->msk[N - 1][0], c->Wk[N - 1], c->Hk[N - 1], c->mg[N - 1][0], c->d_vtop, st);
 
     int par = 0; // index of the fp64 buffer holding the previous level's disparity (this is `disparity[]`)
@@ -685,9 +693,6 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         StageArgs a = level_args(c, k);
         const double Pk = 0.5 * ((double)(a.d[0].own.XR - a.d[0].own.XL + 1) * (a.d[0].own.YR - a.d[0].own.YL + 1) +
                                  (double)(a.d[1].own.XR - a.d[1].own.XL + 1) * (a.d[1].own.YR - a.d[1].own.YL + 1));
-        // Rematch -> SetBoundary_smooth exits on a degenerate margin (.cpp:827-830)
-        if (degenerate(c->mg[k][0]) || degenerate(c->mg[k][1]))
-            return set_err(c, RSM_E_DEGENERATE_MARGIN, "level %d: YL>=YR || XL>=XR", k);
 
         const int ps3 = prof_begin(c, ST_BOXSUM); // what the main stream still has to wait for
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_prep[k], 0));
@@ -782,6 +787,14 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         launch_uniq_f64(c->f64[cur][0], c->f64[cur][1], W, H, c->mg[k][0], c->mg[k][1], st);
         prof_end(c, ps13, ST_UNIQ64, 3, 72.0 * Pk);
         par = cur;
+        { // a launch that could not start (e.g. an LDS request the input drove too high) must not go unnoticed
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) {
+                (void)hipStreamSynchronize(c->stream2);
+                (void)hipStreamSynchronize(st);
+                return set_err(c, RSM_E_HIP, "level %d: kernel launch failed: %s", k, hipGetErrorString(le));
+            }
+        }
     }
 
     // ---- DisparityToCloud<double>(disparity[0], maskPyrm[top][0], Q, top, true) (.cpp:29)
@@ -1385,6 +1398,7 @@ extern "C" int rsm_rectify_pair(rsm_ctx *c, const rsm_rectify_in *in, int radius
     }
     int s = validate(c, &pin);
     if (s != RSM_OK) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream2)); // the maps below reuse the side stream's scratch (tmp1 / tmp2)
     s = ensure_workspace(c, &pin);
     if (s != RSM_OK) return s;
     hipStream_t st = c->stream;
