@@ -715,7 +715,7 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
     const size_t lds = 16 + (size_t)WS * (SA + SB) * 4 + (size_t)(NCC_CH + NCC_G) * 9 + 16;
     if (mode == 2) { // the worklist was filled by launch_set_boundary
         hipLaunchKernelGGL(k_ncc_sparse<R>, dim3(2048), dim3(256), 0, st, a);
-        if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(512), dim3(256), 0, st, a, mode);
+        if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
         return;
     }
     // *a.ncc_cnt (wide-pixel count) is zero on entry: the caller hands every launch a fresh counter
@@ -724,7 +724,7 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
     if (ldsw > 65536) // radii 6 and 7 stage more than the default 64 KB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void *)k_ncc_wide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
     hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), ldsw, st, a, mode);
-    if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(512), dim3(256), 0, st, a, mode);
+    if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
 }
 
 void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
@@ -754,5 +754,5 @@ void launch_ncc_argmax(const StageArgs &a, int mode, hipStream_t st) {
     if (lds > 65536) // radius 15
         (void)hipFuncSetAttribute((const void *)k_ncc_bytes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_ncc_bytes, grid, dim3(NCC_TX), lds, st, a, mode, strideA, strideB);
-    if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(512), dim3(256), 0, st, a, mode);
+    if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
 }

@@ -1,0 +1,22 @@
+#!/bin/bash
+# round-2 profiles of the default bench command: kernel-trace stats, then PMC passes (FETCH_SIZE / WRITE_SIZE / L2 hit / SQ)
+export OMP_NUM_THREADS=16 OMP_WAIT_POLICY=passive TMPDIR=/tmp
+root=$PWD
+out=$root/gpurun_out/prof_r02; rm -rf $out; mkdir -p $out
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $out/stats -o r02 -- python $root/bench.py --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
+echo "stats rc=$?"
+f=$(find $out/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $out/r02_kernel_stats.csv && head -12 $out/r02_kernel_stats.csv
+find $out/stats -name "*kernel_trace.csv" -size +1M -delete; find $out/stats -name "*.db" -size +20M -delete
+tail -1 $out/bench_under_rocprof.log | cut -c1-400
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1)); o=$out/pmc/g$i; mkdir -p $o
+  rocprofv3 --pmc $grp --kernel-trace -d $o -o pmc -- python $root/bench.py --no-cpu-baseline --steps 1 --warmup 0 --inflight 1 > $o/stdout.log 2>&1
+  echo "pmc group $i rc=$?"
+done
+cd $root
+python tests/rocpd_pmc.py $(find $out/pmc -name "*.db") > $out/r02_pmc_all_kernels.csv 2>$out/pmc_err.log
+grep -E "refine_sweep<1>|refine_sweep<0>|k_ncc_dot4|kernel,counter" $out/r02_pmc_all_kernels.csv | head -40
+find $out/pmc -name "*.db" -size +20M -delete
+du -sh $out
