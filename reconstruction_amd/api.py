@@ -413,9 +413,11 @@ def run_pairs(ctxs, repeats=1):
         raise RsmError(st, "; ".join(m for m in msgs if m))
 
 
-def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True):
+def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True, timing=None):
     """rsm_match_pairs: the pair loop of MatchAllLayer (.cpp:17-33) for a list of pair configs over a pool of
-    contexts (same or different GPUs), pairs in flight together.  Returns (results in pair order, statuses)."""
+    contexts (same or different GPUs), pairs in flight together.  Returns (results in pair order, statuses).
+    timing (optional dict) receives "call_s": seconds inside the C call alone (output buffers pre-faulted, the
+    slicing of the results outside)."""
     lib = _lib.load()
     n = len(cfgs)
     ins = (PairIn * n)()
@@ -426,9 +428,9 @@ def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True):
         ins[p] = pin
         keep.append(k)
         H, W = cfg.height, cfg.width
-        d = [np.zeros((H, W), np.float64), np.zeros((H, W), np.float64)] if want_disparity else [None, None]
-        xyz = np.zeros((W * H, 3), np.float64) if want_cloud else None
-        bgr = np.zeros((W * H, 3), np.uint8) if want_cloud else None
+        d = [np.full((H, W), 0.0), np.full((H, W), 0.0)] if want_disparity else [None, None]   # full(): pages touched now
+        xyz = np.full((W * H, 3), 0.0) if want_cloud else None
+        bgr = np.full((W * H, 3), 0, np.uint8) if want_cloud else None
         if want_disparity:
             outs[p].disparity[0] = d[0].ctypes.data
             outs[p].disparity[1] = d[1].ctypes.data
@@ -439,7 +441,11 @@ def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True):
         bufs.append((d, xyz, bgr))
     status = (C.c_int * n)()
     arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    import time as _time
+    t0 = _time.perf_counter()
     lib.rsm_match_pairs(arr, len(ctxs), ins, outs, n, status)
+    if timing is not None:
+        timing["call_s"] = _time.perf_counter() - t0
     res = []
     for p in range(n):
         if status[p] != 0:
@@ -448,8 +454,8 @@ def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True):
         d, xyz, bgr = bufs[p]
         m = int(outs[p].n_points)
         res.append(PairResult(disparity=d, margin=[outs[p].margin[0].astuple(), outs[p].margin[1].astuple()], n_points=m,
-                              xyz=xyz[:m].copy() if want_cloud else np.zeros((0, 3)),
-                              bgr=bgr[:m].copy() if want_cloud else np.zeros((0, 3), np.uint8), v_top=int(outs[p].v_top)))
+                              xyz=xyz[:m] if want_cloud else np.zeros((0, 3)),
+                              bgr=bgr[:m] if want_cloud else np.zeros((0, 3), np.uint8), v_top=int(outs[p].v_top)))
     return res, list(status)
 
 
