@@ -291,12 +291,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // four lanes per entry (a lane each when the list is long); computing them in place would run the data-term
 // routine in every second wave for one or two lanes.
 // TOP only gives the top level's launches (the dominant kernel) their own name in rocprof traces.
-#define RFU_CAP (256 * RF_PPT) // every pixel of the workgroup may miss
+#define RFW_CAP (64 * RF_PPT) // every pixel of a wave may miss
 template <int TOP>
 __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
-    __shared__ uint32_t s_list[RFU_CAP]; // slot of the owner (thread * RF_PPT + i) | (iMatch - x) << 16
-    __shared__ double s_res[RFU_CAP][2];
-    __shared__ int s_n;
+    // Misses are served per WAVE (own list, own results, no workgroup barrier): a wave that has none -- nearly all of
+    // them once the iteration has settled -- never waits for a neighbour's ~3 us service chain.
+    __shared__ uint32_t s_list[4][RFW_CAP]; // slot of the owner (lane * RF_PPT + i) | (iMatch - x) << 16
+    __shared__ double s_res[4][RFW_CAP][2];
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W, H = a.H;
     const int x = d.own.XL + 1 + blockIdx.x * 256 + (int)threadIdx.x;
@@ -307,7 +308,6 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     const int xs = colok ? x : d.own.XL + 1; // out-of-range lanes shadow a valid column (no stores)
     const double *__restrict__ in = d.f64_a;
     double *__restrict__ out = d.f64_b;
-    if (threadIdx.x == 0) s_n = 0;
     double col[RF_PPT + 2], dE[RF_PPT], dW[RF_PPT];
 #pragma unroll
     for (int i = 0; i < RF_PPT + 2; i++) {
@@ -331,10 +331,11 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         pwp[i] = d.rf_pwp[cpix];
         delta[i] = d.rf_delta[cpix];
     }
-    __syncthreads(); // s_n = 0
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int xw0 = d.own.XL + 1 + blockIdx.x * 256 + wid * 64; // column of this wave's lane 0
     unsigned live = 0, miss = 0;
-    int mode[RF_PPT];
+    int mode[RF_PPT], pos[RF_PPT];
+    int n = 0; // misses of this wave (uniform)
 #pragma unroll
     for (int i = 0; i < RF_PPT; i++) {
         const double dC = col[i + 1], dN = col[i], dS = col[i + 2];
@@ -343,58 +344,51 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
                   (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
         const bool ms = lv && mode[i] != 0 && crel[i] != rel[i];
         const unsigned long long mm = __ballot(ms);
-        if (mm) {
-            const int leader = __builtin_ctzll(mm);
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&s_n, __popcll(mm));
-            base = __shfl(base, leader);
-            if (ms) s_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (threadIdx.x * RF_PPT + i) | ((uint32_t)(rel[i] & 0xffff) << 16);
-        }
+        pos[i] = n + __popcll(mm & ((1ull << lane) - 1ull));
+        if (ms) s_list[wid][pos[i]] = (uint32_t)(lane * RF_PPT + i) | ((uint32_t)(rel[i] & 0xffff) << 16);
+        n += __popcll(mm);
         live |= (unsigned)lv << i;
         miss |= (unsigned)ms << i;
     }
-    __syncthreads();
-    const int n = s_n;
-    if (n) { // uniform
+    if (n) { // wave-uniform
+        __builtin_amdgcn_wave_barrier();
         for (int done = 0; done < n;) { // uniform
-            if (n - done > 64) { // a lane per entry: one round serves up to 256 with 1/3 of the quads' instructions
-                const int e = done + (int)threadIdx.x;
+            if (n - done > 16) { // a lane per entry: one round serves up to 64 with 1/3 of the quads' instructions
+                const int e = done + lane;
                 if (e < n) {
-                    const uint32_t en = s_list[e];
+                    const uint32_t en = s_list[wid][e];
                     const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
-                    const int ex = d.own.XL + 1 + blockIdx.x * 256 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
+                    const int ex = xw0 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
                     double p, q;
                     refine_data_term_packed(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, p, q);
-                    s_res[slot][0] = p;
-                    s_res[slot][1] = q;
-                }
-                done += 256;
-            } else { // four lanes per entry: a third of the latency, which is what a handful of misses costs
-                const int e = done + ((int)threadIdx.x >> 2);
-                if (done + (((int)threadIdx.x >> 6) << 4) < n) { // wave-uniform: this wave's 16 quads reach the list
-                    const bool ok = e < n;
-                    const uint32_t en = s_list[ok ? e : done];
-                    const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
-                    const int ex = d.own.XL + 1 + blockIdx.x * 256 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
-                    double p, q;
-                    refine_data_term_quad(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, threadIdx.x & 3, p, q);
-                    if (ok && (threadIdx.x & 3) == 0) {
-                        s_res[slot][0] = p;
-                        s_res[slot][1] = q;
-                    }
+                    s_res[wid][e][0] = p;
+                    s_res[wid][e][1] = q;
                 }
                 done += 64;
+            } else { // four lanes per entry: a third of the latency, which is what a handful of misses costs
+                const int e = done + (lane >> 2);
+                const bool ok = e < n;
+                const uint32_t en = s_list[wid][ok ? e : done];
+                const int slot = en & 0xffff, r = (int)(int16_t)(en >> 16);
+                const int ex = xw0 + slot / RF_PPT, ey = y0 + slot % RF_PPT;
+                double p, q;
+                refine_data_term_quad(d.img4_own, d.img4_oth, W, H, ex, ey, r + ex, lane & 3, p, q);
+                if (ok && (lane & 3) == 0) {
+                    s_res[wid][e][0] = p;
+                    s_res[wid][e][1] = q;
+                }
+                done += 16;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int i = 0; i < RF_PPT; i++) {
         if (!((live >> i) & 1u)) continue;
         const size_t pix = (size_t)(y0 + i) * W + x;
         if ((miss >> i) & 1u) {
-            pwp[i] = s_res[threadIdx.x * RF_PPT + i][0];
-            delta[i] = s_res[threadIdx.x * RF_PPT + i][1];
+            pwp[i] = s_res[wid][pos[i]][0];
+            delta[i] = s_res[wid][pos[i]][1];
             const size_t cpix = pix + (size_t)(rel[i] & 1) * a.rf_stride;
             d.rf_key[cpix] = (int16_t)rel[i];
             d.rf_pwp[cpix] = pwp[i];
@@ -404,7 +398,6 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
                                   : refine_update(mode[i], col[i + 1], dE[i], dW[i], col[i], col[i + 2], pwp[i], delta[i], a.ws);
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Two Jacobi sweeps per launch (option refine_multi_from; OFF by default -- measured slower, see below).
