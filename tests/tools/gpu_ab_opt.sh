@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of one rsm_set_option on the same box: bash tests/gpu_ab_opt.sh name=value [reps]
+# A/B of one rsm_set_option on the same box: bash tests/tools/gpu_ab_opt.sh name=value [reps]
 mkdir -p gpurun_out
 opt=$1; reps=${2:-3}
 for i in $(seq $reps); do

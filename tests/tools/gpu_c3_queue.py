@@ -1,6 +1,6 @@
 """Development aid: the 10-pair C3 rig on one GPU through rsm_match_pairs (host buffers in and out, PCIe included)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reconstruction_amd import Context, match_pairs, synth
 cfgs = [synth.config_c3(pair=p) for p in range(10)]
 for nctx, disp in ((1, True), (2, True), (1, False), (2, False), (3, False)):

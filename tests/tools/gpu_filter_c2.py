@@ -1,6 +1,6 @@
 """Development aid: the cloud filter on a full-size C2 cloud (time, survivors, exhaustive searches)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from reconstruction_amd import Context, synth
 cfg = synth.config_c2(pair=0)

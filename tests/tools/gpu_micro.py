@@ -1,6 +1,6 @@
 """NCC kernel microbenchmarks on the GPU box (development aid)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reconstruction_amd import Context
 ctx = Context(0)
 for (W, H, r) in [(4096, 3072, 5), (2048, 1536, 5)]:

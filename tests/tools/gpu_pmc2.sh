@@ -10,5 +10,5 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_W
   (cd /tmp && rocprofv3 --pmc $grp --kernel-trace -d $out -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --steps 1 --warmup 0 --inflight 1 "$@" > $out/stdout.log 2>&1)
   echo "group $i rc=$?"
 done
-python tests/rocpd_pmc.py --filter=$filt $(find $base -name "*.db") > gpurun_out/pmc2_summary.csv 2>gpurun_out/pmc2_err.log
+python tests/tools/rocpd_pmc.py --filter=$filt $(find $base -name "*.db") > gpurun_out/pmc2_summary.csv 2>gpurun_out/pmc2_err.log
 cat gpurun_out/pmc2_summary.csv | head -60; tail -3 gpurun_out/pmc2_err.log

@@ -16,7 +16,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES 
   echo "pmc group $i rc=$?"
 done
 cd $root
-python tests/rocpd_pmc.py $(find $out/pmc -name "*.db") > $out/r02_pmc_all_kernels.csv 2>$out/pmc_err.log
+python tests/tools/rocpd_pmc.py $(find $out/pmc -name "*.db") > $out/r02_pmc_all_kernels.csv 2>$out/pmc_err.log
 grep -E "refine_sweep<1>|refine_sweep<0>|k_ncc_dot4|kernel,counter" $out/r02_pmc_all_kernels.csv | head -40
 find $out/pmc -name "*.db" -size +20M -delete
 du -sh $out

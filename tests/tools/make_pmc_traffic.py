@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/pmc_traffic.json from the PMC summary of tests/gpu_profile_r02.sh (run on the GPU box), keyed by the hash of
+"""profiles/pmc_traffic.json from the PMC summary of tests/tools/gpu_profile_r02.sh (run on the GPU box), keyed by the hash of
 the dominant kernel's source so that bench.py stops quoting it once the kernel changes."""
 import csv
 import hashlib
@@ -7,7 +7,7 @@ import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_pmc_main_kernels.csv")
 rows = list(csv.DictReader(open(src)))
 
@@ -25,8 +25,8 @@ for fn in ("k_refine.hip", "rsm_dev.h"):
     h.update(open(os.path.join(ROOT, "reconstruction_amd", "csrc", fn), "rb").read())
 out = {"kernel": "k_refine_sweep<1>", "workload": "C2_4096x3072_r5_d128", "kernel_src_sha256": h.hexdigest(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python bench.py "
-                 "--no-cpu-baseline --steps 1 --warmup 0 --inflight 1; tests/gpu_profile_r02.sh, summarised by "
-                 "tests/rocpd_pmc.py -> " + os.path.relpath(src, ROOT),
+                 "--no-cpu-baseline --steps 1 --warmup 0 --inflight 1; tests/tools/gpu_profile_r02.sh, summarised by "
+                 "tests/tools/rocpd_pmc.py -> " + os.path.relpath(src, ROOT),
        "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "dispatches": nd,
        "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: the counter tallies 128-byte requests at 64 "
                      "bytes; calibrated in round 1 on a 37.7 MB device copy of the same run: FETCH_SIZE 18.4 MB); WRITE_SIZE as "
