@@ -562,6 +562,8 @@ class StereoMatching:
                                               data.m_LowestLevelSize, data.m_PyrmNum, raw, rawm)
                 for j in range(2):
                     cams[j].image, cams[j].mask, cams[j].P = rect["image"][j], rect["mask"][j], rect["P"][j]
+                    if getattr(data, "isoutput", 0):   # .cpp:159-166: "%d_%d.jpg" of the rectified image
+                        _cfg.imwrite_bgr("%d_%d.jpg" % (CamPair, cams[j].camID), cams[j].image)
             else:
                 if cams[0].image is None or cams[1].image is None:
                     print("read image %s error" % (cams[0].image_name or cams[1].image_name))

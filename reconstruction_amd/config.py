@@ -78,6 +78,16 @@ def imread_bgr(path: str):
         return None
 
 
+def imwrite_bgr(path: str, img) -> bool:
+    """cv::imwrite(path, bgr): the format follows the extension (the reference dumps "%d_%d.jpg", .cpp:163-164)."""
+    try:
+        from PIL import Image
+        Image.fromarray(np.ascontiguousarray(np.asarray(img)[:, :, ::-1])).save(path)
+        return True
+    except Exception:
+        return False
+
+
 def imread_gray(path: str):
     """cv::imread(path, CV_LOAD_IMAGE_GRAYSCALE) -> HxW uint8 or None."""
     try:

@@ -133,3 +133,38 @@ def test_cli_config_to_ply(ctx, tmp_path):
                            origin_width=raw["origin"][0], image=o["image"], mask=o["mask"], Q=o["Q"],
                            R_final=o["R_final"], T_final=o["T_final"])
     assert n == orc.match_pair(cfg)["n_points"] and n > 1000
+
+
+def test_cli_isoutput_and_filter(ctx, tmp_path, monkeypatch):
+    """isoutput = 1: the rectified "%d_%d.jpg" images of Rectify (CStereoMatching.cpp:159-166) and the in-call cloud%d.ply of
+    DisparityToCloud (.cpp:707-757) appear in the working directory; outfilename already ending in .ply is used as is
+    (BatchProcess/main.cpp:56); --filter runs CCloudOptimization::filter's outlier removal per pair."""
+    from PIL import Image
+    from reconstruction_amd import config as cfgmod
+    from reconstruction_amd.__main__ import main
+    raw = synth.make_raw_pair(baseline=-150.0)
+    root = str(tmp_path) + "/"
+    (tmp_path / "mask").mkdir()
+    for j in range(2):
+        Image.fromarray(raw["image"][j][:, :, ::-1]).save(root + "0001_Cam%d.png" % j)
+        Image.fromarray(raw["mask"][j]).save(root + "mask/0001_Cam%d.png" % j)
+    cfgmod.dump_opencv_yaml(root + "calib_camera.yml", {"intrinsic-0": raw["K"][0], "extrinsic-0": raw["E"][0],
+                                                         "intrinsic-1": raw["K"][1], "extrinsic-1": raw["E"][1]})
+    cfgmod.dump_opencv_yaml(root + "config.yml", {
+        "filepath": root, "outfilename": root + "scan1.ply", "isoutput": 1, "camera_calib_name": "calib_camera.yml",
+        "PyrmNum": raw["pyr_levels"], "LowestLevelWidth": raw["lowest"][0], "LowestLevelHeight": raw["lowest"][1],
+        "imagelist": ["0001_Cam%d.png" % j for j in range(2)], "masklist": ["mask\\0001_Cam%d.png" % j for j in range(2)],
+        "camID": np.array([[0, 1]], np.uint8)})
+    monkeypatch.chdir(tmp_path)
+    assert main([root + "config.yml"]) == 0
+    import os
+    assert os.path.exists(root + "scan1.ply") and not os.path.exists(root + "scan1.ply.ply")
+    n_all = int(open(root + "scan1.ply", "rb").read(400).decode("latin1").split("element vertex")[1].split()[0])
+    assert os.path.exists("0_0.jpg") and os.path.exists("0_1.jpg") and os.path.exists("cloud0.ply")
+    assert Image.open("0_0.jpg").size == (raw["lowest"][0] << (raw["pyr_levels"] - 1), raw["lowest"][1] << (raw["pyr_levels"] - 1))
+    assert main([root + "config.yml", "--filter", "--out", root + "filtered.ply"]) == 0
+    n_f = int(open(root + "filtered.ply", "rb").read(400).decode("latin1").split("element vertex")[1].split()[0])
+    assert 0.5 * n_all < n_f < n_all
+    # an unreadable first mask is reported like the reference's "read image ... error", not an assertion
+    os.remove(root + "mask/0001_Cam0.png")
+    assert main([root + "config.yml"]) == 1
