@@ -28,6 +28,8 @@ static int cmp_float(const void *a, const void *b) {
     return (x > y) - (x < y);
 }
 
+static inline int finite3(const float *p) { return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]); }
+
 static inline float dist2f(const float *a, const float *b) {
     const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     return (dx * dx + dy * dy) + dz * dz;
@@ -42,9 +44,15 @@ void orc_sor_filter(const float *xyz, int64_t n, int mean_k, double std_mul, uin
         float *d2 = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
 #pragma omp for schedule(dynamic, 64)
         for (int64_t i = 0; i < n; i++) {
-            for (int64_t j = 0; j < n; j++) d2[j] = dist2f(xyz + 3 * i, xyz + 3 * j);
-            qsort(d2, (size_t)n, sizeof(float), cmp_float);
-            const int64_t m = (n < (int64_t)mean_k + 1) ? n : (int64_t)mean_k + 1;
+            if (!finite3(xyz + 3 * i)) { /* "distances[iii] = 0.0; continue;": skipped by the searches, kept by the filter */
+                dist[i] = 0.0f;
+                continue;
+            }
+            int64_t nn = 0;
+            for (int64_t j = 0; j < n; j++)
+                if (finite3(xyz + 3 * j)) d2[nn++] = dist2f(xyz + 3 * i, xyz + 3 * j);
+            qsort(d2, (size_t)nn, sizeof(float), cmp_float);
+            const int64_t m = (nn < (int64_t)mean_k + 1) ? nn : (int64_t)mean_k + 1;
             double sum = 0.0;
             for (int64_t k = 1; k < m; k++) sum += (double)sqrtf(d2[k]); /* nn_dists[0] is the point itself */
             dist[i] = (float)(sum / mean_k);
@@ -56,8 +64,10 @@ void orc_sor_filter(const float *xyz, int64_t n, int mean_k, double std_mul, uin
         sum += dist[i];
         sq_sum += dist[i] * dist[i]; /* float * float, as in PCL */
     }
-    const double mean = sum / (double)n;
-    const double variance = (sq_sum - sum * sum / (double)n) / ((double)n - 1);
+    int64_t nv = 0; /* valid_distances */
+    for (int64_t i = 0; i < n; i++) nv += finite3(xyz + 3 * i);
+    const double mean = sum / (double)nv;
+    const double variance = (sq_sum - sum * sum / (double)nv) / ((double)nv - 1);
     const double stddev = sqrt(variance);
     const double thr = mean + std_mul * stddev;
     for (int64_t i = 0; i < n; i++) keep[i] = !(dist[i] > thr);
@@ -143,8 +153,8 @@ void orc_cloud_normals(const float *xyz, int64_t n, double radius, const float *
     for (int64_t i = 0; i < n; i++) {
         double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         int64_t cnt = 0;
-        for (int64_t j = 0; j < n; j++) {
-            if (!(dist2f(xyz + 3 * i, xyz + 3 * j) < r2)) continue;
+        for (int64_t j = 0; j < n && finite3(xyz + 3 * i); j++) {
+            if (!finite3(xyz + 3 * j) || !(dist2f(xyz + 3 * i, xyz + 3 * j) < r2)) continue;
             const double x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
             a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z;
             a[6] += x; a[7] += y; a[8] += z;

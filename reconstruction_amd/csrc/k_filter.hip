@@ -52,10 +52,14 @@ __global__ void k_cell_keys(const float *__restrict__ xyz, int64_t n, FGrid g, u
                             unsigned int *__restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int ix = cell_of(xyz[3 * i], g.ox, g.inv_h, g.nx), iy = cell_of(xyz[3 * i + 1], g.oy, g.inv_h, g.ny),
-              iz = cell_of(xyz[3 * i + 2], g.oz, g.inv_h, g.nz);
-    keys[i] = ((unsigned long long)iz * g.ny + iy) * g.nx + ix;
     vals[i] = (unsigned int)i;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) { // PCL's searches skip such points: they sort behind every cell
+        keys[i] = ~0ull;
+        return;
+    }
+    const int ix = cell_of(x, g.ox, g.inv_h, g.nx), iy = cell_of(y, g.oy, g.inv_h, g.ny), iz = cell_of(z, g.oz, g.inv_h, g.nz);
+    keys[i] = ((unsigned long long)iz * g.ny + iy) * g.nx + ix;
 }
 
 __global__ void k_gather_sorted(const float *__restrict__ xyz, const unsigned int *__restrict__ vals, int64_t n,
@@ -441,12 +445,18 @@ __host__ __device__ inline float ord_to_float(unsigned int o) {
 }
 __global__ void k_bbox(const float *__restrict__ xyz, int64_t n, unsigned int *__restrict__ bb) {
     unsigned int lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    unsigned int nfin = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!(isfinite(xyz[3 * i]) && isfinite(xyz[3 * i + 1]) && isfinite(xyz[3 * i + 2]))) continue;
+        nfin++;
         for (int a = 0; a < 3; a++) {
             const unsigned int o = float_to_ord(xyz[3 * i + a]);
             lo[a] = min(lo[a], o);
             hi[a] = max(hi[a], o);
         }
+    }
+    for (int o = 32; o > 0; o >>= 1) nfin += (unsigned int)__shfl_xor((int)nfin, o);
+    if ((threadIdx.x & 63) == 0 && nfin) atomicAdd(&bb[6], nfin);
     for (int a = 0; a < 3; a++) {
         for (int o = 32; o > 0; o >>= 1) {
             lo[a] = min(lo[a], (unsigned int)__shfl_xor((int)lo[a], o));
@@ -492,11 +502,13 @@ bool sample_extent(const float *d_xyz, int64_t n, hipStream_t st, float lo[3], f
         if (hipMemcpyAsync(&h[3 * (size_t)s], d_xyz + 3 * (size_t)(s * step), 3 * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     if (hipStreamSynchronize(st) != hipSuccess) return false;
     for (int a = 0; a < 3; a++) {
-        std::vector<float> v((size_t)S);
-        for (int s = 0; s < S; s++) v[(size_t)s] = h[3 * (size_t)s + a];
+        std::vector<float> v;
+        for (int s = 0; s < S; s++)
+            if (std::isfinite(h[3 * (size_t)s]) && std::isfinite(h[3 * (size_t)s + 1]) && std::isfinite(h[3 * (size_t)s + 2])) v.push_back(h[3 * (size_t)s + a]);
+        if (v.empty()) v.push_back(0.0f);
         std::sort(v.begin(), v.end());
-        lo[a] = v[(size_t)(0.01 * (S - 1))];
-        hi[a] = v[(size_t)(0.99 * (S - 1))];
+        lo[a] = v[(size_t)(0.01 * (v.size() - 1))];
+        hi[a] = v[(size_t)(0.99 * (v.size() - 1))];
         full_lo[a] = v.front();
         full_hi[a] = v.back();
     }
@@ -551,17 +563,19 @@ int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mu
     if (!sample_extent(d_xyz, n, st, lo, hi, flo, fhi)) return RSM_E_HIP;
     // exact bounding box (the sample's extremes are not the cloud's)
     DevBuf b_dist, b_redo, b_cnt, b_flag, b_pos, b_tmp, b_bb;
-    unsigned int *d_bb = b_bb.get<unsigned int>(6);
+    unsigned int *d_bb = b_bb.get<unsigned int>(8);
     if (!d_bb) return RSM_E_NOMEM;
+    int64_t nv = 0; // finite points: only they take part in the searches (PCL: the k-d tree skips the others)
     {
-        const unsigned int init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-        unsigned int bb[6];
+        const unsigned int init[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
+        unsigned int bb[7];
         if (hipMemcpyAsync(d_bb, init, sizeof init, hipMemcpyHostToDevice, st) != hipSuccess) return RSM_E_HIP;
         hipLaunchKernelGGL(k_bbox, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, st, d_xyz, n, d_bb);
         if (hipMemcpyAsync(bb, d_bb, sizeof bb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
+        nv = bb[6];
         for (int a = 0; a < 3; a++) {
-            flo[a] = ord_to_float(bb[a]);
-            fhi[a] = ord_to_float(bb[3 + a]);
+            flo[a] = nv ? ord_to_float(bb[a]) : 0.0f;
+            fhi[a] = nv ? ord_to_float(bb[3 + a]) : 0.0f;
         }
     }
     // first cell edge: ~sqrt(k + 1) point spacings of a surface patch whose area is the product of the two largest
@@ -570,7 +584,7 @@ int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mu
     // that remain after KNN_LEVELS grids are searched exhaustively
     double e[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
     std::sort(e, e + 3);
-    const double area = std::max(e[2] * e[1], 1e-12), spacing = sqrt(area / (0.98 * 0.98 * 0.98 * (double)n));
+    const double area = std::max(e[2] * e[1], 1e-12), spacing = sqrt(area / (0.98 * 0.98 * 0.98 * (double)std::max<int64_t>(nv, 1)));
     float h = (float)(spacing * sqrt((double)(mean_k + 1)));
     if (!(h > 0.0f) || !std::isfinite(h)) h = 1.0f;
     float *d_dist = b_dist.get<float>((size_t)n);
@@ -580,7 +594,8 @@ int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mu
     if (!d_dist || !d_redo || !d_redo2 || !d_cnt) return RSM_E_NOMEM;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const int KNN_LEVELS = 5;
-    int nq = (int)n, redo_n = 0;
+    if (hipMemsetAsync(d_dist, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return RSM_E_HIP; // non-finite points: distance 0, as PCL
+    int nq = (int)nv, redo_n = 0;
     const unsigned int *queries = nullptr;
     int s = RSM_OK;
     {
@@ -592,7 +607,7 @@ int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mu
             if (level == 0) queries = G.vals; // every point, in grid order (coherent waves)
             if (hipMemsetAsync(d_cnt, 0, sizeof(int) * 4, st) != hipSuccess) return RSM_E_HIP;
             unsigned int *out_list = (level & 1) ? d_redo2 : d_redo;
-            hipLaunchKernelGGL(k_sor_knn, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_xyz, G.sxyz, G.keys, (int)n, G.g, h * h, mean_k,
+            hipLaunchKernelGGL(k_sor_knn, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_xyz, G.sxyz, G.keys, (int)nv, G.g, h * h, mean_k,
                                queries, nq, d_dist, out_list, d_cnt);
             if (hipMemcpyAsync(&redo_n, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
                 return RSM_E_HIP;
@@ -600,7 +615,7 @@ int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mu
             nq = redo_n;
             if (nq <= 64) break; // cheaper to finish exhaustively than to sort again
         }
-        if (nq > 0) hipLaunchKernelGGL(k_sor_knn_all, dim3((unsigned)std::min(nq, 4096)), dim3(256), 0, st, d_xyz, G.sxyz, (int)n, mean_k, d_dist, queries, d_cnt);
+        if (nq > 0) hipLaunchKernelGGL(k_sor_knn_all, dim3((unsigned)std::min(nq, 4096)), dim3(256), 0, st, d_xyz, G.sxyz, (int)nv, mean_k, d_dist, queries, d_cnt);
         if (hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
     }
     redo_n = nq;
@@ -613,8 +628,8 @@ int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mu
         sum += hd[(size_t)i];
         sq_sum += hd[(size_t)i] * hd[(size_t)i]; // float * float, as in PCL
     }
-    const double mean = sum / (double)n;
-    const double variance = (sq_sum - sum * sum / (double)n) / ((double)n - 1);
+    const double mean = sum / (double)nv; // valid_distances
+    const double variance = (sq_sum - sum * sum / (double)nv) / ((double)nv - 1);
     const double stddev = sqrt(variance), thr = mean + std_mul * stddev;
     if (stats) {
         stats[0] = mean;
@@ -638,13 +653,17 @@ int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mu
     const int64_t m = (int64_t)last_pos + last_flag;
     *n_kept = m;
     if (m == 0 || !d_normals) return RSM_OK;
-    // normals of the filtered cloud: grid with cell edge = search radius
+    // normals of the filtered cloud: grid with cell edge = search radius; the non-finite points (all kept: distance 0)
+    // sort behind the finite ones and keep the NaN normal the buffer is filled with
     FilterGridDev G2;
     s = build_grid(d_fxyz, m, (float)normal_radius, flo, fhi, st, G2);
     if (s != RSM_OK) return s;
     const float r2 = (float)(normal_radius * normal_radius);
-    hipLaunchKernelGGL(k_cloud_normals, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, G2.sxyz, G2.keys, (int)m, G2.g, r2, cam_center[0],
-                       cam_center[1], cam_center[2], d_normals);
+    const int64_t mv = m - (n - nv);
+    if (hipMemsetD32Async((hipDeviceptr_t)d_normals, 0x7fc00000, (size_t)4 * m, st) != hipSuccess) return RSM_E_HIP;
+    if (mv > 0)
+        hipLaunchKernelGGL(k_cloud_normals, dim3((unsigned)((mv + 255) / 256)), dim3(256), 0, st, G2.sxyz, G2.keys, (int)mv, G2.g, r2,
+                           cam_center[0], cam_center[1], cam_center[2], d_normals);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return RSM_E_HIP;
     return RSM_OK;
 }

@@ -5,7 +5,8 @@
 //
 // The exchange is a FAN-IN, not a ring: xGMI is point to point, every peer owns a link to the root, so all peers
 // send at once and nothing is forwarded (a ring all-gather would be per-link bound and move world-1 times the data).
-//   1. one ncclAllReduce of 2 * n_pairs int64 (point count and owner of every pair) -- sizes the receives;
+//   1. one ncclAllReduce of 2 * n_pairs int64 (point count and owner of every pair) -- sizes the receives -- and one of
+//      a status word (can the root hold them?), so that all ranks fail together instead of half of them waiting;
 //   2. one ncclGroup: the root posts a ncclRecv per remote pair straight into its slot of the output (pair order),
 //      every other rank a ncclSend per local pair; the root's own pairs are device-to-device copies.
 // librccl is opened at run time (dlopen), so the library loads and every other entry point works without RCCL, and a
@@ -160,10 +161,15 @@ extern "C" int rsm_gather_clouds(rsm_comm *c, int root, int n_local, const int *
         if (meta[(size_t)P + p] < 0 || meta[(size_t)P + p] > c->world) return comm_err(c, RSM_E_INVALID, "rsm_gather_clouds", "a pair is held by two ranks");
         off[(size_t)p + 1] = off[(size_t)p] + meta[(size_t)p];
     }
-    if (c->rank == root) {
-        if (off[(size_t)P] > max_out || (off[(size_t)P] > 0 && !d_out)) return comm_err(c, RSM_E_INVALID, "rsm_gather_clouds", "output capacity");
-        if (out_offsets) memcpy(out_offsets, off.data(), sizeof(int64_t) * ((size_t)P + 1));
-    }
+    // the root may not be able to take the clouds (capacity): every rank has to learn that BEFORE the payload group, or
+    // the peers' sends would wait for receives that are never posted
+    int64_t bad = (c->rank == root && (off[(size_t)P] > max_out || (off[(size_t)P] > 0 && !d_out))) ? 1 : 0;
+    HCHK(c, hipMemcpyAsync(c->d_meta, &bad, sizeof bad, hipMemcpyHostToDevice, c->stream));
+    NCHK(c, R.AllReduce(c->d_meta, c->d_meta, 1, ncclInt64, ncclMax, c->comm, c->stream));
+    HCHK(c, hipMemcpyAsync(&bad, c->d_meta, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    HCHK(c, hipStreamSynchronize(c->stream));
+    if (bad) return comm_err(c, RSM_E_INVALID, "rsm_gather_clouds", "the root's output capacity is too small for the gathered clouds");
+    if (c->rank == root && out_offsets) memcpy(out_offsets, off.data(), sizeof(int64_t) * ((size_t)P + 1));
     // 2. payload fan-in: one group, every peer's sends and the root's receives in flight together
     NCHK(c, R.GroupStart());
     if (c->rank == root) {

@@ -25,7 +25,9 @@ def surface_cloud(n, seed, extent=60.0, outliers=200, duplicates=50):
     idx = rng.choice(n, duplicates, replace=False)
     xyz[idx] = xyz[rng.choice(n, duplicates)]
     xyz[:30] = [200.0, 150.0, 900.0] + rng.normal(0, 0.2, (30, 3))     # an island of 30 < k points
-    return xyz.astype(np.float32)
+    xyz = xyz.astype(np.float32)
+    xyz[40:44] = [[np.inf, 1.0, 2.0], [np.nan, np.nan, np.nan], [0.0, -np.inf, 5.0], [1.0, 2.0, np.nan]]   # d == 0 gives 1/0 (.cpp:745)
+    return xyz
 
 
 @pytest.mark.parametrize("n,seed,k", [(50000, 1, 100), (6000, 2, 100), (3000, 3, 20)])
@@ -40,6 +42,7 @@ def test_sor_and_normals_equal_the_oracle(ctx, n, seed, k):
     nrm_o = orc.cloud_normals(xyz[keep_o], 2.5, cam)
     nan_o = np.isnan(nrm_o[:, 0])
     assert np.array_equal(np.isnan(nrm[:, 0]), nan_o)
+    assert set(range(40, 44)) <= set(kept.tolist()) and nan_o.sum() >= 4    # non-finite points: kept (distance 0), NaN normal -- as PCL
     ok = ~nan_o
     # well-conditioned neighbourhoods: 1e-6; the cross-product eigenvector of a nearly isotropic neighbourhood (few
     # points) is ill-conditioned in the formula itself
