@@ -284,6 +284,8 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int
 //               rows carrying as many evaluations as the rest of the level.)
 #define NCC_G 5
 #define NCC_WIDE 160
+#define RG_SLOTS 512 // rows per direction k_ncc_rowgemm can take (more: the surplus rows fall back to k_ncc_wide)
+#define RG_MIN 48 // wide pixels of a (direction, row) from which the row is matched by k_ncc_rowgemm instead of k_ncc_wide
 
 // offers the candidate group c0..c0+G-1 (their G accumulated Sab) to the running best, ascending columns
 template <int R>
@@ -343,7 +345,10 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
         if (mm) {
             const int leader = __builtin_ctzll(mm);
             int base = 0;
-            if (lane == leader) base = atomicAdd(a.ncc_cnt, __popcll(mm));
+            if (lane == leader) {
+                base = atomicAdd(a.ncc_cnt, __popcll(mm));
+                atomicAdd(a.wrow + blockIdx.z * a.H + y, __popcll(mm));
+            }
             base = __shfl(base, leader);
             if (wide) a.rf_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
         }
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
         const DirArgs &d = a.d[ent >> 31];
         const size_t pix = ent & 0x7fffffffu;
         const int y = (int)(pix / W), x = (int)(pix % W);
+        if (!a.opt_no_rowgemm && a.wrow[(ent >> 31) * a.H + y] >= RG_MIN) continue; // the row is k_ncc_rowgemm's (uniform)
         int L, Rr;
         if (mode == 0) {
             L = d.oth.XL;
@@ -709,6 +715,225 @@ __global__ __launch_bounds__(256) void k_ncc_exact(StageArgs a, int mode) {
     }
 }
 
+
+// ---------------------------------------------------------------- rows of wide pixels as an int8 GEMM on the matrix cores
+// A row whose parent row holds no disparity searches the WHOLE other margin for every pixel (.cpp:260-283; at the lowest
+// level of a 256-disparity rig every pixel does, .cpp:207): for such a row Sab(x, c) = <window(x), window(c)> over all
+// pixels x and all candidates c is a dense [pixels x candidates x n] product -- the one place on this path where the
+// patch correlation IS a tile GEMM (north_star).  v_mfma_i32_16x16x64_i8 takes signed bytes: both views are staged as
+// b - 128 (BGRX dwords ^ 0x00808080, X = 0), then
+//     Sab = acc + 128 (Sa + Sb) - 16384 n        (exact int32; |acc| <= n 2^14)
+// K runs over the window as 16-byte pieces (4 pixels of one window row; the pixels past the window edge are zeroed in
+// the A operand): lane l feeds piece 4 ks + (l >> 4) of pixel / candidate (l & 15) -- the layout of the instruction
+// (tests/micro/mfma_i8_probe.hip).  A wave owns 16 pixels x 64 candidates per step (1 x 4 tiles, 4 MFMAs per 20 LDS
+// dwords); the epilogue turns the 16 accumulators of a lane into filter scores scaled by the pixel's own sqrt(va)
+// (constant per pixel, so the argmax and -- with the tolerance scaled alike -- the tie test are unchanged) and keeps the
+// running best of 4 pixels per lane; candidates ascend per lane, lanes are merged at the end (largest score, then
+// smallest column).  Near ties go to k_ncc_exact like everywhere else.
+#define RG_T 1                 // 16-pixel tiles per wave
+#define RG_PX (4 * 16 * RG_T)   // pixels per workgroup: 4 waves x RG_T tiles
+#define RG_CC 512 // candidates per staged chunk (the staging latency is exposed once per chunk)
+typedef int rg_v4i __attribute__((ext_vector_type(4)));
+// the rows of a direction with at least RG_MIN wide pixels, in order: wrow[2H + dir (H + 1)] = count, then the rows
+__global__ __launch_bounds__(64) void k_rg_rows(StageArgs a) {
+    const DirArgs &d = a.d[blockIdx.x];
+    int32_t *rowlist = a.wrow + 2 * a.H + blockIdx.x * (a.H + 1);
+    const int lane = threadIdx.x;
+    int seen = 0;
+    for (int yb = d.own.YL; yb <= d.own.YR; yb += 64) { // uniform
+        const int yy = yb + lane;
+        const bool q = yy <= d.own.YR && a.wrow[blockIdx.x * a.H + yy] >= RG_MIN;
+        const unsigned long long mm = __ballot(q);
+        if (q) rowlist[1 + seen + __popcll(mm & ((1ull << lane) - 1ull))] = yy;
+        seen += __popcll(mm);
+    }
+    if (lane == 0) rowlist[0] = seen;
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
+    constexpr int WS = 2 * R + 1, n = 3 * WS * WS, PQ = (WS + 3) / 4, NP = WS * PQ, KS = (NP + 3) / 4;
+    constexpr int SA = RG_PX + 4 * PQ, SB = RG_CC + 4 * PQ;
+    __shared__ uint32_t sA[WS * SA], sB[WS * SB];
+    __shared__ double sRvb[RG_CC], sPSa[RG_PX], sPsv[RG_PX]; // candidates: 1 / sqrt(vb); pixels: Sa, sqrt(va)
+    __shared__ int sSb[RG_CC], sPL[RG_PX], sPR[RG_PX];       // candidates: Sb; pixels: their interval (empty: not wide)
+    __shared__ uint8_t sOk[RG_CC];
+    __shared__ int s_lohi[2];
+    const DirArgs &d = a.d[blockIdx.z];
+    const int W = a.W;
+    const int x0 = d.own.XL + blockIdx.x * RG_PX;
+    if (x0 > d.own.XR) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    // blockIdx.y = slot: this workgroup takes the slot-th row of the direction with at least RG_MIN wide pixels (the few
+    // wide pixels of other rows stay with k_ncc_wide), from the list k_rg_rows made.
+    const int32_t *rowlist = a.wrow + 2 * a.H + blockIdx.z * (a.H + 1); // [0] = number of rows, then the rows
+    const int nrows = rowlist[0];
+    for (int slot = blockIdx.y; slot < nrows; slot += gridDim.y) { // uniform
+        __syncthreads(); // the previous row is done with the shared arrays
+        const int y = rowlist[1 + slot];
+        if (tid == 0) {
+            s_lohi[0] = 0x7fffffff;
+            s_lohi[1] = -1;
+        }
+        __syncthreads();
+        if (tid < RG_PX) { // this workgroup's pixels
+            const int x = x0 + tid;
+            const size_t pix = (size_t)y * W + min(x, W - 1);
+            bool active = (x <= d.own.XR) && (d.mask_own[pix] == 255);
+            int L = 0x7fffffff, Rr = -1;
+            if (active) {
+                if (mode == 0) {
+                    L = d.oth.XL; // .cpp:207
+                    Rr = d.oth.XR;
+                } else {
+                    L = d.BL[pix];
+                    Rr = d.BR[pix];
+                }
+                L = max(L, R);
+                Rr = min(Rr, W - 1 - R);
+                if (L > Rr) active = false;
+            }
+            const bool wide = active && (Rr - L + 1 > NCC_WIDE); // exactly k_ncc_dot4's test
+            const double Sa = wide ? (double)d.S1_own[pix] : 0.0;
+            const double va = wide ? (double)n * (double)d.S2_own[pix] - Sa * Sa : 0.0;
+            sPSa[tid] = Sa;
+            sPsv[tid] = va > 0.0 ? sqrt(va) : -1.0; // -1: zero variance -- every score is exactly 0, the scale is 1
+            sPL[tid] = wide ? L : 0x7fffffff;
+            sPR[tid] = wide ? Rr : -1;
+            int lo_ = wide ? L : 0x7fffffff, hi_ = wide ? Rr : -1;
+            for (int o = 32; o > 0; o >>= 1) {
+                lo_ = min(lo_, __shfl_xor(lo_, o));
+                hi_ = max(hi_, __shfl_xor(hi_, o));
+            }
+            if (lane == 0) {
+                atomicMin(&s_lohi[0], lo_);
+                atomicMax(&s_lohi[1], hi_);
+            }
+        }
+        // own-view rows as signed bytes: sA[j][i] <-> column x0 - R + i of row y - R + j
+        for (int i = tid; i < SA; i += 256) {
+            const int col = x0 - R + i;
+#pragma unroll
+            for (int j = 0; j < WS; j++) sA[j * SA + i] = ((col >= 0 && col < W) ? d.img4_own[(size_t)(y - R + j) * W + col] : 0u) ^ 0x00808080u;
+        }
+        __syncthreads();
+        const int cmin = s_lohi[0], cmax = s_lohi[1];
+        // running best of this lane's 4 RG_T pixels e = 4 t + r: tile t, accumulator register r -> pixel wv * 16 RG_T + t * 16 + 4 lg + r
+        double bestv[4 * RG_T];
+        int bestc[4 * RG_T];
+        unsigned exact = 0xffu, tie = 0u; // the initial -1 is exact
+#pragma unroll
+        for (int e = 0; e < 4 * RG_T; e++) {
+            const double sv = sPsv[wv * (16 * RG_T) + (e >> 2) * 16 + lg * 4 + (e & 3)];
+            bestv[e] = sv > 0.0 ? -sv : -1.0; // .cpp:205, scaled
+            bestc[e] = 0x7fffffff;
+        }
+        for (int lo = cmin; lo <= cmax; lo += RG_CC) { // uniform (no trip when the chunk holds no wide pixel)
+            __syncthreads();
+            for (int i = tid; i < SB; i += 256) {
+                const int col = lo - R + i;
+#pragma unroll
+                for (int j = 0; j < WS; j++) sB[j * SB + i] = ((col >= 0 && col < W) ? d.img4_oth[(size_t)(y - R + j) * W + col] : 0u) ^ 0x00808080u;
+            }
+            for (int ci = tid; ci < RG_CC; ci += 256) {
+                const int c = lo + ci;
+                const bool ok = c <= cmax && c >= R && c <= W - 1 - R && d.mask_oth[(size_t)y * W + c] == 255; // .cpp:209
+                const size_t o = (size_t)y * W + (ok ? c : min(max(lo, 0), W - 1));
+                const int Sb = d.S1_oth[o];
+                const double vb = (double)n * (double)d.S2_oth[o] - (double)Sb * (double)Sb;
+                double r = __builtin_amdgcn_rsq(vb > 0.0 ? vb : 1.0);
+                r = __builtin_fma(0.5 * r, __builtin_fma(-(vb * r), r, 1.0), r); // one Newton step: ~2e-16 relative
+                sOk[ci] = ok;
+                sSb[ci] = Sb;
+                sRvb[ci] = vb > 0.0 ? r : 0.0; // zero variance: score exactly 0
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int cb = 0; cb < RG_CC / 64 && lo + cb * 64 <= cmax; cb++) { // uniform
+                rg_v4i acc[RG_T][4];
+#pragma unroll
+                for (int t = 0; t < RG_T; t++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc[t][u] = rg_v4i{0, 0, 0, 0};
+#pragma unroll 2 // two k-steps of fragments in flight (fully unrolled, the hoisted gathers of all KS steps cost hundreds of registers)
+                for (int ks = 0; ks < KS; ks++) {
+                    const int p = 4 * ks + lg, j = min(p / PQ, WS - 1), q = p % PQ;
+                    rg_v4i fa[RG_T], fb[4];
+#pragma unroll
+                    for (int t = 0; t < RG_T; t++) {
+                        const int xl = wv * (16 * RG_T) + t * 16 + lr;
+#pragma unroll
+                        for (int m = 0; m < 4; m++) fa[t][m] = (p < NP && 4 * q + m < WS) ? (int)sA[j * SA + xl + 4 * q + m] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int cl = cb * 64 + u * 16 + lr;
+#pragma unroll
+                        for (int m = 0; m < 4; m++) fb[u][m] = (p < NP) ? (int)sB[j * SB + cl + 4 * q + m] : 0;
+                    }
+#pragma unroll
+                    for (int t = 0; t < RG_T; t++)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], fb[u], acc[t][u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0); // keep the later steps' gathers from being hoisted up here (registers)
+                }
+                // epilogue: D[4 lg + r][lr] of tile (t, u) = pixel e = 4 t + r of this lane x candidate cb * 64 + u * 16 + lr
+#pragma unroll
+                for (int e = 0; e < 4 * RG_T; e++) {
+                    const int xl = wv * (16 * RG_T) + (e >> 2) * 16 + lg * 4 + (e & 3);
+                    const int Lp = sPL[xl], Rp = sPR[xl];
+                    const double Sa = sPSa[xl], sv = sPsv[xl];
+                    const double tol = NCC_TIE_TOL * (sv > 0.0 ? sv : 1.0);
+                    const int Sai = (int)Sa;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int cl = cb * 64 + u * 16 + lr, c = lo + cl;
+                        if (!sOk[cl] || c < Lp || c > Rp) continue;
+                        const int Sb = sSb[cl];
+                        const double rvb = sRvb[cl];
+                        const int Sab = acc[e >> 2][u][e & 3] + 128 * (Sai + Sb) - 16384 * n;
+                        const double sc = ((double)n * (double)Sab - Sa * (double)Sb) * rvb; // score * sqrt(va)
+                        const bool exc = rvb == 0.0 || !(sv > 0.0); // a zero-variance window on either side: exactly 0
+                        if (fabs(sc - bestv[e]) <= tol && !(exc && ((exact >> e) & 1u))) tie |= 1u << e;
+                        if (sc > bestv[e]) { // .cpp:213
+                            bestv[e] = sc;
+                            bestc[e] = c;
+                            exact = (exact & ~(1u << e)) | ((unsigned)exc << e);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0); // one pixel's constants live at a time
+                }
+            }
+        }
+        // merge the 16 lanes that share the pixels (same lg): largest score, then smallest column
+#pragma unroll
+        for (int e = 0; e < 4 * RG_T; e++) {
+            const int xl = wv * (16 * RG_T) + (e >> 2) * 16 + lg * 4 + (e & 3), x = x0 + xl;
+            const double sv = sPsv[xl];
+            const double tol = NCC_TIE_TOL * (sv > 0.0 ? sv : 1.0);
+            double bv = bestv[e];
+            int bc = bestc[e];
+            bool bx = (exact >> e) & 1u, tt = (tie >> e) & 1u;
+            for (int o = 1; o < 16; o <<= 1) {
+                const double ov = __shfl_xor(bv, o);
+                const int oc = __shfl_xor(bc, o);
+                const bool ox = __shfl_xor((int)bx, o) != 0;
+                if (bc != 0x7fffffff && oc != 0x7fffffff && fabs(ov - bv) <= tol && !(ox && bx)) tt = true;
+                if (ov > bv || (ov == bv && oc < bc)) {
+                    bv = ov;
+                    bc = oc;
+                    bx = ox;
+                }
+            }
+            for (int o = 1; o < 16; o <<= 1) tt |= __shfl_xor((int)tt, o) != 0;
+            if (lr == 0 && sPR[xl] >= 0) { // a wide pixel
+                const size_t pix = (size_t)y * W + x;
+                if (bc != 0x7fffffff) d.d16_out[pix] = (int16_t)(bc - x); // .cpp:219-222 / 301-302
+                if (tt) a.tie_list[atomicAdd(a.tie_cnt, 1)] = (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
+            }
+        }
+    }
+}
+
 template <int R>
 static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st) {
     constexpr int WS = 2 * R + 1, SA = NCC_TX + 2 * R, SB = NCC_CH + 2 * R + NCC_G + 3;
@@ -724,6 +949,9 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
     if (ldsw > 65536) // radii 6 and 7 stage more than the default 64 KB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void *)k_ncc_wide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
     hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), ldsw, st, a, mode);
+    if (!a.opt_no_rowgemm) hipLaunchKernelGGL(k_rg_rows, dim3(a.ndir), dim3(64), 0, st, a);
+    if (!a.opt_no_rowgemm) // grid.y = row SLOTS: rows with many wide pixels are few (all of them only at a wide lowest level)
+        hipLaunchKernelGGL(k_ncc_rowgemm<R>, dim3((grid.x * NCC_TX + RG_PX - 1) / RG_PX, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), 0, st, a, mode);
     if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
 }
 

@@ -80,6 +80,7 @@ struct rsm_ctx {
     int32_t *nv[2]{};
     int16_t *rf_key[2]{};
     int32_t *rf_cnt = nullptr; // NCC wide-pixel counter
+    int32_t *wrow = nullptr;   // NCC: wide pixels per (direction, row) of the level at hand
     uint32_t *rf_list = nullptr;
     uint32_t *tie_list = nullptr; // NCC tie pixels (k_ncc_exact)
     int32_t *tie_cnt = nullptr;   // [2 * level + (Rematch ? 1 : 0)]
@@ -109,6 +110,7 @@ struct rsm_ctx {
     // options (rsm_set_option)
     int opt_ncc_bytes = 0;
     int opt_no_exact = 0;
+    int opt_no_rowgemm = 0;
     int opt_heavy_exclusive = 1; // large-level refine sections of contexts sharing a GPU take turns (heavy_begin)
     int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
     int opt_refine_multi_from = 0;  // first sweep of a level that may run in the two-sweeps-per-launch kernel (0: never = default: measured slower, k_refine.hip)
@@ -331,6 +333,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->rf_cnt, 32 + 2 * (size_t)in->height); // level k uses rf_cnt + k: [0] wide-pixel count, [16 + dir * H + y] Rematch pixels of a row
     DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
     DALLOC(c, c->tie_list, 2 * px + 64);
+    DALLOC(c, c->wrow, 4 * (size_t)in->height + 16); // [2H] wide pixels per row, then per direction the list of GEMM rows
     c->upd_cap = (int)std::min<size_t>(65536, std::max<size_t>(1024, px / 8));
     DALLOC(c, c->upd_list, (size_t)RF_UPD_SHARDS * c->upd_cap);
     DALLOC(c, c->upd_cnt, 2 * RF_UPD_SHARDS);
@@ -430,6 +433,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
     else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = value != 0;
+    else if (!strcmp(name, "no_rowgemm")) c->opt_no_rowgemm = value != 0;
     else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
     else if (!strcmp(name, "refine_multi_from")) c->opt_refine_multi_from = (int)std::max(0LL, std::min(value, 100000LL));
     else if (!strcmp(name, "refine_multi_min_px")) c->opt_refine_multi_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
@@ -477,6 +481,8 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.ncc_cnt = c->rf_cnt + k; // a counter per level, zeroed together at the start of the run
     a.tie_list = c->tie_list;
     a.tie_cnt = c->tie_cnt + 2 * k;
+    a.wrow = c->wrow;
+    a.opt_no_rowgemm = c->opt_no_rowgemm;
     a.upd_list = c->upd_list;
     a.upd_cnt = c->upd_cnt;
     a.upd_cap = c->upd_cap;
@@ -704,6 +710,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
             a.d[v].d16_in = c->d16i[k][v];
             a.d[v].d16_out = c->d16i[k][v];
         }
+        HIPCHK(c, hipMemsetAsync(c->wrow, 0, sizeof(int32_t) * 2 * (size_t)H, st)); // wide pixels per row of this level
         if (k == 0) {
             launch_ncc_argmax(a, 0, st);
         } else {
@@ -1071,6 +1078,7 @@ struct MatchBufs {
     int32_t *wc;
     uint32_t *tl; // tie list + counters (k_ncc_exact)
     int32_t *tc;
+    int32_t *wr;  // wide pixels per row
     int32_t *S1o, *S2o, *S1t, *S2t;
 };
 bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_oth, const uint8_t *mask_own,
@@ -1086,6 +1094,8 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     b.tl = t.alloc<uint32_t>(px + 64);
     b.tc = t.alloc<int32_t>(2);
     if (b.tc) (void)hipMemsetAsync(b.tc, 0, 2 * sizeof(int), c->stream);
+    b.wr = t.alloc<int32_t>(4 * (size_t)H + 16);
+    if (b.wr) (void)hipMemsetAsync(b.wr, 0, sizeof(int32_t) * (4 * (size_t)H + 16), c->stream);
     b.i4o = t.alloc<uint32_t>(px);
     b.i4t = t.alloc<uint32_t>(px);
     b.S1o = t.alloc<int32_t>(px);
@@ -1104,6 +1114,7 @@ StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, cons
     StageArgs a{};
     a.opt_ncc_bytes = c->opt_ncc_bytes;
     a.opt_no_exact = c->opt_no_exact;
+    a.opt_no_rowgemm = c->opt_no_rowgemm;
     a.row_lo = 0;
     a.row_hi = INT_MAX;
     a.ndir = 1;
@@ -1119,6 +1130,7 @@ void bind_match(StageArgs &a, const MatchBufs &b) {
     a.ncc_cnt = b.wc;
     a.tie_list = b.tl;
     a.tie_cnt = b.tc;
+    a.wrow = b.wr;
     DirArgs &d = a.d[0];
     d.img_own = b.io;
     d.img_oth = b.it;
@@ -1610,6 +1622,7 @@ extern "C" int rsm_bench_ncc(rsm_ctx *c, int W, int H, int r, int cands, int ite
     for (int i = 0; i < iters; i++) {
         (void)hipMemsetAsync(a.ncc_cnt, 0, sizeof(int), c->stream); // fresh wide-pixel counter per launch
         (void)hipMemsetAsync(a.tie_cnt, 0, 2 * sizeof(int), c->stream);
+        (void)hipMemsetAsync(a.wrow, 0, sizeof(int32_t) * (size_t)H, c->stream);
         launch_ncc_argmax(a, 1, c->stream);
     }
     HIPCHK(c, hipEventRecord(e1, c->stream));

@@ -66,6 +66,8 @@ struct StageArgs {
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
     uint32_t *tie_list; // NCC: pixels (dir << 31 | pixel index) whose scan saw a (near) tie -> k_ncc_exact
     int32_t *tie_cnt;   // NCC: [0] entries of tie_list after an initial-match launch, [1] after a Rematch launch (zero on entry)
+    int32_t *wrow;     // NCC: [dir * H + y] wide pixels of a row after k_ncc_dot4 (zero on entry); rows with many go to k_ncc_rowgemm
+    int opt_no_rowgemm; // A/B: every wide pixel through k_ncc_wide
     int32_t *ncc_cnt;  // NCC: [0] number of wide pixels in rf_list (zero before an initial-match launch), [16 + dir * H + y] Rematch pixels of a row
 };
 
