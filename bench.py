@@ -186,6 +186,10 @@ def main():
         except Exception:
             traffic = None
         stage_ms = {k: round(v["ms"], 3) for k, v in stage_prof.items()}  # one untimed step with stage events
+        # the same kernel with the GPU to itself (the untimed single-pair run): what the other pair in flight costs it
+        alone = stage_prof["refine_multi_top" if multi else "refine_light_top"]
+        alone_ms = alone["ms"] / max(1, alone["launches"])
+        alone_gbs = (alone["bytes"] / max(1, alone["launches"])) / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else 0.0
         total_alg_bytes = sum(v["bytes"] for k, v in stage_prof.items() if k not in ("refine_light_top", "refine_multi_top"))
         out = {
             "metric": "Mdisparities/s per GPU (11x11 NCC, 128 disp)" if args.config == "c2" else "Mdisparities/s",
@@ -203,7 +207,11 @@ def main():
                          # memory system's rate, as opposed to how many of those bytes the algorithm needs
                          "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
                          "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_ms > 0 else None,
-                         "avg_launch_ms": round(avg_ms, 5), "launches_timed_per_step": launches // args.steps // F, "concurrent_pairs": F,
+                         "avg_launch_ms": round(avg_ms, 5),
+                         "alone": {"avg_launch_ms": round(alone_ms, 5), "achieved": round(alone_gbs, 2),
+                                   "frac": round(alone_gbs / HBM_PEAK_GBS, 4),
+                                   "note": "one pair in flight (untimed extra run): no other pair's kernels beside the launch"},
+                         "launches_timed_per_step": launches // args.steps // F, "concurrent_pairs": F,
                          "sweeps_per_step": stage_prof["refine_sweep_top"]["launches"],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_pair_algorithmic_GB": round(total_alg_bytes / 1e9, 3),

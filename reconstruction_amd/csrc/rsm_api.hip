@@ -111,7 +111,8 @@ struct rsm_ctx {
     int opt_ncc_bytes = 0;
     int opt_no_exact = 0;
     int opt_no_rowgemm = 0;
-    int opt_heavy_exclusive = 1; // large-level refine sections of contexts sharing a GPU take turns (heavy_begin)
+    int opt_heavy_min_px = 400000; // ... from this many margin pixels on (smaller levels are launch-bound themselves)
+    int opt_heavy_exclusive = 1; // refine sections of contexts sharing a GPU take turns (heavy_begin): 1 = the top level's, 2 = every large level's, 0 = none
     int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
     int opt_refine_multi_from = 0;  // first sweep of a level that may run in the two-sweeps-per-launch kernel (0: never = default: measured slower, k_refine.hip)
     int opt_refine_multi_min_px = 400000; // ... at levels with at least this many margin pixels
@@ -135,14 +136,18 @@ struct rsm_ctx {
 // alone -- and would only halve each other's speed.  So those sections take turns, ordered on the GPU by events (the host
 // never blocks for it): a section waits for the event that ends the previous context's section; the short mutex
 // only makes "enqueue the section, publish its end event" atomic.
+// MEASURED (C2, two pairs in flight): no turns 214-220 Mdisp/s with every top-level sweep launch twice as long (236 us);
+// turns for every large level 210 with isolated-like launches (125 us); turns for the TOP level only (the default) 227-231:
+// the other pair's second-largest level and full-size non-refine stages then run beside the top-level sweeps and fill
+// their launch tails, at the price of 158 us per top-level launch.
 #define RSM_MAX_DEVICES 64
 static std::mutex g_heavy_mu[RSM_MAX_DEVICES];
 static hipEvent_t g_heavy_last[RSM_MAX_DEVICES];
 static rsm_ctx *g_heavy_owner[RSM_MAX_DEVICES];
-#define HEAVY_MIN_PIXELS 400000.0 // sections smaller than this are launch-bound themselves
 
-static bool heavy_begin(rsm_ctx *c, double pixels) {
-    if (!c->opt_heavy_exclusive || pixels < HEAVY_MIN_PIXELS || c->device >= RSM_MAX_DEVICES) return false;
+static bool heavy_begin(rsm_ctx *c, double pixels, bool top) {
+    if (!c->opt_heavy_exclusive || pixels < (double)c->opt_heavy_min_px || c->device >= RSM_MAX_DEVICES) return false;
+    if (c->opt_heavy_exclusive == 1 && !top) return false; // 1: only the top level's sweeps take turns
     g_heavy_mu[c->device].lock();
     if (g_heavy_last[c->device] && g_heavy_owner[c->device] != c) (void)hipStreamWaitEvent(c->stream, g_heavy_last[c->device], 0);
     return true;
@@ -432,7 +437,8 @@ static void prof_end(rsm_ctx *c, int slot, int stage, int launches, double bytes
 extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
-    else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = value != 0;
+    else if (!strcmp(name, "heavy_min_px")) c->opt_heavy_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
+    else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = (int)std::max(0LL, std::min(value, 2LL));
     else if (!strcmp(name, "no_rowgemm")) c->opt_no_rowgemm = value != 0;
     else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
     else if (!strcmp(name, "refine_multi_from")) c->opt_refine_multi_from = (int)std::max(0LL, std::min(value, 100000LL));
@@ -780,7 +786,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         const int ps12 = prof_begin(c, st_sweep);
         a.flag = (k == N - 1);
         double *bufA[2] = {c->f64[ia][0], c->f64[ia][1]}, *bufB[2] = {c->f64[ib][0], c->f64[ib][1]};
-        const bool heavy = heavy_begin(c, Pk);
+        const bool heavy = heavy_begin(c, Pk, k == N - 1);
         bool inB = false;
         const int nlaunch = refine_sweeps(c, a, bufA, bufB, iters, st, k == N - 1, &inB);
         heavy_end(c, heavy);
