@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=["c2", "c2s", "c1", "c3", "c5"])
     ap.add_argument("--inflight", type=int, default=2, help="pairs in flight per GPU (contexts run concurrently by rsm_run_pairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
