@@ -320,6 +320,13 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         dE[i] = in[(size_t)yy * W + xs + 1];
         dW[i] = in[(size_t)yy * W + xs - 1];
     }
+    { // a wave whose 64 x RF_PPT pixels are all NOMATCH (outside an elliptic mask, a hole) has nothing to update: the cache
+      // addresses below depend on the state anyway, so leaving here costs no extra round trip and saves its entry loads
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < RF_PPT; i++) any |= colok && (y0 + i <= ylast) && col[i + 1] != (double)NOMATCH;
+        if (!__ballot(any)) return; // wave-uniform; no workgroup barrier follows
+    }
     int rel[RF_PPT], crel[RF_PPT];
     double pwp[RF_PPT], delta[RF_PPT];
 #pragma unroll
