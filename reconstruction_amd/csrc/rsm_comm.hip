@@ -36,11 +36,8 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
-Rccl &rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+Rccl load_rccl() {
+    Rccl r;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -59,6 +56,10 @@ Rccl &rccl() {
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+    return r;
+}
+Rccl &rccl() {
+    static Rccl r = load_rccl(); // initialised once, thread-safe (C++11)
     return r;
 }
 } // namespace
