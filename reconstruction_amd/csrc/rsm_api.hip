@@ -111,6 +111,7 @@ struct rsm_ctx {
     int opt_ncc_bytes = 0;
     int opt_no_exact = 0;
     int opt_no_rowgemm = 0;
+    int opt_heavy_from_sweep = 1;  // ... from this sweep of the level on
     int opt_heavy_min_px = 400000; // ... from this many margin pixels on (smaller levels are launch-bound themselves)
     int opt_heavy_exclusive = 1; // refine sections of contexts sharing a GPU take turns (heavy_begin): 1 = the top level's, 2 = every large level's, 0 = none
     int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
@@ -437,6 +438,7 @@ static void prof_end(rsm_ctx *c, int slot, int stage, int launches, double bytes
 extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
+    else if (!strcmp(name, "heavy_from_sweep")) c->opt_heavy_from_sweep = (int)std::max(1LL, std::min(value, 100000LL));
     else if (!strcmp(name, "heavy_min_px")) c->opt_heavy_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = (int)std::max(0LL, std::min(value, 2LL));
     else if (!strcmp(name, "no_rowgemm")) c->opt_no_rowgemm = value != 0;
@@ -543,7 +545,7 @@ static bool degenerate(const Mg &m) { return m.YL >= m.YR || m.XL >= m.XR; } // 
 // Large levels run their settled sweeps two per launch (k_refine_multi, from sweep `refine_multi_from` on: before
 // that too many pixels still miss the data-term cache for its in-wave miss service).
 static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double *const bufB[2], int iters,
-                         hipStream_t st, bool top, bool *final_in_B) {
+                         hipStream_t st, bool top, bool *final_in_B, double heavy_px = 0.0) {
     int launches = 0;
     bool curB = false; // the current values are in bufA
     auto bind = [&](int t) {
@@ -603,7 +605,12 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         const bool multi = c && c->opt_refine_multi_from > 0 && a.upd_list && px / a.ndir >= c->opt_refine_multi_min_px;
         if (multi) (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
         int nmulti = 0;
+        // the section that takes turns with the other contexts of this GPU starts once the sweeps have settled into pure
+        // streaming: the first ones are busy computing data terms (VALU) and run well beside another pair's streaming sweeps
+        bool held = false;
+        const int turn_from = (c && heavy_px > 0.0) ? std::min(std::max(c->opt_heavy_from_sweep, 1), iters) : iters + 1;
         for (int t = 1; t < iters;) {
+            if (t >= turn_from && !held) held = heavy_begin(c, heavy_px, top);
             if (multi && t >= c->opt_refine_multi_from && t + 1 < iters) {
                 a.flag3 = nmulti++;
                 launch(t, 0, INT_MAX, true);
@@ -613,6 +620,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
                 t += 1;
             }
         }
+        heavy_end(c, held);
     } else { // time-skewed bands: sweep u + 1 of band j reads what sweep u wrote, buffers alternate with u
         for (int j = 0; Y0 + j * B - (nsw - 1) < Y1; j++)
             for (int u = 0; u < nsw; u++) {
@@ -786,10 +794,8 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         const int ps12 = prof_begin(c, st_sweep);
         a.flag = (k == N - 1);
         double *bufA[2] = {c->f64[ia][0], c->f64[ia][1]}, *bufB[2] = {c->f64[ib][0], c->f64[ib][1]};
-        const bool heavy = heavy_begin(c, Pk, k == N - 1);
         bool inB = false;
-        const int nlaunch = refine_sweeps(c, a, bufA, bufB, iters, st, k == N - 1, &inB);
-        heavy_end(c, heavy);
+        const int nlaunch = refine_sweeps(c, a, bufA, bufB, iters, st, k == N - 1, &inB, Pk);
         const int cur = inB ? ib : ia;
         prof_end(c, ps12, st_sweep, nlaunch, 32.0 * Pk * iters);
 
