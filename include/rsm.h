@@ -153,8 +153,14 @@ int rsm_gather_clouds(rsm_comm *comm, int root, int n_local, const int *pair_ids
                       const int64_t *n_points, int n_pairs_total, rsm_point16 *d_out, int64_t max_out,
                       int64_t *out_offsets);
 
-/* Validation knob (results never change): "ncc_bytes" = 1 forces the generic byte-wise NCC kernel instead of the
- * dot4 one. */
+/* Tuning / validation knobs.  None of them changes a result (every alternative path is held bit-identical by the tests):
+ *   "ncc_bytes" = 1        the generic byte-wise NCC kernel instead of the dot4 one
+ *   "no_rowgemm" = 1       rows of wide pixels through the one-workgroup-per-pixel kernel instead of the int8 row GEMM
+ *   "no_exact" = 1         (timing A/B only) skip the reference-order re-evaluation of near-tie pixels
+ *   "refine_band_mb" / "refine_band_rows"   time-skewed band schedule of the refine sweeps (0 = whole-frame, default)
+ *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)
+ *   "heavy_exclusive" = 0 | 1 | 2   contexts sharing a GPU: no turns / the top level's refine sweeps take turns (default) /
+ *                          every large level's; "heavy_min_px", "heavy_from_sweep" bound the sections that take turns */
 int rsm_set_option(rsm_ctx *ctx, const char *name, long long value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
