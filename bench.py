@@ -2,14 +2,15 @@
 """bench.py -- Mdisparities/s of the CStereoMatching hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either as above -- bench.py then starts N ranks itself through torch.distributed.run on 127.0.0.1 -- or
+   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path (ConstructPyrm -> MatchOneLayer x PyrmNum, both directions ->
-DisparityToCloud) over one stereo pair per GPU, inputs already resident in HBM, followed (N > 1) by
-the RCCL fan-in gather of the per-pair clouds to rank 0 (in flight while the next step's pair is matched; all
+DisparityToCloud) over a batch of --inflight (2) stereo pairs per GPU, inputs already resident in HBM, followed (N > 1)
+by the RCCL fan-in gather of the per-pair clouds to rank 0 (in flight while the next step's pairs are matched; all
 gathers complete inside the timed region).  Workload at every N: BASELINE.json
-configs[1] = C2 (4096x3072, 5 levels, 11x11 NCC, 128 disparities at the lowest level), one
-differently-seeded pair per rank (weak scaling).
+configs[1] = C2 (4096x3072, 5 levels, 11x11 NCC, 128 disparities at the lowest level), differently-seeded pairs on
+every rank (weak scaling).  `python bench.py --gpus N` started plainly launches its N ranks itself.
 
 metric value = sum over ranks of V_top (masked view-0 top-level pixels inside the margin) per step
              / (max-over-ranks wall time per step) / 1e6.
@@ -46,10 +47,17 @@ def main():
     ap.add_argument("--ncc-bench", action="store_true", help="also report the NCC kernel MDE/s microbenchmark")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started plainly: become the launcher of N ranks (one process per GPU)
+        raise SystemExit(self_launch(args.gpus))
+
     from reconstruction_amd import Context, run_pairs, synth
     from reconstruction_amd.dist import gather_clouds_async
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- refusing to report a %d-GPU number as --gpus %d"
+                         % (args.gpus, world, world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -66,7 +74,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, found %d" % (world, world, torch.cuda.device_count()))
 
     make = {"c2": synth.config_c2, "c2s": synth.config_c2_sample, "c1": synth.config_c1,
             "c3": synth.config_c3, "c5": synth.config_c5}[args.config]
@@ -86,33 +95,56 @@ def main():
         ctxs.append(c); cfgs.append(cfg); keep.append((t_img, t_msk))
     ctx, cfg = ctxs[0], cfgs[0]
 
-    # N > 1: the cloud of step i travels to rank 0 (RCCL fan-in) while step i + 1 is being matched -- what a rank
-    # with several pairs does in production; every gather completes inside the timed region (drain() below).
-    pending = [None]
+    # N > 1: every context free-runs its K steps on its own host thread exactly as at N = 1 (run -> pack the cloud as
+    # 16-byte records), handing each step's records to this thread, which posts the fan-in gathers in a fixed order
+    # (step, then slot) -- collectives must be posted alike on every rank -- and leaves the gather of step i in flight
+    # while step i + 1 is matched; every gather completes inside the timed region.
+    import queue
+    import threading
 
-    def step():
-        run_pairs(ctxs)  # host-synchronous; the F resident pairs are matched concurrently
-        if world > 1:
+    def run_steps(k):
+        if world == 1:
+            # K steps = every context matches its pair K times.  The contexts are not made to meet between steps: as in
+            # rsm_match_pairs (a stream of pairs over a pool of contexts) one pair's launch-bound small levels run under
+            # the other's top-level sweeps, also across step boundaries.
+            run_pairs(ctxs, repeats=k)
+            return
+        qs = [queue.Queue() for _ in ctxs]
+
+        def worker(i, c):
+            try:
+                torch.cuda.set_device(local_rank)
+                for _ in range(k):
+                    c.run_pair()
+                    n = c.n_points
+                    rec = torch.empty((n, 16), dtype=torch.uint8, device=dev)  # rsm_point16 records: 16 B per point
+                    c.pack_cloud16(rec.data_ptr(), n)
+                    qs[i].put(rec if backend == "nccl" else rec.cpu())
+            except BaseException as e:  # the main thread must not wait for records that never come
+                qs[i].put(e)
+
+        threads = [threading.Thread(target=worker, args=(i, c)) for i, c in enumerate(ctxs)]
+        for t in threads:
+            t.start()
+        pending = None
+        for _ in range(k):
             local = []
-            for i, c in enumerate(ctxs):
-                n = c.n_points
-                rec = torch.empty((n, 16), dtype=torch.uint8, device=dev)  # rsm_point16 records: 16 B per point
-                c.pack_cloud16(rec.data_ptr(), n)
-                if backend != "nccl":
-                    rec = rec.cpu()
+            for i in range(F):
+                rec = qs[i].get()
+                if isinstance(rec, BaseException):
+                    raise rec
                 local.append((rank * F + i, rec))
             h = gather_clouds_async(local, dst=0)
-            drain()
-            pending[0] = h
+            if pending is not None:
+                pending.wait()
+            pending = h
+        if pending is not None:
+            pending.wait()
+        for t in threads:
+            t.join()
 
-    def drain():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
-
-    for _ in range(args.warmup):
-        step()
-    drain()
+    if args.warmup:
+        run_steps(args.warmup)
 
     def fence():
         if world > 1:
@@ -126,15 +158,7 @@ def main():
     prof_acc = {}
     fence()
     t0 = time.perf_counter()
-    if world == 1:
-        # K steps = every context matches its pair K times.  The contexts are not made to meet between steps: as in
-        # rsm_match_pairs (a stream of pairs over a pool of contexts) one pair's launch-bound small levels run under
-        # the other's top-level sweeps, also across step boundaries.
-        run_pairs(ctxs, repeats=args.steps)
-    else:
-        for _ in range(args.steps):
-            step()
-    drain()
+    run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     for c in ctxs:
@@ -231,6 +255,29 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """Re-executes this command under torch.distributed.run with N ranks on this node (rendezvous on 127.0.0.1) and
+    passes the ranks' output through: rank 0 prints the ONE JSON line.  Fewer than N visible GPUs is an error, never a
+    silent 1-GPU measurement (RSM_BENCH_BACKEND=gloo, the single-GPU stand-in of the tests, shares device 0)."""
+    import socket
+    import subprocess
+    if os.environ.get("RSM_BENCH_BACKEND", "nccl") == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print("bench.py: --gpus %d needs %d visible GPUs, found %d" % (n, n, have), file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def kernel_src_sha():

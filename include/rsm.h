@@ -142,16 +142,62 @@ typedef struct rsm_comm rsm_comm;
  * (MPI, a file, torch.distributed's store, ...); then every rank creates its communicator on its GPU. */
 int rsm_comm_unique_id(char id[RSM_COMM_ID_BYTES]);
 int rsm_comm_create(rsm_comm **comm, const char id[RSM_COMM_ID_BYTES], int rank, int world, int hip_device);
+/* The gather protocol is written against this small transport table; rsm_comm_create fills it with RCCL.  A pipeline
+ * that already owns a transport (MPI, its own RCCL communicator) -- and the protocol tests, which run world 2/3/8 over
+ * an in-process mock on host memory -- hand in theirs.  All functions return 0 or non-zero (failure); `buf` pointers
+ * are whatever memory the caller of rsm_gather_clouds passes (device memory for RCCL).
+ *   allreduce_sum_i64  in-place sum of n int64 in HOST memory over all ranks (collective)
+ *   group_begin/_end   bracket the payload exchange; everything posted in between is complete when group_end returns
+ *   send / recv        point-to-point; between one (sender, receiver) pair they match IN POSTING ORDER (RCCL's rule)
+ *   copy               local copy (the root's own pairs) */
+typedef struct rsm_transport {
+    void *self;
+    int (*allreduce_sum_i64)(void *self, int64_t *host_buf, int n);
+    int (*group_begin)(void *self);
+    int (*send)(void *self, const void *buf, uint64_t bytes, int peer);
+    int (*recv)(void *self, void *buf, uint64_t bytes, int peer);
+    int (*copy)(void *self, void *dst, const void *src, uint64_t bytes);
+    int (*group_end)(void *self);
+} rsm_transport;
+int rsm_comm_create_transport(rsm_comm **comm, const rsm_transport *transport, int rank, int world);
 void rsm_comm_destroy(rsm_comm *comm);
 const char *rsm_comm_last_error(const rsm_comm *comm);
 /* Fan-in of the clouds of all pairs to rank `root` -- the replacement of the global `cloud_in += cloud` accumulation
  * (CCloudOptimization.cpp:61,123) when pairs are sharded one process per GPU.  Every rank passes its n_local clouds
- * (device buffers of 16-byte records, their pair ids in [0, n_pairs_total) and point counts).  On the root the clouds
- * of ALL pairs arrive in d_out (device, capacity max_out records) in pair order; out_offsets (host, n_pairs_total + 1)
- * receives each pair's first record.  Collective: every rank of the communicator calls it. */
+ * (device buffers of 16-byte records, their pair ids in [0, n_pairs_total) IN ANY ORDER, and point counts).  On the
+ * root the clouds of ALL pairs arrive in d_out (device, capacity max_out records) in pair order; out_offsets (host,
+ * n_pairs_total + 1) receives each pair's first record.  Collective: every rank of the communicator calls it, and
+ * every rank returns the SAME status: a bad argument on one rank, a pair claimed by two ranks or a root buffer that
+ * is too small make all ranks return RSM_E_INVALID before any payload moves (nobody is left waiting). */
 int rsm_gather_clouds(rsm_comm *comm, int root, int n_local, const int *pair_ids, const rsm_point16 *const *d_clouds,
                       const int64_t *n_points, int n_pairs_total, rsm_point16 *d_out, int64_t max_out,
                       int64_t *out_offsets);
+/* Counts only: every rank learns the point count of every pair (counts: n_pairs_total int64, host), e.g. to size the
+ * root's buffer before rsm_gather_clouds.  Collective, same status on every rank, same checks as the gather. */
+int rsm_gather_counts(rsm_comm *comm, int n_local, const int *pair_ids, const int64_t *n_points, int n_pairs_total,
+                      int64_t *counts);
+/* The transport-free core of rsm_gather_clouds, exposed for tests and for pipelines that post the transfers
+ * themselves.  Step 1: every rank fills its contribution to the metadata vector (RSM_GATHER_META_WORDS(P) int64:
+ * per pair the point count and the number of claims, the owner's rank, then an error count and the root's capacity);
+ * the vectors are summed over the ranks.  Step 2: from the summed vector every rank derives the SAME verdict, the
+ * pair offsets, and its own ordered list of transfers: a rank's sends ascend by pair id, and the root posts its
+ * receives per peer in that same order -- the order in which point-to-point operations between two ranks match. */
+#define RSM_GATHER_META_WORDS(P) (3 * (P) + 2)
+typedef struct rsm_gather_op {
+    int kind;          /* 0 = send to `peer`, 1 = receive from `peer`, 2 = local copy (root's own pair) */
+    int peer;
+    int pair;          /* pair id */
+    int local_index;   /* index into the caller's local arrays (send / copy), -1 for a receive */
+    int64_t offset;    /* first record of the pair in the root's output (receive / copy) */
+    int64_t count;     /* records */
+} rsm_gather_op;
+int rsm_gather_meta_fill(int rank, int world, int root, int n_local, const int *pair_ids, const int64_t *n_points,
+                         int n_pairs_total, int64_t max_out, int64_t *meta);
+/* offsets: n_pairs_total + 1; ops: capacity max_ops (n_local + n_pairs_total always suffices), *n_ops written.
+ * Returns RSM_OK, or RSM_E_INVALID when the summed metadata says the gather must not start (same on every rank). */
+int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_ids, const int64_t *n_points,
+                    int n_pairs_total, const int64_t *meta_summed, int64_t *offsets, rsm_gather_op *ops, int max_ops,
+                    int *n_ops);
 
 /* Tuning / validation knobs.  None of them changes a result (every alternative path is held bit-identical by the tests):
  *   "ncc_bytes" = 1        the generic byte-wise NCC kernel instead of the dot4 one

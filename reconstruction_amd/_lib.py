@@ -81,7 +81,8 @@ EXPORTS = [
     "rsm_bench_ncc", "rsm_write_ply", "rsm_rectify_pair", "rsm_stereo_rectify", "rsm_stage_rect_map",
     "rsm_stage_remap", "rsm_stage_erode_gray", "rsm_run_pairs", "rsm_run_pairs_repeat", "rsm_match_pairs", "rsm_match_pairs_multi_gpu",
     "rsm_pack_cloud16", "rsm_comm_unique_id", "rsm_comm_create", "rsm_comm_destroy", "rsm_comm_last_error",
-    "rsm_gather_clouds", "rsm_filter_cloud", "rsm_filter_last_cloud",
+    "rsm_gather_clouds", "rsm_gather_counts", "rsm_gather_meta_fill", "rsm_gather_plan", "rsm_comm_create_transport",
+    "rsm_filter_cloud", "rsm_filter_last_cloud",
 ]
 
 _lib = None

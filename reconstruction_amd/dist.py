@@ -140,10 +140,26 @@ class Comm:
             raise _lib.RsmError(st, "rsm_comm_unique_id (is librccl loadable?)")
         return buf.raw
 
-    def gather(self, local, n_pairs_total, root=0):
-        """local: [(pair_id, records uint8 [n,16] CUDA tensor)].  Root returns [(pair_id, records view)] for all pairs."""
+    def counts(self, local, n_pairs_total):
+        """Point count of every pair, on every rank (rsm_gather_counts: one all-reduce)."""
         from . import _lib
         n = len(local)
+        ids = (C.c_int * max(n, 1))(*[int(p) for p, _ in local])
+        cnts = (C.c_int64 * max(n, 1))(*[int(r.shape[0]) for _, r in local])
+        out = (C.c_int64 * max(n_pairs_total, 1))()
+        st = self._lib.rsm_gather_counts(self._h, n, ids, cnts, n_pairs_total, out)
+        if st != 0:
+            raise _lib.RsmError(st, (self._lib.rsm_comm_last_error(self._h) or b"").decode())
+        return list(out[:n_pairs_total])
+
+    def gather(self, local, n_pairs_total, root=0, capacity=None):
+        """local: [(pair_id, records uint8 [n,16] CUDA tensor)] in any order.  Root returns [(pair_id, records view)]
+        for all pairs.  capacity = records the root's buffer holds; None sizes it exactly with a counts-only
+        exchange first (one more all-reduce)."""
+        from . import _lib
+        n = len(local)
+        if capacity is None:
+            capacity = sum(self.counts(local, n_pairs_total))
         ids = (C.c_int * max(n, 1))(*[int(p) for p, _ in local])
         ptrs = (C.c_void_p * max(n, 1))(*[int(r.data_ptr()) if r.shape[0] else None for _, r in local])
         cnts = (C.c_int64 * max(n, 1))(*[int(r.shape[0]) for _, r in local])
@@ -151,10 +167,8 @@ class Comm:
         out = None
         cap = 0
         if self.rank == root:
-            # counts are not known before the call: size for the worst case the caller states via its own clouds'
-            # capacity; here: sum over all ranks is bounded by n_pairs_total * largest local cloud * 2
-            cap = max([int(r.shape[0]) for _, r in local] + [1]) * 2 * max(n_pairs_total, 1)
-            out = torch.empty((cap, REC), dtype=torch.uint8, device=local[0][1].device if local else "cuda")
+            cap = int(capacity)
+            out = torch.empty((max(cap, 1), REC), dtype=torch.uint8, device=local[0][1].device if local else "cuda")
         st = self._lib.rsm_gather_clouds(self._h, root, n, ids, ptrs, cnts, n_pairs_total,
                                          C.c_void_p(out.data_ptr()) if out is not None else None, C.c_int64(cap), offs)
         if st != 0:

@@ -97,13 +97,36 @@ def test_rccl_gather_of_the_c_abi_on_one_rank(ctx):
         comm.close()
 
 
-def test_bench_runs_with_two_ranks_on_the_gloo_stand_in():
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_runs_with_two_ranks_on_the_gloo_stand_in(launcher):
+    """`python bench.py --gpus 2` started plainly launches its two ranks itself (the driver's command); under
+    torch.distributed.run it takes the ranks it is given.  Either way the line says n_gpus = 2."""
     env = dict(os.environ, RSM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--config", "c2s"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "c2s"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # ONE json line, from rank 0
+    d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "roofline" in d
+    assert d["config"]["pairs_per_gpu"] == 2
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """One visible GPU, --gpus 2 on the real (nccl) backend: exit non-zero, never a silent 1-GPU number."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RSM_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr
