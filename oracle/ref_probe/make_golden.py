@@ -86,7 +86,90 @@ def build_inputs():
         else:
             a["uq_p_%d" % i], a["uq_q_%d" % i] = p, q
         a["uq_margins_%d" % i] = np.array(own + oth, np.int32)
+    build_inputs_round3(a)
     return a
+
+
+def build_inputs_round3(a):
+    """Round 3: inputs shaped like what the C2 workload produces (own generator: the entries above keep their bytes)."""
+    rng = np.random.default_rng(20260930)
+    # FindMargin at the radii of C2 / C5 (5, 7): isolated 255 pixels inside and outside the r-frame, values 254 nearby
+    for i, (r, Hh, Ww) in enumerate([(5, 64, 97), (7, 71, 120), (5, 40, 40), (7, 31, 200)], start=4):
+        m = rng.integers(0, 255, (Hh, Ww)).astype(np.uint8)          # never 255
+        if i != 6:
+            m[r + 6:Hh - r - 9, r + 11:Ww - r - 4] = 255
+        m[r - 1, Ww // 2] = 255                                      # just outside the scanned frame: ignored
+        m[Hh - r, 3] = 255
+        m[r, r] = 255 if i == 5 else 254                             # the frame's corner pixel
+        m[Hh // 2, Ww - r - 1] = 255                                 # last scanned column
+        a["fm_mask_%d" % i] = m
+        a["fm_r_%d" % i] = np.array([r], np.int32)
+    # OrderConstraint rows with ONE long crossing component (C2's top level: an outlier ties ~2000 pixels together)
+    for i, (Ww, nrows) in enumerate([(2100, 3), (2100, 3), (900, 4)], start=4):
+        x = np.arange(Ww)
+        d = np.round(6 * np.sin(x / 70.0) + 3 * np.sin(x / 13.0))[None, :].repeat(nrows + 4, 0).astype(np.int16)
+        d += rng.integers(-1, 2, d.shape).astype(np.int16)
+        for y in range(d.shape[0]):
+            if i == 4:      # an early pixel thrown far to the right: crosses everything it jumps over
+                d[y, 20 + y] = 2000
+            elif i == 5:    # a late pixel thrown far to the left, plus a second long jump nested inside the first
+                d[y, Ww - 30 - y] = -1990
+                d[y, 300] = 1200
+            else:           # several medium jumps and equal targets (ties of the crossing count)
+                for k in range(6):
+                    d[y, 60 + 130 * k] = 400 - 50 * k
+                d[y, 500:520] = (519 - np.arange(500, 520)).astype(np.int16) + 500 - 500  # all land on column 519
+        d[rng.random(d.shape) < 0.05] = NOMATCH
+        XL, XR = 5, Ww - 6
+        a["oc_disp_%d" % i] = d
+        a["oc_margin_%d" % i] = np.array([2, 2 + nrows - 1, XL, XR, XR - XL + 1, nrows], np.int32)
+    # UniquenessContraint<double>: values within 1e-12 of the int(p + 0.5) switch points k - 0.5, both signs, and of
+    # the |q + p| < 2 decision
+    for i in range(4, 6):
+        Hh, Ww = 16, 160
+        base = rng.integers(-5, 6, (Hh, Ww)).astype(np.float64)
+        eps = rng.choice([0.0, 1e-12, -1e-12, 2.0 ** -40, -2.0 ** -40, 1e-9, -1e-9], (Hh, Ww))
+        p = base - 0.5 + eps                                         # p + 0.5 = k + eps
+        q = np.zeros((Hh, Ww))
+        for y in range(Hh):
+            for x in range(Ww):
+                q[y, x] = -p[y, max(0, min(Ww - 1, x - int(rng.integers(-5, 6))))] + rng.choice([0.0, 2.0, -2.0, 2.0 - 1e-12, -2.0 + 1e-12, 1.3])
+        p[rng.random((Hh, Ww)) < 0.1] = NOMATCH
+        q[rng.random((Hh, Ww)) < 0.15] = NOMATCH
+        own = [2, Hh - 3, 9, Ww - 10, Ww - 18, Hh - 4]
+        oth = [2, Hh - 3, 11, Ww - 13, Ww - 23, Hh - 4]
+        a["uq_p_%d" % i], a["uq_q_%d" % i] = p, q
+        a["uq_margins_%d" % i] = np.array(own + oth, np.int32)
+    # NCC scores of whole rows exactly as the matchers compute them (.cpp:202-211: vecL /= normL;
+    # dot(vecL, vecR) / normR): random, two-grey-level, periodic and saturated textures (near and exact ties)
+    for i, (r, kind) in enumerate([(2, "random"), (2, "two_level"), (5, "periodic"), (5, "saturated"), (7, "two_level"), (1, "random"),
+                                   (1, "two_level_gray"), (2, "three_level"), (1, "three_level")]):
+        Hh, Ww = 2 * r + 1 + 3, 72
+        if kind == "random":
+            A = rng.integers(0, 256, (Hh, Ww, 3))
+            B = np.roll(A, 3, axis=1) + rng.integers(-6, 7, A.shape)
+        elif kind == "two_level":
+            A = rng.choice([40, 200], (Hh, Ww, 1)).repeat(3, 2)
+            B = np.roll(A, -2, axis=1)
+            B[:, ::7] = 200
+        elif kind == "two_level_gray":      # r = 1: few distinct score values, reached through different summation orders
+            A = rng.choice([0, 255], (Hh, Ww, 1)).repeat(3, 2)
+            B = rng.choice([0, 255], (Hh, Ww, 1)).repeat(3, 2)
+        elif kind == "three_level":
+            A = rng.choice([10, 100, 250], (Hh, Ww, 3))
+            B = np.where(rng.random((Hh, Ww, 3)) < 0.8, np.roll(A, 2, axis=1), rng.choice([10, 100, 250], (Hh, Ww, 3)))
+        elif kind == "periodic":
+            col = rng.integers(0, 256, (Hh, 8, 3))
+            A = np.tile(col, (1, Ww // 8, 1))
+            B = np.roll(A, 5, axis=1)
+        else:
+            A = rng.integers(0, 256, (Hh, Ww, 3))
+            A[:, 20:45] = 255
+            B = np.roll(A, 4, axis=1)
+            B[:, 50:] = 0
+        a["ncc_imgA_%d" % i] = np.clip(A, 0, 255).astype(np.uint8)
+        a["ncc_imgB_%d" % i] = np.clip(B, 0, 255).astype(np.uint8)
+        a["ncc_r_%d" % i] = np.array([r], np.int32)
 
 
 def main():

@@ -174,6 +174,40 @@ int main(int argc, char **argv) {
         snprintf(key, sizeof key, "uq_out0_%d", i); out[key] = p;
         snprintf(key, sizeof key, "uq_out1_%d", i); out[key] = q;
     }
+    fprintf(stderr, "probe: uniqueness done\n");
+    // ---- the NCC score of the matchers, evaluated with the reference's own WindowToVec and Armadillo exactly as the
+    //      call sites do (.cpp:202-211, :255-257, :290-291): vecL /= normL; CurrentValue = arma::dot(vecL, vecR) / normR.
+    //      Output: for every row y in [r, H - r) and every window centre pair (x, c) in [r, W - r)^2 the score.
+    for (int i = 0;; i++) {
+        snprintf(key, sizeof key, "ncc_imgA_%d", i);
+        if (!in.count(key)) break;
+        Arr &A = in[key];
+        snprintf(key, sizeof key, "ncc_imgB_%d", i);
+        Arr &B = in[key];
+        snprintf(key, sizeof key, "ncc_r_%d", i);
+        const int r = in[key].p<int>()[0];
+        const int H = (int)A.dims[0], W = (int)A.dims[1];
+        const int ws = 2 * r + 1, nv = ws * ws * 3, ny = H - 2 * r, nx = W - 2 * r;
+        Arr sc = make(3, {ny, nx, nx});
+        for (int y = r; y < H - r; y++) {
+            std::vector<uchar *> rowsL(ws), rowsR(ws);
+            for (int k = -r; k <= r; k++) {
+                rowsL[k + r] = A.p<uchar>() + (size_t)(y + k) * W * 3;
+                rowsR[k + r] = B.p<uchar>() + (size_t)(y + k) * W * 3;
+            }
+            for (int x = r; x < W - r; x++) {
+                arma::vec vecL(nv), vecR(nv);
+                double normL = data.WindowToVec(rowsL.data(), x - r, ws, vecL);
+                vecL /= normL;
+                for (int c = r; c < W - r; c++) {
+                    double normR = data.WindowToVec(rowsR.data(), c - r, ws, vecR);
+                    double CurrentValue = arma::dot(vecL, vecR) / normR;
+                    sc.p<double>()[((size_t)(y - r) * nx + (x - r)) * nx + (c - r)] = CurrentValue;
+                }
+            }
+        }
+        snprintf(key, sizeof key, "ncc_scores_%d", i); out[key] = sc;
+    }
     write_blob(argv[2], out);
     printf("ref_probe: %zu outputs\n", out.size());
     return 0;

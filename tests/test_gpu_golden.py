@@ -1,0 +1,84 @@
+"""The reference's golden vectors straight in front of the HIP kernels, through the C ABI (no oracle in between):
+tests/golden/ref_probe_golden.npz holds inputs and the outputs of the COMPILED reference (oracle/ref_probe links
+CStereoMatching.cpp / CManageData.cpp and the vendored Armadillo where they lie; oracle/ref_probe/make_golden.py made
+the fixture).  FindMargin (.cpp:1011-1038), OrderConstraint (.cpp:310-368), UniquenessContraint<short|double>
+(.cpp:450-497) and the NCC argmax of LowestLevelInitialMatch (.cpp:202-218, scores = WindowToVec + arma::dot of the
+reference, incl. exact and last-bit ties) must come out bit for bit.
+
+The module also re-runs tests/test_oracle_golden.py under the gpu mark, so the GPU box's own toolchain shows
+oracle == reference next to HIP == reference."""
+import numpy as np
+import pytest
+
+import test_oracle_golden as cpu_side
+from test_oracle_golden import G, N_FM, N_NCC, N_OC, N_UQ, ncc_expected_disparity
+
+pytestmark = pytest.mark.gpu
+NOMATCH = -10000
+
+
+@pytest.mark.parametrize("i", range(N_FM))
+def test_hip_find_margin_equals_the_reference(ctx, i):
+    m = ctx.find_margin(G["in__fm_mask_%d" % i], int(G["in__fm_r_%d" % i][0]))
+    assert list(m.astuple()) == list(G["ref__fm_out_%d" % i])
+
+
+@pytest.mark.parametrize("i", range(N_OC))
+def test_hip_order_constraint_equals_the_reference(ctx, i):
+    d = G["in__oc_disp_%d" % i]
+    out = ctx.order_constraint(d, tuple(int(v) for v in G["in__oc_margin_%d" % i]))
+    ref = G["ref__oc_out_%d" % i]
+    assert np.array_equal(out, ref), "%d pixels differ" % (out != ref).sum()
+
+
+@pytest.mark.parametrize("i", range(N_UQ))
+def test_hip_uniqueness_equals_the_reference(ctx, i):
+    m = [int(v) for v in G["in__uq_margins_%d" % i]]
+    p, q = G["in__uq_p_%d" % i], G["in__uq_q_%d" % i]
+    d0, d1 = ctx.uniqueness(p, q, tuple(m[:6]), tuple(m[6:]))
+    assert d0.dtype == p.dtype
+    assert np.array_equal(d0, G["ref__uq_out0_%d" % i]), (d0 != G["ref__uq_out0_%d" % i]).sum()
+    assert np.array_equal(d1, G["ref__uq_out1_%d" % i]), (d1 != G["ref__uq_out1_%d" % i]).sum()
+
+
+@pytest.mark.parametrize("i", range(N_NCC))
+def test_hip_lowest_level_match_equals_the_reference_scores_argmax(ctx, i):
+    """All masks 255, both margins = the r-frame: every pixel scans every candidate of its row; the reference's own fp64
+    scores decide the expected column (first maximum of a strict `>` scan from -1)."""
+    A, B, r = G["in__ncc_imgA_%d" % i], G["in__ncc_imgB_%d" % i], int(G["in__ncc_r_%d" % i][0])
+    H, W = A.shape[:2]
+    want = ncc_expected_disparity(G["ref__ncc_scores_%d" % i], r, W)
+    mask = np.full((H, W), 255, np.uint8)
+    mg = (r, H - 1 - r, r, W - 1 - r, W - 2 * r, H - 2 * r)
+    got = ctx.initial_match(A, B, mask, mask, r, 2, mg, mg)
+    bad = got[r:H - r] != want
+    assert not bad.any(), "%d of %d pixels pick another column than the reference's scores" % (bad.sum(), bad.size)
+    assert (got[:r] == NOMATCH).all() and (got[H - r:] == NOMATCH).all()
+
+
+@pytest.mark.parametrize("i", range(N_NCC))
+def test_hip_high_level_match_equals_the_reference_scores_argmax(ctx, i):
+    """HighLevelInitialMatch (.cpp:255-301) on the same rows: a constant parent disparity p gives every pixel the
+    interval [x + 2p - offset, x + 2p + offset] clipped to the other margin; the expected column is the first maximum
+    of the REFERENCE's scores over that interval."""
+    A, B, r = G["in__ncc_imgA_%d" % i], G["in__ncc_imgB_%d" % i], int(G["in__ncc_r_%d" % i][0])
+    H, W = A.shape[:2]
+    sc = G["ref__ncc_scores_%d" % i]
+    mask = np.full((H, W), 255, np.uint8)
+    mg = (r, H - 1 - r, r, W - 1 - r, W - 2 * r, H - 2 * r)
+    for pd, offset in cpu_side.HL_CASES:
+        parent = np.full(((H + 1) // 2 + 1, (W + 1) // 2 + 1), pd, np.float64)
+        got = ctx.initial_match(A, B, mask, mask, r, offset, mg, mg, parent=parent)
+        want = cpu_side.ncc_expected_high_level(sc, r, H, W, pd, offset)
+        assert np.array_equal(got, want), (i, pd, offset, int((got != want).sum()))
+
+
+# ---- oracle == reference, shown on the GPU box as well ---------------------------------------------------------------
+test_oracle_armadillo_on_the_gpu_box = cpu_side.test_armadillo_mean_norm_dot
+test_oracle_median_on_the_gpu_box = cpu_side.test_armadillo_median
+test_oracle_window_to_vec_on_the_gpu_box = cpu_side.test_window_to_vec
+test_oracle_find_margin_on_the_gpu_box = cpu_side.test_find_margin
+test_oracle_order_constraint_on_the_gpu_box = cpu_side.test_order_constraint
+test_oracle_uniqueness_on_the_gpu_box = cpu_side.test_uniqueness_three_passes
+test_oracle_ncc_argmax_on_the_gpu_box = cpu_side.test_lowest_level_match_against_reference_scores
+test_oracle_high_level_argmax_on_the_gpu_box = cpu_side.test_high_level_match_against_reference_scores

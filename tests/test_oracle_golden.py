@@ -44,13 +44,20 @@ def test_window_to_vec():
     assert G["ref__w2v_out_%d" % (len(G["in__w2v_cases"]) - 1)][0] == 1.0
 
 
-@pytest.mark.parametrize("i", range(4))
+N_FM, N_OC, N_UQ, N_NCC = _n("fm_mask_"), _n("oc_disp_"), _n("uq_p_"), _n("ncc_imgA_")
+
+
+def test_fixture_holds_the_round3_cases():
+    assert (N_FM, N_OC, N_UQ, N_NCC) == (8, 7, 6, 9)
+
+
+@pytest.mark.parametrize("i", range(N_FM))
 def test_find_margin(i):
     m = orc.find_margin(G["in__fm_mask_%d" % i], int(G["in__fm_r_%d" % i][0]))
     assert list(m.astuple()) == list(G["ref__fm_out_%d" % i])
 
 
-@pytest.mark.parametrize("i", range(4))
+@pytest.mark.parametrize("i", range(N_OC))
 def test_order_constraint(i):
     out = orc.order_constraint(G["in__oc_disp_%d" % i], tuple(int(v) for v in G["in__oc_margin_%d" % i]))
     ref = G["ref__oc_out_%d" % i]
@@ -58,10 +65,94 @@ def test_order_constraint(i):
     assert (ref != G["in__oc_disp_%d" % i]).sum() > 50  # the case really exercises the greedy removal
 
 
-@pytest.mark.parametrize("i", range(4))
+@pytest.mark.parametrize("i", range(N_UQ))
 def test_uniqueness_three_passes(i):
     m = [int(v) for v in G["in__uq_margins_%d" % i]]
     d0, d1 = orc.uniqueness(G["in__uq_p_%d" % i], G["in__uq_q_%d" % i], tuple(m[:6]), tuple(m[6:]))
     assert np.array_equal(d0, G["ref__uq_out0_%d" % i])
     assert np.array_equal(d1, G["ref__uq_out1_%d" % i])
     assert (G["ref__uq_out0_%d" % i] != G["in__uq_p_%d" % i]).sum() > 100
+
+
+def test_order_constraint_golden_has_a_long_crossing_component():
+    """Cases 4 and 5 are C2-shaped: one thrown pixel ties ~2000 pixels of a row into a single crossing component."""
+    for i in (4, 5):
+        d = G["in__oc_disp_%d" % i]
+        m = [int(v) for v in G["in__oc_margin_%d" % i]]
+        row = d[m[0], m[2]:m[3] + 1].astype(np.int64)
+        t = (row + np.arange(m[2], m[3] + 1))[row != -10000]
+        cuts = np.nonzero(np.maximum.accumulate(t)[:-1] <= np.minimum.accumulate(t[::-1])[::-1][1:])[0]
+        longest = np.diff(np.concatenate([[-1], cuts, [len(t) - 1]])).max()
+        assert longest >= 1800, longest
+
+
+def ncc_expected_disparity(scores, r, W):
+    """The strict-`>`-from--1 scan of LowestLevelInitialMatch (.cpp:204-218) over the REFERENCE's scores (all masks 255,
+    both margins = the r-frame): first maximum wins, a row of scores that never exceeds -1 keeps NOMATCH."""
+    ny, nx, _ = scores.shape
+    out = np.full((ny, W), -10000, np.int16)
+    for y in range(ny):
+        for x in range(nx):
+            best, arg = -1.0, -1
+            for c in range(nx):
+                v = scores[y, x, c]
+                if v > best:
+                    best, arg = v, c
+            if arg != -1:
+                out[y, x + r] = arg - x
+    return out
+
+
+@pytest.mark.parametrize("i", range(N_NCC))
+def test_lowest_level_match_against_reference_scores(i):
+    """The oracle's LowestLevelInitialMatch picks, for every pixel, the candidate the reference's own fp64 scores
+    (WindowToVec + arma::dot of the compiled reference, incl. exact and near ties) make the first maximum."""
+    A, B, r = G["in__ncc_imgA_%d" % i], G["in__ncc_imgB_%d" % i], int(G["in__ncc_r_%d" % i][0])
+    H, W = A.shape[:2]
+    sc = G["ref__ncc_scores_%d" % i]
+    want = ncc_expected_disparity(sc, r, W)
+    mask = np.full((H, W), 255, np.uint8)
+    mg = (r, H - 1 - r, r, W - 1 - r, W - 2 * r, H - 2 * r)
+    got = orc.lowest_level_initial_match(A, B, mask, mask, r, mg, mg)
+    assert np.array_equal(got[r:H - r], want)
+    assert (got[:r] == -10000).all() and (got[H - r:] == -10000).all()
+    srt = np.sort(sc, axis=2)
+    gap = srt[:, :, -1] - srt[:, :, -2]
+    if i in (2, 3, 6):      # periodic / saturated / binary textures: the maximum is shared -> the first-maximum rule decides
+        assert (gap == 0).mean() > 0.05
+    if i == 6:              # mathematically equal scores that differ in their last bits: the summation ORDER decides
+        assert ((gap > 0) & (gap < 1e-11)).sum() >= 20
+
+
+HL_CASES = ((1.0, 2), (-1.5, 3), (0.25, 5))
+
+
+def ncc_expected_high_level(scores, r, H, W, pd, offset):
+    """HighLevelInitialMatch (.cpp:255-301) with a constant parent disparity pd, all masks 255 and both margins = the
+    r-frame: candidates [x + int(2 pd + 0.5) -+ offset] clipped to the other margin, first maximum of the REFERENCE's
+    scores, strict `>` from -1."""
+    out = np.full((H, W), -10000, np.int16)
+    XL1, XR1 = r, W - 1 - r
+    for y in range(r, H - r):
+        for x in range(r, W - r):
+            c = x + int(pd * 2 + 0.5)           # int(): truncation toward zero, as the C cast
+            best, arg = -1.0, None
+            for cand in range(max(c - offset, XL1), min(c + offset, XR1) + 1):
+                v = scores[y - r, x - r, cand - r]
+                if v > best:
+                    best, arg = v, cand
+            if arg is not None:
+                out[y, x] = arg - x
+    return out
+
+
+@pytest.mark.parametrize("i", range(N_NCC))
+def test_high_level_match_against_reference_scores(i):
+    A, B, r = G["in__ncc_imgA_%d" % i], G["in__ncc_imgB_%d" % i], int(G["in__ncc_r_%d" % i][0])
+    H, W = A.shape[:2]
+    mask = np.full((H, W), 255, np.uint8)
+    mg = (r, H - 1 - r, r, W - 1 - r, W - 2 * r, H - 2 * r)
+    for pd, offset in HL_CASES:
+        parent = np.full(((H + 1) // 2 + 1, (W + 1) // 2 + 1), pd, np.float64)
+        got = orc.high_level_initial_match(A, B, mask, mask, r, offset, mg, mg, parent)
+        assert np.array_equal(got, ncc_expected_high_level(G["ref__ncc_scores_%d" % i], r, H, W, pd, offset)), (i, pd, offset)
