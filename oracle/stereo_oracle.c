@@ -78,10 +78,10 @@ double orc_exp_neg(double t) {
     } v;
     v.d = p;
     if (k >= -1021) {
-        v.u += (uint64_t)((int64_t)k << 52);
+        v.u += (uint64_t)(int64_t)k << 52;              /* shift the two's-complement pattern (no signed shift) */
         return v.d;
     }
-    v.u += (uint64_t)((int64_t)(k + 1000) << 52);
+    v.u += (uint64_t)(int64_t)(k + 1000) << 52;
     return v.d * 0x1p-1000;
 }
 

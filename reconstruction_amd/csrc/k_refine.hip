@@ -53,8 +53,8 @@ __device__ __forceinline__ double exp_neg(double t) {
     p = p * r + 1.0; // 1/0!
     // p * 2^k by exponent arithmetic; results below the normal range go through an exact power-of-two product
     const unsigned long long u = (unsigned long long)__double_as_longlong(p);
-    if (k >= -1021) return __longlong_as_double((long long)(u + (unsigned long long)((long long)k << 52)));
-    return __longlong_as_double((long long)(u + (unsigned long long)((long long)(k + 1000) << 52))) * 0x1p-1000;
+    if (k >= -1021) return __longlong_as_double((long long)(u + ((unsigned long long)(long long)k << 52)));
+    return __longlong_as_double((long long)(u + ((unsigned long long)(long long)(k + 1000) << 52))) * 0x1p-1000;
 }
 
 __global__ void k_refine_init(StageArgs a) {
