@@ -44,7 +44,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="rsm_set_option name=value (tuning knobs)")
     ap.add_argument("--stage-events", type=int, default=0, help="1: per-stage events inside the timed region too")
-    ap.add_argument("--ncc-bench", action="store_true", help="also report the NCC kernel MDE/s microbenchmark")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -173,6 +172,24 @@ def main():
     stage_prof = ctx.profile_get()
     ctx.profile_enable(False)
 
+    single = None
+    if world == 1 and rank == 0:
+        # one context alone, same workload, same run: what ONE pair costs with the GPU to itself (BASELINE configs[1]
+        # is a single pair), and the host-buffer boundary (rsm_upload_pair / rsm_download_pair over PCIe) beside it
+        ks = max(2, args.steps // 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_pairs([ctx], repeats=ks)
+        torch.cuda.synchronize()
+        single = (time.perf_counter() - t1) / ks
+        t1 = time.perf_counter()
+        ctx.upload_pair(cfg)                     # pageable host buffers -> HBM (100 MB at C2)
+        h2d = time.perf_counter() - t1
+        ctx.run_pair()
+        ctx.download_pair()                      # first call sizes and faults the host buffers
+        t1 = time.perf_counter()
+        ctx.download_pair()                      # both fp64 disparity maps + the cloud (fp64 xyz + BGR)
+        d2h = time.perf_counter() - t1
     res = ctx.download_pair(want_cloud=False, want_disparity=False)
     v_top = sum(c.download_pair(want_cloud=False, want_disparity=False).v_top for c in ctxs)
     if world > 1:
@@ -242,11 +259,21 @@ def main():
                          "whole_pair_frac": round(total_alg_bytes * F / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
             "stage_ms_per_step": stage_ms,
         }
-        if args.ncc_bench:
-            k = cfg.pyr_levels - 1
-            ms = ctx.bench_ncc(cfg.width, cfg.height, cfg.radius, 129, iters=3)
-            px = (cfg.width - 2 * cfg.radius) * (cfg.height - 2 * cfg.radius)
-            out["ncc_kernel"] = {"cands": 129, "ms_per_launch": round(ms, 3), "MDE_per_s": round(px * 129 / ms / 1e3, 1)}
+        out["roofline"]["traffic_source"] = "quoted" if traffic else None  # quoted = profiles/pmc_traffic.json (separate --pmc passes)
+        if single is not None:
+            out["value_single_pair"] = round(res.v_top / single / 1e6, 3)   # one pair in flight, inputs resident in HBM
+            out["ms_single_pair"] = round(single * 1e3, 3)
+            out["h2d_ms"] = round(h2d * 1e3, 2)
+            out["d2h_ms"] = round(d2h * 1e3, 2)
+            out["value_single_pair_pcie_inclusive"] = round(res.v_top / (single + h2d + d2h) / 1e6, 3)
+        if world == 1 and args.config in ("c2", "c5"):
+            # the NCC kernel alone (pixel x candidate evaluations per second) at SURVEY 8(d)'s two points, two launches each
+            out["ncc_kernel"] = {}
+            for r_, cands in ((5, 129), (7, 257)):
+                ms = ctx.bench_ncc(cfg.width, cfg.height, r_, cands, iters=2)
+                px = (cfg.width - 2 * r_) * (cfg.height - 2 * r_)
+                out["ncc_kernel"]["%dx%d_%d" % (2 * r_ + 1, 2 * r_ + 1, cands)] = {
+                    "ms_per_launch": round(ms, 3), "MDE_per_s": round(px * cands / ms / 1e3, 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth)
         print(json.dumps(out), flush=True)
@@ -299,9 +326,19 @@ def cpu_baseline(synth):
     t0 = time.perf_counter()
     r = orc.match_pair(cfg, want_cloud=True, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(r["v_top"] / dt / 1e6, 5), "unit": "Mdisparities/s", "cores": cores, "kind": "port",
-            "sample": "%s: one whole pair of the bench workload (5 levels, 11x11 NCC, offset 2), %d masked pixels, %.1f s "
-                      "(refine %.1f s, NCC match %.1f s)" % (cfg.name, r["v_top"], dt, r["refine_seconds"], r["match_seconds"])}
+    out = {"value": round(r["v_top"] / dt / 1e6, 5), "unit": "Mdisparities/s", "cores": cores, "kind": "port",
+           "sample": "%s: one whole pair of the bench workload (5 levels, 11x11 NCC, offset 2), %d masked pixels, %.1f s "
+                     "(refine %.1f s, NCC match %.1f s)" % (cfg.name, r["v_top"], dt, r["refine_seconds"], r["match_seconds"])}
+    # the scalar figure ("1 thread"): the same port on ONE thread, on a sample sized for ~20 s
+    small = synth.make_pair(1024, 768, 3, radius=5, offset=2, pair=0, mask_kind="rect", mask_l0_width=128, border_l0=6,
+                            d0_l0=2.0, amp_l0=1.0, name="C2t_1024x768_r5_3levels")
+    t0 = time.perf_counter()
+    r1 = orc.match_pair(small, want_cloud=True, threads=1)
+    dt1 = time.perf_counter() - t0
+    out["value_1thread"] = round(r1["v_top"] / dt1 / 1e6, 5)
+    out["sample_1thread"] = "%s (11x11 NCC, 3 levels, 64 candidates at the lowest level), %d masked pixels, %.1f s on 1 thread" % (
+        small.name, r1["v_top"], dt1)
+    return out
 
 
 if __name__ == "__main__":

@@ -65,7 +65,8 @@ def main(argv=None) -> int:
             print("no points")
             return 2
         xyz = np.concatenate([c[0] for c in sink.cloud_normals]).astype(np.float64)
-        bgr = np.zeros((len(xyz), 3), np.uint8)
+        bgr = np.concatenate(sink.cloud_bgr)
+        normals = np.concatenate([c[1] for c in sink.cloud_normals])
     else:
         if not sink.xyz:
             print("no points")
@@ -75,7 +76,7 @@ def main(argv=None) -> int:
     # the configuration's outfilename already carries its extension ("%s%d.ply", BatchProcess/main.cpp:56)
     name = data.outfilename or "cloud"
     out = args.out or (name if name.lower().endswith(".ply") else name + ".ply")
-    write_ply(out, xyz, bgr)
+    write_ply(out, xyz, bgr, normals if args.filter else None)
     print("%d points -> %s" % (len(xyz), out))
     return 0
 

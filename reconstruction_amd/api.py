@@ -47,11 +47,24 @@ def stereo_rectify(K1, K2, size, R, T):
     return R1, R2, P1, P2, Q
 
 
-def write_ply(path, xyz, bgr):
-    """cloud%d.ply of DisparityToCloud (.cpp:723-729,754-756) through the C ABI (host-only, no GPU needed)."""
+def write_ply(path, xyz, bgr, normals=None):
+    """cloud%d.ply of DisparityToCloud (.cpp:723-729,754-756) through the C ABI (host-only, no GPU needed).
+    With `normals` ([n,4]: nx, ny, nz, curvature -- pcl::PointNormal's fields, what filter() accumulates in
+    cloud_normals, CCloudOptimization.cpp:123) the same records are followed by four float properties."""
     xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
     bgr = _u8(bgr).reshape(-1, 3)
     assert len(xyz) == len(bgr)
+    if normals is not None:
+        nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 4)
+        assert len(nrm) == len(xyz)
+        rec = np.zeros(len(xyz), dtype=[("xyz", "<f4", 3), ("bgr", "u1", 3), ("n", "<f4", 4)])
+        rec["xyz"], rec["bgr"], rec["n"] = xyz.astype(np.float32), bgr, nrm
+        with open(path, "wb") as f:
+            f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                     "property float z\nproperty uchar blue\nproperty uchar green\nproperty uchar red\nproperty float nx\n"
+                     "property float ny\nproperty float nz\nproperty float curvature\nend_header\n" % len(xyz)).encode())
+            f.write(rec.tobytes())
+        return
     st = _lib.load().rsm_write_ply(str(path).encode(), _p(xyz), _p(bgr), C.c_int64(len(xyz)))
     if st != 0:
         raise RsmError(st, "rsm_write_ply(%s)" % path)
@@ -611,7 +624,9 @@ class CloudOptimization:
     def __init__(self, ctx: Context | None = None, device: int = 0):
         self._ctx = ctx or Context(device)
         self._pts = []
+        self._bgr = None
         self.cloud_normals = []
+        self.cloud_bgr = []      # colours of the surviving points, per pair (imagePyrm[top][0], .cpp:756)
         self.stats = []
 
     def Init(self, sor_meank, sor_stdThres, outrem_neighbor, outrem_radius, mls_radius, ImageData, isdelete_=False):
@@ -625,10 +640,14 @@ class CloudOptimization:
 
     def InsertPoints(self, xyz, bgr=None):
         self._pts = [np.asarray(xyz, np.float64).reshape(-1, 3)]
+        self._bgr = None if bgr is None else np.asarray(bgr, np.uint8).reshape(-1, 3)
 
     def filter(self, idx):
         xyz = (np.concatenate([np.atleast_2d(p) for p in self._pts]) if self._pts else np.zeros((0, 3))).astype(np.float32)
         kept, nrm, st = self._ctx.filter_cloud(xyz, self.m_sor_meank, self.m_sor_stdThres, self.m_mls_radius, self.CamCenter[idx])
         self.cloud_normals.append((xyz[kept], nrm))
+        self.cloud_bgr.append(self._bgr[kept] if self._bgr is not None and len(self._bgr) == len(xyz)
+                              else np.zeros((len(kept), 3), np.uint8))
         self.stats.append(st)
         self._pts = []   # cloud_in->clear(), :145
+        self._bgr = None

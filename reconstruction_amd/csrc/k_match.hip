@@ -711,6 +711,10 @@ __global__ __launch_bounds__(256) void k_ncc_exact(StageArgs a, int mode) {
                 bc = oc;
             }
         }
+        // No candidate beats -1 strictly: the reference leaves d[x] as it was (.cpp:219, :301, :563) -- and "as it was" is
+        // NOMATCH in all three callers: both initial matchers start from a NOMATCH-filled map (.cpp:174, :235) and Rematch
+        // only scans pixels whose value IS NOMATCH (.cpp:537).  The filter kernel may already have stored its own choice
+        // here, so the value is restored explicitly.
         if (on && lane == 0) d.d16_out[pix] = (bc != 0x7fffffff) ? (int16_t)(bc - x) : (int16_t)NOMATCH;
     }
 }

@@ -72,6 +72,49 @@ def test_c3_shipped_scale_ten_pair_loop(ctx):
     assert np.array_equal(sm.disparity[0], ref["disparity"][0])  # the last pair's maps
 
 
+def test_c3_ten_fullsize_pairs_through_the_pair_queue(ctx):
+    """BASELINE config 3 as stated: ALL ten stereo pairs of the rig at full size (3072x4096, 5 levels, 11x11 NCC) on one
+    MI355X.  rsm_match_pairs over a pool of two contexts (host buffers in and out, pairs overlapping each other's PCIe
+    copies) must give, for every pair, exactly the bytes of the same pair run alone through one context
+    (rsm_match_pair); statuses all 0; the PCIe-inclusive rate is reported.  (One of these pairs is held against the
+    oracle by test_c3_pair_equals_the_oracle; the loop at the shipped scale by the test above.)"""
+    import hashlib
+    import time
+
+    from reconstruction_amd import Context, match_pairs
+
+    n_pairs = 10
+    cfgs = [synth.config_c3(pair=p) for p in range(n_pairs)]
+
+    def digest(res):
+        h = hashlib.sha1()
+        for a in (res.disparity[0], res.disparity[1], res.xyz, res.bgr):
+            h.update(np.ascontiguousarray(a).tobytes())
+        return (h.hexdigest(), tuple(res.margin), res.n_points, res.v_top)
+
+    alone = []
+    for cfg in cfgs:                       # pair by pair through ONE context
+        alone.append(digest(ctx.match_pair(cfg)))
+    assert len({a[0] for a in alone}) == n_pairs          # ten different pairs
+    pool = [Context(0), Context(0)]
+    try:
+        match_pairs(pool, cfgs[:2], want_cloud=True, want_disparity=True)     # sizes the workspaces (untimed)
+        tm = {}
+        res, st = match_pairs(pool, cfgs, want_cloud=True, want_disparity=True, timing=tm)
+    finally:
+        for c in pool:
+            c.close()
+    assert st == [0] * n_pairs
+    for p in range(n_pairs):
+        assert digest(res[p]) == alone[p], "pair %d differs between the queue and the single context" % p
+        assert res[p].v_top > 5_000_000 and res[p].n_points > 4_000_000
+    v = sum(r.v_top for r in res)
+    rate = v / tm["call_s"] / 1e6
+    print("C3 rig, 10 full-size pairs, 2 contexts, host buffers in/out: %.1f ms per pair, %.1f Mdisp/s PCIe-inclusive"
+          % (tm["call_s"] / n_pairs * 1e3, rate))
+    assert rate > 50.0                     # a queue that serialised on the host would sit far below
+
+
 def test_c5_geometry_reduced_equals_the_oracle(ctx):
     """15x15 windows (n = 675), 256 candidates at the lowest level -- wider than NCC_WIDE, so every lowest-level pixel
     goes through the one-workgroup-per-pixel kernel with its 78 KB of LDS."""
