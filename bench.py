@@ -190,6 +190,19 @@ def main():
         t1 = time.perf_counter()
         ctx.download_pair()                      # both fp64 disparity maps + the cloud (fp64 xyz + BGR)
         d2h = time.perf_counter() - t1
+        # the per-pair cloud filter on the cloud just made (statistical outlier removal k = 100 / 1 sigma +
+        # radius-2.5 normals, CReconstruction.cpp:18), on the GPU, output = the RCCL payload without the outliers
+        n_pts = ctx.n_points
+        rec = torch.empty((n_pts, 16), dtype=torch.uint8, device=dev)
+        nrm = torch.empty((n_pts, 4), dtype=torch.float32, device=dev)
+        filt = None
+        for _ in range(2):                       # the first call sizes the filter's arena
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_kept, _st = ctx.filter_last_cloud(rec.data_ptr(), nrm.data_ptr(), n_pts, 100, 1.0, 2.5, (0.0, 0.0, 0.0))
+            torch.cuda.synchronize()
+            filt = (time.perf_counter() - t1, n_kept)
+        del rec, nrm
     res = ctx.download_pair(want_cloud=False, want_disparity=False)
     v_top = sum(c.download_pair(want_cloud=False, want_disparity=False).v_top for c in ctxs)
     if world > 1:
@@ -266,6 +279,8 @@ def main():
             out["h2d_ms"] = round(h2d * 1e3, 2)
             out["d2h_ms"] = round(d2h * 1e3, 2)
             out["value_single_pair_pcie_inclusive"] = round(res.v_top / (single + h2d + d2h) / 1e6, 3)
+            out["filter_ms"] = round(filt[0] * 1e3, 2)
+            out["filter_points"] = {"in": int(n_pts), "kept": int(filt[1])}
         if world == 1 and args.config in ("c2", "c5"):
             # the NCC kernel alone (pixel x candidate evaluations per second) at SURVEY 8(d)'s two points, two launches each
             out["ncc_kernel"] = {}

@@ -34,10 +34,16 @@
 
 #include <string.h>
 
+#define FILTER_MAX_CELLS (1 << 25) // cells a per-cell table is made for (256 MB); beyond that: binary search on the keys
+// Grid in KEY order: axis "x" is the fastest digit of the cell key, and it is the WORLD axis with the most cells (p0) --
+// a depth map is a sheet in a deep box, so the rows of cells along its depth hold a handful of points each and the
+// per-row table + short search inside the row (table kind 2) stays cheap when the cells are too many for a table.
 struct FGrid {
     float ox, oy, oz, inv_h;
     int nx, ny, nz;
+    int p0, p1, p2; // world axis (0 = x, 1 = y, 2 = z) of key axis x, y, z
 };
+__device__ __forceinline__ float pick_axis(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
 
 __device__ __forceinline__ float fdist2(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
@@ -46,6 +52,12 @@ __device__ __forceinline__ float fdist2(float ax, float ay, float az, float bx, 
 __device__ __forceinline__ int cell_of(float v, float o, float inv_h, int n) {
     const int c = (int)floorf((v - o) * inv_h);
     return min(max(c, 0), n - 1);
+}
+// cell of a world point, in key order
+__device__ __forceinline__ void grid_cell(const FGrid &g, float x, float y, float z, int &ix, int &iy, int &iz) {
+    ix = cell_of(pick_axis(g.p0, x, y, z), g.ox, g.inv_h, g.nx);
+    iy = cell_of(pick_axis(g.p1, x, y, z), g.oy, g.inv_h, g.ny);
+    iz = cell_of(pick_axis(g.p2, x, y, z), g.oz, g.inv_h, g.nz);
 }
 
 __global__ void k_cell_keys(const float *__restrict__ xyz, int64_t n, FGrid g, unsigned long long *__restrict__ keys,
@@ -58,7 +70,8 @@ __global__ void k_cell_keys(const float *__restrict__ xyz, int64_t n, FGrid g, u
         keys[i] = ~0ull;
         return;
     }
-    const int ix = cell_of(x, g.ox, g.inv_h, g.nx), iy = cell_of(y, g.oy, g.inv_h, g.ny), iz = cell_of(z, g.oz, g.inv_h, g.nz);
+    int ix, iy, iz;
+    grid_cell(g, x, y, z, ix, iy, iz);
     keys[i] = ((unsigned long long)iz * g.ny + iy) * g.nx + ix;
 }
 
@@ -80,10 +93,30 @@ __device__ __forceinline__ int lower_bound_key(const unsigned long long *__restr
     return lo;
 }
 
-// the 9 contiguous ranges of the sorted array that hold the 27 cells around p
+// cell table: (first, one-past-last) sorted index of every cell's points; (0, 0) for an empty cell
+// div = 1: per cell; div = nx: per (y, z) row of cells (a deep or thick cloud has too many cells for a table of them)
+__global__ void k_cell_table(const unsigned long long *__restrict__ keys, int nv, unsigned long long div, int2 *__restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const unsigned long long k = keys[i] / div;
+    if (i == 0 || keys[i - 1] / div != k) table[k].x = i;
+    if (i == nv - 1 || keys[i + 1] / div != k) table[k].y = i + 1;
+}
+__device__ __forceinline__ int lower_bound_key_in(const unsigned long long *__restrict__ keys, int lo, int hi, unsigned long long k) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < k) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// the 9 contiguous ranges of the sorted array that hold the 27 cells around p (binary search on the keys; used by the
+// normals and by the k-nearest search when the grid has too many cells for a table)
 __device__ __forceinline__ void ranges9(const unsigned long long *__restrict__ keys, int n, const FGrid &g, float px, float py,
                                         float pz, int (&rs)[9], int (&re)[9]) {
-    const int ix = cell_of(px, g.ox, g.inv_h, g.nx), iy = cell_of(py, g.oy, g.inv_h, g.ny), iz = cell_of(pz, g.oz, g.inv_h, g.nz);
+    int ix, iy, iz;
+    grid_cell(g, px, py, pz, ix, iy, iz);
     const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.nx - 1);
 #pragma unroll
     for (int t = 0; t < 9; t++) {
@@ -98,24 +131,60 @@ __device__ __forceinline__ void ranges9(const unsigned long long *__restrict__ k
     }
 }
 
-// mean distance to the k nearest neighbours (statistical_outlier_removal.hpp).  One wave per query point: the squared
-// distances to the candidates of the 27 cells are computed once into registers (lane l holds candidates l, l + 64, ...),
-// the (k+1)-th smallest is found by bisection on its bit pattern with ballots, the sum by a wave reduction.
+// mean distance to the k nearest neighbours (statistical_outlier_removal.hpp).  One wave per query point: the 27 cells
+// around it are 9 contiguous ranges of the sorted array -- their ends come from the cell table (lanes 0..26 load one
+// cell each: one round trip) or, without a table, from binary searches; the squared distances to the candidates are
+// computed once into registers (lane l holds candidates l, l + 64, ...; the asm fence keeps the compiler from
+// re-loading them in every bisection step -- the first version did, 36 VGPRs and 120 ns per query), the (k+1)-th
+// smallest is found by bisection on its bit pattern with ballots, the sum by a wave reduction.
 // A query with more than 64 * KNN_C candidates re-computes them per bisection step instead.
-#define KNN_C 32
+#define KNN_C 32    // registers per lane for the candidates within h
+#define KNN_CAP (64 * KNN_C)
+#define KNN_B 16    // candidate loads in flight per lane
+template <int TABLE> // 1: per-cell table, 2: per-row table + a short binary search inside the row, 0: binary search on all keys
 __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, const float4 *__restrict__ sxyz,
-                                                  const unsigned long long *__restrict__ keys, int n, FGrid g, float h2, int mean_k,
-                                                  const unsigned int *__restrict__ queries, int nq, float *__restrict__ dist_orig,
-                                                  unsigned int *__restrict__ redo, int *__restrict__ redo_cnt) {
+                                                  const unsigned long long *__restrict__ keys, const int2 *__restrict__ table, int n,
+                                                  FGrid g, float h2, int mean_k, const unsigned int *__restrict__ queries, int nq,
+                                                  float *__restrict__ dist_orig, unsigned int *__restrict__ undecided /* [nq]: 1 = retry on a coarser grid */) {
+    __shared__ float s_d2[4][KNN_CAP];
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= nq) return; // wave-uniform
+    if (qi >= nq) return; // wave-uniform; no workgroup barrier below
     const unsigned int orig = queries[qi];
     const float px = xyz[3 * (size_t)orig], py = xyz[3 * (size_t)orig + 1], pz = xyz[3 * (size_t)orig + 2];
-    // lanes 0..8 find one range each
-    int my_s = 0, my_e = 0;
-    if (lane < 9) {
-        const int ix = cell_of(px, g.ox, g.inv_h, g.nx), iy = cell_of(py, g.oy, g.inv_h, g.ny), iz = cell_of(pz, g.oz, g.inv_h, g.nz);
+    int ix, iy, iz;
+    grid_cell(g, px, py, pz, ix, iy, iz);
+    int my_s = 0, my_e = 0; // range t in lane t (t < 9)
+    if (TABLE == 2) {
+        if (lane < 9) {
+            const int yy = iy + lane % 3 - 1, zz = iz + lane / 3 - 1;
+            if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const unsigned long long row = (unsigned long long)zz * g.ny + yy, base = row * g.nx;
+                const int2 se = table[row];
+                my_s = lower_bound_key_in(keys, se.x, se.y, base + max(ix - 1, 0));
+                my_e = lower_bound_key_in(keys, my_s, se.y, base + min(ix + 1, g.nx - 1) + 1);
+            }
+        }
+    } else if (TABLE == 1) {
+        // lane 3 t + j: cell (ix - 1 + j, iy + t % 3 - 1, iz + t / 3 - 1); its points are [x, y) of the sorted array
+        int cs = 0, ce = 0;
+        if (lane < 27) {
+            const int t = lane / 3, xx = ix - 1 + lane % 3, yy = iy + t % 3 - 1, zz = iz + t / 3 - 1;
+            if (xx >= 0 && xx < g.nx && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const int2 se = table[((size_t)zz * g.ny + yy) * g.nx + xx];
+                cs = se.x;
+                ce = se.y;
+            }
+        }
+        // the three x-adjacent cells hold consecutive keys: first non-empty cell's start .. last non-empty cell's end
+        const int s0 = __shfl(cs, 3 * lane), s1 = __shfl(cs, 3 * lane + 1), s2 = __shfl(cs, 3 * lane + 2);
+        const int e0 = __shfl(ce, 3 * lane), e1 = __shfl(ce, 3 * lane + 1), e2 = __shfl(ce, 3 * lane + 2);
+        if (lane < 9) {
+            my_s = e0 > s0 ? s0 : (e1 > s1 ? s1 : s2);
+            my_e = e2 > s2 ? e2 : (e1 > s1 ? e1 : (e0 > s0 ? e0 : my_s));
+            if (!(e0 > s0 || e1 > s1 || e2 > s2)) my_s = my_e = 0;
+        }
+    } else if (lane < 9) {
         const int yy = iy + lane % 3 - 1, zz = iz + lane / 3 - 1;
         if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
             const unsigned long long base = ((unsigned long long)zz * g.ny + yy) * g.nx;
@@ -132,45 +201,67 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
     }
     const int M = pre[9], want = mean_k + 1; // the point itself is the first of the k + 1 results
     auto cand = [&](int c) -> float { // squared distance to candidate c < M of the concatenated ranges
-        int r = 0;
+        int base = rs[0] - pre[0];
 #pragma unroll
-        for (int t = 1; t < 9; t++) r += c >= pre[t];
-        int off = c, base = 0;
-#pragma unroll
-        for (int t = 0; t < 9; t++)
-            if (t == r) {
-                off = c - pre[t];
-                base = rs[t];
-            }
-        const float4 o = sxyz[base + off];
+        for (int t = 1; t < 9; t++) base = c >= pre[t] ? rs[t] - pre[t] : base;
+        const float4 o = sxyz[base + c];
         return fdist2(px, py, pz, o.x, o.y, o.z);
     };
     const float inf = __uint_as_float(0x7f800000u);
+    // Only candidates within h of the query matter (a query is decided here iff k + 1 of them exist): the squared
+    // distances are computed in chunks of KNN_B loads per lane in flight, those <= h^2 are compacted into the wave's
+    // LDS list (about a third of the 27 cells' points for a surface, a sixth for a volume) and read back into registers,
+    // lane l holding entries l, l + 64, ...; the asm fence keeps the compiler from re-deriving them from memory in
+    // every bisection step (the first version did: 120 ns per query).
+    float *mine = s_d2[threadIdx.x >> 6];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int K = 0; // candidates within h so far (uniform)
+    for (int c0 = 0; c0 < M; c0 += 64 * KNN_B) { // uniform
+        float v[KNN_B];
+#pragma unroll
+        for (int i = 0; i < KNN_B; i++) {
+            const int c = c0 + lane + 64 * i;
+            v[i] = (c < M) ? cand(c) : inf;
+        }
+#pragma unroll
+        for (int i = 0; i < KNN_B; i++) {
+            const bool keep = v[i] <= h2;
+            const unsigned long long mm = __ballot(keep);
+            const int pos = K + __popcll(mm & lt);
+            if (keep && pos < KNN_CAP) mine[pos] = v[i];
+            K += __popcll(mm);
+        }
+    }
+    // (a flag per query, compacted by a scan afterwards: appending to one list through a single counter retires ~88
+    // appends per microsecond -- 62 ms for a level that decides nothing)
+    if (lane == 0) undecided[qi] = K < want;
+    if (K < want) return; // not decidable inside the 27 cells
     float tau;
     double sum = 0.0;
     int less = 0;
-    if (M <= 64 * KNN_C) {
+    if (K <= KNN_CAP) {
+        __builtin_amdgcn_wave_barrier();
         float d2[KNN_C];
-        const int nreg = (M + 63) >> 6; // wave-uniform
+        const int nreg = (K + 63) >> 6; // wave-uniform
 #pragma unroll
         for (int i = 0; i < KNN_C; i++) {
             d2[i] = inf;
-            if (i < nreg) {
-                const int c = lane + 64 * i;
-                if (c < M) d2[i] = cand(c);
-            }
+            if (i < nreg && lane + 64 * i < K) d2[i] = mine[lane + 64 * i];
+            asm volatile("" : "+v"(d2[i])); // materialise: the value lives in a register from here on
         }
-        auto count_le = [&](float t) {
+        auto count4 = [&](float t, int i0) {
             int cnt = 0;
 #pragma unroll
-            for (int i = 0; i < KNN_C; i++)
-                if (i < nreg) cnt += __popcll(__ballot(d2[i] <= t));
+            for (int i = 0; i < 4; i++) cnt += __popcll(__ballot(d2[i0 + i] <= t));
             return cnt;
         };
-        if (count_le(h2) < want) { // not decidable inside the 27 cells
-            if (lane == 0) redo[atomicAdd(redo_cnt, 1)] = orig;
-            return;
-        }
+        auto count_le = [&](float t) { // registers past nreg hold +inf; whole groups of 4 are skipped (uniform)
+            int cnt = count4(t, 0);
+#pragma unroll
+            for (int g4 = 1; g4 < KNN_C / 4; g4++)
+                if (nreg > 4 * g4) cnt += count4(t, 4 * g4);
+            return cnt;
+        };
         unsigned int lo = 0u, hi = __float_as_uint(h2); // smallest bit pattern b with count_le(b) >= want
         while (lo < hi) {
             const unsigned int mid = lo + ((hi - lo) >> 1);
@@ -184,7 +275,7 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
                 sum += (double)sqrtf(d2[i]);
                 less++;
             }
-    } else {
+    } else { // more than KNN_CAP points within h (a far too coarse first level): bisection straight on the candidates
         auto count_le = [&](float t) {
             int cnt = 0;
             for (int c0 = 0; c0 < M; c0 += 64) { // uniform trip count
@@ -193,10 +284,6 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
             }
             return cnt;
         };
-        if (count_le(h2) < want) {
-            if (lane == 0) redo[atomicAdd(redo_cnt, 1)] = orig;
-            return;
-        }
         unsigned int lo = 0u, hi = __float_as_uint(h2);
         while (lo < hi) {
             const unsigned int mid = lo + ((hi - lo) >> 1);
@@ -219,75 +306,185 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
     if (lane == 0) dist_orig[orig] = (float)((sum + (double)(want - less) * (double)sqrtf(tau)) / mean_k);
 }
 
-// the same for one listed point per workgroup against ALL points: radix select of the (k+1)-th smallest d2
-// (bits 30..20, 19..9, 8..0 of its pattern), then the sum
-__global__ __launch_bounds__(256) void k_sor_knn_all(const float *__restrict__ xyz, const float4 *__restrict__ sxyz, int n, int mean_k,
-                                                      float *__restrict__ dist_orig, const unsigned int *__restrict__ redo,
-                                                      const int *__restrict__ redo_cnt) {
+// ---- the few queries no grid level could decide (isolated points -- what this filter removes -- and clusters smaller
+// than k): against ALL points, the whole chip on every query.  Three-pass radix select of the (k+1)-th smallest squared
+// distance (bits 30..20, 19..9, 8..0 of its pattern): per pass every workgroup histograms its slice of the points for
+// one query and adds the non-empty bins to the query's global histogram, a one-workgroup kernel picks the bin; then the
+// partial sums of sqrt(d2) over d2 < tau (exact in double for <= 100 float32 values, hence order-free) are added up.
+#define XQ_SLICES 128
+struct XqState { // per listed query
+    unsigned int prefix, mask;
+    int rank;
+    int less;
+    double sum;
+};
+__global__ void k_xq_init(XqState *__restrict__ st, int count, int mean_k, int n) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    st[q].prefix = 0u;
+    st[q].mask = 0u;
+    st[q].rank = min(mean_k + 1, n);
+    st[q].less = 0;
+    st[q].sum = 0.0;
+}
+__global__ __launch_bounds__(256) void k_xq_hist(const float *__restrict__ xyz, const float4 *__restrict__ sxyz, int n,
+                                                  const unsigned int *__restrict__ list, int count,
+                                                  const XqState *__restrict__ st, int shift, int width, int *__restrict__ ghist) {
     __shared__ int hist[2048];
-    __shared__ unsigned int s_prefix;
-    __shared__ int s_rank;
-    __shared__ double s_sum[256];
-    __shared__ int s_less[256];
-    const int count = *redo_cnt;
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        const unsigned int orig = redo[item];
-        const float3 p = make_float3(xyz[3 * (size_t)orig], xyz[3 * (size_t)orig + 1], xyz[3 * (size_t)orig + 2]);
-        const int want = min(mean_k + 1, n);
-        if (threadIdx.x == 0) {
-            s_prefix = 0u;
-            s_rank = want; // rank (1-based) of the wanted element among those matching the prefix so far
+    const int per = (n + XQ_SLICES - 1) / XQ_SLICES, q0 = blockIdx.x * per, q1 = min(n, q0 + per);
+    for (int item = blockIdx.y; item < count; item += gridDim.y) { // uniform
+        const unsigned int orig = list[item];
+        const float px = xyz[3 * (size_t)orig], py = xyz[3 * (size_t)orig + 1], pz = xyz[3 * (size_t)orig + 2];
+        const unsigned int prefix = st[item].prefix, mask = st[item].mask;
+        for (int b = threadIdx.x; b < 2048; b += 256) hist[b] = 0;
+        __syncthreads();
+        for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+            const float4 o = sxyz[q];
+            const unsigned int u = __float_as_uint(fdist2(px, py, pz, o.x, o.y, o.z));
+            // the distances to one far query share a handful of bins: one LDS atomic per distinct bin of the wave
+            int bin = ((u & mask) == prefix) ? (int)((u >> shift) & ((1u << width) - 1u)) : -1;
+            while (__ballot(bin >= 0)) { // uniform
+                const unsigned long long act = __ballot(bin >= 0);
+                const int b0 = __shfl(bin, __ffsll((long long)act) - 1);
+                const unsigned long long same = __ballot(bin == b0);
+                if (((int)threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&hist[b0], __popcll(same));
+                if (bin == b0) bin = -1;
+            }
         }
         __syncthreads();
-        const int shifts[3] = {20, 9, 0}, widths[3] = {11, 11, 9};
-        unsigned int mask = 0u;
-        for (int pass = 0; pass < 3; pass++) {
-            for (int b = threadIdx.x; b < 2048; b += 256) hist[b] = 0;
-            __syncthreads();
-            const unsigned int prefix = s_prefix;
-            for (int q = threadIdx.x; q < n; q += 256) {
-                const float4 o = sxyz[q];
-                const unsigned int u = __float_as_uint(fdist2(p.x, p.y, p.z, o.x, o.y, o.z));
-                if ((u & mask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & ((1u << widths[pass]) - 1u)], 1);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int rank = s_rank, b = 0;
-                for (; b < (1 << widths[pass]) - 1; b++) {
-                    if (hist[b] >= rank) break;
-                    rank -= hist[b];
-                }
-                s_rank = rank;
-                s_prefix = prefix | ((unsigned int)b << shifts[pass]);
-            }
-            mask |= ((1u << widths[pass]) - 1u) << shifts[pass];
-            __syncthreads();
+        for (int b = threadIdx.x; b < (1 << width); b += 256)
+            if (hist[b]) atomicAdd(&ghist[(size_t)item * 2048 + b], hist[b]);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(64) void k_xq_pick(XqState *__restrict__ st, int count, int shift, int width,
+                                                 int *__restrict__ ghist) {
+    const int item = blockIdx.x;
+    if (item >= count) return;
+    int *h = ghist + (size_t)item * 2048;
+    if (threadIdx.x == 0) {
+        int rank = st[item].rank, b = 0;
+        for (; b < (1 << width) - 1; b++) {
+            if (h[b] >= rank) break;
+            rank -= h[b];
         }
-        const float tau = __uint_as_float(s_prefix);
+        st[item].rank = rank;
+        st[item].prefix |= (unsigned int)b << shift;
+        st[item].mask |= ((1u << width) - 1u) << shift;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 2048; b += 64) h[b] = 0; // ready for the next pass
+}
+__global__ __launch_bounds__(256) void k_xq_sum(const float *__restrict__ xyz, const float4 *__restrict__ sxyz, int n,
+                                                 const unsigned int *__restrict__ list, int count,
+                                                 XqState *__restrict__ st) {
+    __shared__ double s_sum[4];
+    __shared__ int s_less[4];
+    const int per = (n + XQ_SLICES - 1) / XQ_SLICES, q0 = blockIdx.x * per, q1 = min(n, q0 + per);
+    for (int item = blockIdx.y; item < count; item += gridDim.y) {
+        const unsigned int orig = list[item];
+        const float px = xyz[3 * (size_t)orig], py = xyz[3 * (size_t)orig + 1], pz = xyz[3 * (size_t)orig + 2];
+        const float tau = __uint_as_float(st[item].prefix);
         double sum = 0.0;
         int less = 0;
-        for (int q = threadIdx.x; q < n; q += 256) {
+        for (int q = q0 + threadIdx.x; q < q1; q += 256) {
             const float4 o = sxyz[q];
-            const float d2 = fdist2(p.x, p.y, p.z, o.x, o.y, o.z);
+            const float d2 = fdist2(px, py, pz, o.x, o.y, o.z);
             if (d2 < tau) {
                 sum += (double)sqrtf(d2);
                 less++;
             }
         }
-        s_sum[threadIdx.x] = sum;
-        s_less[threadIdx.x] = less;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-                s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
-                s_less[threadIdx.x] += s_less[threadIdx.x + o];
-            }
-            __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_xor(sum, o);
+            less += __shfl_xor(less, o);
         }
-        if (threadIdx.x == 0)
-            dist_orig[orig] = (float)((s_sum[0] + (double)(want - s_less[0]) * (double)sqrtf(tau)) / mean_k);
+        if ((threadIdx.x & 63) == 0) {
+            s_sum[threadIdx.x >> 6] = sum;
+            s_less[threadIdx.x >> 6] = less;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int l = s_less[0] + s_less[1] + s_less[2] + s_less[3];
+            if (l) { // at most k values are below tau over ALL slices: the double sum is exact, any order
+                atomicAdd(&st[item].sum, (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+                atomicAdd(&st[item].less, l);
+            }
+        }
         __syncthreads();
     }
+}
+__global__ void k_xq_finish(const XqState *__restrict__ st, const unsigned int *__restrict__ list, int count, int mean_k,
+                            int n, float *__restrict__ dist_orig) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    const int want = min(mean_k + 1, n);
+    const float tau = __uint_as_float(st[q].prefix);
+    dist_orig[list[q]] = (float)((st[q].sum + (double)(want - st[q].less) * (double)sqrtf(tau)) / mean_k);
+}
+
+// ---- sum and sum of squares of the per-point distances as PCL forms them (a sequential loop adding floats to doubles,
+// `sq_sum += d * d` with the product in float).  A parallel reduction gives the same bits whenever NO addition rounds:
+// every value is a multiple of 2^q (q = the lowest set bit over all values) and the total is below 2^(q + 53), so every
+// partial sum, in any order, is representable.  The kernel returns the sums and the two q's; the host checks the
+// condition and falls back to the sequential loop otherwise (never on the test or bench clouds).
+__device__ __forceinline__ int low_bit_exp(float v) { // exponent of the lowest set bit of a finite float, INT_MAX for 0
+    const unsigned int u = __float_as_uint(v) & 0x7fffffffu;
+    if (u == 0u) return 0x7fffffff;
+    const int e = (int)(u >> 23);
+    const unsigned int m = u & 0x7fffffu;
+    if (e == 0) return -149 + (__ffs((int)m) - 1);           // subnormal
+    return (e - 150) + (m ? __ffs((int)m) - 1 : 23);
+}
+struct DistStats {
+    double sum, sq_sum;
+    int q_sum, q_sq;
+    int bad; // a negative or non-finite distance (cannot happen; makes the host take the sequential path)
+};
+__global__ __launch_bounds__(256) void k_dist_stats(const float *__restrict__ dist, int64_t n, DistStats *__restrict__ out) {
+    double s = 0.0, s2 = 0.0;
+    int q1 = 0x7fffffff, q2 = 0x7fffffff, bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = dist[i];
+        const float dd = __fmul_rn(d, d); // float * float, as in PCL
+        bad |= !(d >= 0.0f) || !isfinite(dd);
+        s += (double)d;
+        s2 += (double)dd;
+        q1 = min(q1, low_bit_exp(d));
+        q2 = min(q2, low_bit_exp(dd));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        s2 += __shfl_xor(s2, o);
+        q1 = min(q1, __shfl_xor(q1, o));
+        q2 = min(q2, __shfl_xor(q2, o));
+        bad |= __shfl_xor(bad, o);
+    }
+    __shared__ double s_d[4][2];
+    __shared__ int s_i[4][3];
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        s_d[w][0] = s, s_d[w][1] = s2;
+        s_i[w][0] = q1, s_i[w][1] = q2, s_i[w][2] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // one set of atomics per workgroup; exact sums are order-free (see above)
+        atomicAdd(&out->sum, (s_d[0][0] + s_d[1][0]) + (s_d[2][0] + s_d[3][0]));
+        atomicAdd(&out->sq_sum, (s_d[0][1] + s_d[1][1]) + (s_d[2][1] + s_d[3][1]));
+        atomicMin(&out->q_sum, min(min(s_i[0][0], s_i[1][0]), min(s_i[2][0], s_i[3][0])));
+        atomicMin(&out->q_sq, min(min(s_i[0][1], s_i[1][1]), min(s_i[2][1], s_i[3][1])));
+        if (s_i[0][2] | s_i[1][2] | s_i[2][2] | s_i[3][2]) atomicOr(&out->bad, 1);
+    }
+}
+
+// every `step`-th point into a small buffer (the robust extent's sample)
+__global__ void k_sample_points(const float *__restrict__ xyz, int64_t step, int S, float *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const size_t i = (size_t)s * (size_t)step;
+    out[3 * s] = xyz[3 * i];
+    out[3 * s + 1] = xyz[3 * i + 1];
+    out[3 * s + 2] = xyz[3 * i + 2];
 }
 
 __global__ void k_keep_flags(const float *__restrict__ dist, int64_t n, double thr, unsigned int *__restrict__ flag) {
@@ -455,52 +652,87 @@ __global__ void k_bbox(const float *__restrict__ xyz, int64_t n, unsigned int *_
             hi[a] = max(hi[a], o);
         }
     }
+    // one set of atomics per WORKGROUP (same-address atomics retire at ~88 per microsecond: per wave they were the kernel)
+    __shared__ unsigned int s_r[4][7];
     for (int o = 32; o > 0; o >>= 1) nfin += (unsigned int)__shfl_xor((int)nfin, o);
-    if ((threadIdx.x & 63) == 0 && nfin) atomicAdd(&bb[6], nfin);
-    for (int a = 0; a < 3; a++) {
+    for (int a = 0; a < 3; a++)
         for (int o = 32; o > 0; o >>= 1) {
             lo[a] = min(lo[a], (unsigned int)__shfl_xor((int)lo[a], o));
             hi[a] = max(hi[a], (unsigned int)__shfl_xor((int)hi[a], o));
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&bb[a], lo[a]);
-            atomicMax(&bb[3 + a], hi[a]);
-        }
+    if ((threadIdx.x & 63) == 0) {
+        unsigned int *r = s_r[threadIdx.x >> 6];
+        r[0] = lo[0], r[1] = lo[1], r[2] = lo[2], r[3] = hi[0], r[4] = hi[1], r[5] = hi[2], r[6] = nfin;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int a = threadIdx.x;
+        unsigned int v = s_r[0][a];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) v = a < 3 ? min(v, s_r[w][a]) : (a < 6 ? max(v, s_r[w][a]) : v + s_r[w][a]);
+        if (a < 3) atomicMin(&bb[a], v);
+        else if (a < 6) atomicMax(&bb[a], v);
+        else if (v) atomicAdd(&bb[6], v);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-namespace {
-struct DevBuf {
-    void *p = nullptr;
-    DevBuf() = default;
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) {
-            if (p) (void)hipFree(p);
-            p = o.p;
-            o.p = nullptr;
-        }
-        return *this;
-    }
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
+// Grow-only device arena owned by the context: one hipMalloc sized for the cloud at hand instead of ~25 hipMalloc /
+// hipFree pairs per call (hipFree synchronises the device).  Stack discipline: mark() / release().
+struct FilterArena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    void *h_pinned = nullptr; // small pinned staging block (samples, counters, statistics)
+    bool failed = false;
     template <typename T>
     T *get(size_t n) {
-        if (hipMalloc(&p, n * sizeof(T) + 64) != hipSuccess) p = nullptr;
-        return (T *)p;
+        const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) {
+            failed = true;
+            return nullptr;
+        }
+        T *p = (T *)(base + off);
+        off += bytes;
+        return p;
     }
 };
+FilterArena *filter_arena_create() { return new FilterArena(); }
+void filter_arena_destroy(FilterArena *a) {
+    if (!a) return;
+    if (a->base) (void)hipFree(a->base);
+    if (a->h_pinned) (void)hipHostFree(a->h_pinned);
+    delete a;
+}
+#define FA_PINNED_BYTES (3 * 8192 * sizeof(float) + 1024)
+// room for `bytes` from offset 0 (contents are scratch: nothing survives a call)
+int filter_arena_reserve(FilterArena *a, size_t bytes) {
+    if (!a->h_pinned && hipHostMalloc(&a->h_pinned, FA_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) return RSM_E_NOMEM;
+    a->off = 0;
+    a->failed = false;
+    if (bytes <= a->cap) return RSM_OK;
+    if (a->base) (void)hipFree(a->base);
+    a->base = nullptr;
+    a->cap = 0;
+    if (hipMalloc((void **)&a->base, bytes) != hipSuccess) return RSM_E_NOMEM;
+    a->cap = bytes;
+    return RSM_OK;
+}
+size_t filter_arena_bytes(int64_t n) { // upper bound of one filter call's scratch for an n-point cloud (callers add their own buffers)
+    return (size_t)n * 112 + ((size_t)FILTER_MAX_CELLS + 64) * sizeof(int2) + ((size_t)64 << 20);
+}
+void *filter_arena_alloc(FilterArena *a, size_t bytes) { return a->get<char>(bytes); }
 
+namespace {
 // robust grid: extents from the 1 % .. 99 % quantiles of a sample (far outliers must not set the cell size)
-bool sample_extent(const float *d_xyz, int64_t n, hipStream_t st, float lo[3], float hi[3], float full_lo[3], float full_hi[3]) {
+bool sample_extent(FilterArena *A, const float *d_xyz, int64_t n, hipStream_t st, float lo[3], float hi[3]) {
     const int S = (int)std::min<int64_t>(n, 8192);
-    std::vector<float> h((size_t)3 * S);
-    const int64_t step = n / S;
-    for (int s = 0; s < S; s++)
-        if (hipMemcpyAsync(&h[3 * (size_t)s], d_xyz + 3 * (size_t)(s * step), 3 * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
-    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    const size_t mark = A->off;
+    float *d_s = A->get<float>((size_t)3 * S);
+    float *h = (float *)A->h_pinned;
+    if (!d_s) return false;
+    hipLaunchKernelGGL(k_sample_points, dim3((S + 255) / 256), dim3(256), 0, st, d_xyz, n / S, S, d_s);
+    if (hipMemcpyAsync(h, d_s, sizeof(float) * 3 * (size_t)S, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return false;
+    A->off = mark;
     for (int a = 0; a < 3; a++) {
         std::vector<float> v;
         for (int s = 0; s < S; s++)
@@ -509,124 +741,223 @@ bool sample_extent(const float *d_xyz, int64_t n, hipStream_t st, float lo[3], f
         std::sort(v.begin(), v.end());
         lo[a] = v[(size_t)(0.01 * (v.size() - 1))];
         hi[a] = v[(size_t)(0.99 * (v.size() - 1))];
-        full_lo[a] = v.front();
-        full_hi[a] = v.back();
     }
     return true;
 }
 } // namespace
 
 struct FilterGridDev {
-    DevBuf b_keys, b_keys2, b_vals, b_vals2, b_sxyz, b_tmp;
     unsigned long long *keys = nullptr;
     unsigned int *vals = nullptr; // original index of every sorted point
     float4 *sxyz = nullptr;
+    int2 *table = nullptr; // (first, one past last) sorted index per cell (table_kind 1) or per (y, z) row of cells (2)
+    int table_kind = 0;    // 0: none, binary search on all keys
     FGrid g{};
-    FilterGridDev() = default;
-    FilterGridDev &operator=(FilterGridDev &&o) noexcept = default;
 };
 
-// sorts the n points of d_xyz by the key of a grid with cell edge h covering their bounding box
-static int build_grid(const float *d_xyz, int64_t n, float h, const float bb_lo[3], const float bb_hi[3], hipStream_t st, FilterGridDev &G) {
-    G.g.ox = bb_lo[0];
-    G.g.oy = bb_lo[1];
-    G.g.oz = bb_lo[2];
+// sorts the n points of d_xyz by the key of a grid with cell edge h over the box [bb_lo, bb_hi] (points outside fall
+// into the border cells: clamping is non-expansive, so two points within h of each other still sit in adjacent cells);
+// nv = finite points (they sort first).  Arena space stays allocated until the caller releases its mark.
+static int build_grid(FilterArena *A, const float *d_xyz, int64_t n, int64_t nv, float h, const float bb_lo[3], const float bb_hi[3],
+                      hipStream_t st, FilterGridDev &G) {
     G.g.inv_h = 1.0f / h;
     auto dim = [&](int a) { return (int)std::min<double>(1 << 20, std::max<double>(1.0, floor((double)(bb_hi[a] - bb_lo[a]) / h) + 1.0)); };
-    G.g.nx = dim(0);
-    G.g.ny = dim(1);
-    G.g.nz = dim(2);
-    unsigned long long *k1 = G.b_keys.get<unsigned long long>((size_t)n), *k2 = G.b_keys2.get<unsigned long long>((size_t)n);
-    unsigned int *v1 = G.b_vals.get<unsigned int>((size_t)n), *v2 = G.b_vals2.get<unsigned int>((size_t)n);
-    G.sxyz = G.b_sxyz.get<float4>((size_t)n);
+    int ax[3] = {0, 1, 2};
+    std::sort(ax, ax + 3, [&](int a, int b) { return dim(a) != dim(b) ? dim(a) > dim(b) : a < b; }); // most cells first = fastest key digit
+    G.g.p0 = ax[0], G.g.p1 = ax[1], G.g.p2 = ax[2];
+    G.g.ox = bb_lo[ax[0]], G.g.oy = bb_lo[ax[1]], G.g.oz = bb_lo[ax[2]];
+    G.g.nx = dim(ax[0]), G.g.ny = dim(ax[1]), G.g.nz = dim(ax[2]);
+    unsigned long long *k1 = A->get<unsigned long long>((size_t)n), *k2 = A->get<unsigned long long>((size_t)n);
+    unsigned int *v1 = A->get<unsigned int>((size_t)n), *v2 = A->get<unsigned int>((size_t)n);
+    G.sxyz = A->get<float4>((size_t)n);
     if (!k1 || !k2 || !v1 || !v2 || !G.sxyz) return RSM_E_NOMEM;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_cell_keys, dim3(blocks), dim3(256), 0, st, d_xyz, n, G.g, k1, v1);
+    const double ncell = (double)G.g.nx * G.g.ny * G.g.nz;
+    int key_bits = 1;
+    while (key_bits < 64 && ncell > (double)(1ull << key_bits)) key_bits++;
+    key_bits = 64; // non-finite points carry the key ~0: all bits take part
     size_t tmp_bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, k1, k2, v1, v2, (size_t)n, 0, 64, st) != hipSuccess) return RSM_E_HIP;
-    void *tmp = G.b_tmp.get<uint8_t>(tmp_bytes);
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, k1, k2, v1, v2, (size_t)n, 0, key_bits, st) != hipSuccess) return RSM_E_HIP;
+    void *tmp = A->get<uint8_t>(tmp_bytes);
     if (!tmp) return RSM_E_NOMEM;
-    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, k1, k2, v1, v2, (size_t)n, 0, 64, st) != hipSuccess) return RSM_E_HIP;
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, k1, k2, v1, v2, (size_t)n, 0, key_bits, st) != hipSuccess) return RSM_E_HIP;
     hipLaunchKernelGGL(k_gather_sorted, dim3(blocks), dim3(256), 0, st, d_xyz, v2, n, G.sxyz);
     G.keys = k2;
     G.vals = v2;
+    G.table = nullptr;
+    G.table_kind = 0;
+    const double nrow = (double)G.g.ny * G.g.nz;
+    if (nv > 0 && (ncell <= (double)FILTER_MAX_CELLS || nrow <= (double)FILTER_MAX_CELLS)) {
+        G.table_kind = ncell <= (double)FILTER_MAX_CELLS ? 1 : 2;
+        const size_t nc = (size_t)(G.table_kind == 1 ? ncell : nrow);
+        G.table = A->get<int2>(nc);
+        if (!G.table) return RSM_E_NOMEM;
+        if (hipMemsetAsync(G.table, 0, sizeof(int2) * nc, st) != hipSuccess) return RSM_E_HIP;
+        hipLaunchKernelGGL(k_cell_table, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, k2, (int)nv,
+                           (unsigned long long)(G.table_kind == 1 ? 1 : G.g.nx), G.table);
+    }
     return RSM_OK;
 }
 
+__global__ void k_compact_list(const unsigned int *__restrict__ src, const unsigned int *__restrict__ flag, const unsigned int *__restrict__ pos,
+                               int n, unsigned int *__restrict__ dst, int *__restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) dst[pos[i]] = src[i];
+    if (i == n - 1) *count = (int)(pos[i] + flag[i]);
+}
+
+static void launch_knn(const float *d_xyz, const FilterGridDev &G, int nv, float h, int mean_k, const unsigned int *queries, int nq,
+                       float *d_dist, unsigned int *d_cnt /* undecided flags */, hipStream_t st) {
+    const dim3 grid((unsigned)((nq + 3) / 4));
+    if (G.table_kind == 1)
+        hipLaunchKernelGGL(k_sor_knn<1>, grid, dim3(256), 0, st, d_xyz, G.sxyz, G.keys, G.table, nv, G.g, h * h, mean_k, queries, nq, d_dist, d_cnt);
+    else if (G.table_kind == 2)
+        hipLaunchKernelGGL(k_sor_knn<2>, grid, dim3(256), 0, st, d_xyz, G.sxyz, G.keys, G.table, nv, G.g, h * h, mean_k, queries, nq, d_dist, d_cnt);
+    else
+        hipLaunchKernelGGL(k_sor_knn<0>, grid, dim3(256), 0, st, d_xyz, G.sxyz, G.keys, G.table, nv, G.g, h * h, mean_k, queries, nq, d_dist, d_cnt);
+}
+
 // d_xyz: n x 3 float (device).  Outputs (device): kept_index [n] (first *n_kept valid), fxyz [3n], normals [n] float4.
-int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius, const float cam_center[3],
-                        int32_t *d_kept_index, float *d_fxyz, float4 *d_normals, int64_t *n_kept, double stats[4], hipStream_t st) {
+// A: reserved by the caller (filter_arena_reserve) with at least filter_arena_bytes(n) free.
+int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius,
+                        const float cam_center[3], int32_t *d_kept_index, float *d_fxyz, float4 *d_normals, int64_t *n_kept,
+                        double stats[4], hipStream_t st) {
     *n_kept = 0;
     if (n <= 0) return RSM_OK;
-    if (n >= (1ll << 31) || mean_k < 1) return RSM_E_INVALID;
+    if (n >= (1ll << 31) || mean_k < 1 || !A) return RSM_E_INVALID;
     float lo[3], hi[3], flo[3], fhi[3];
-    if (!sample_extent(d_xyz, n, st, lo, hi, flo, fhi)) return RSM_E_HIP;
-    // exact bounding box (the sample's extremes are not the cloud's)
-    DevBuf b_dist, b_redo, b_cnt, b_flag, b_pos, b_tmp, b_bb;
-    unsigned int *d_bb = b_bb.get<unsigned int>(8);
-    if (!d_bb) return RSM_E_NOMEM;
-    int64_t nv = 0; // finite points: only they take part in the searches (PCL: the k-d tree skips the others)
+    if (!sample_extent(A, d_xyz, n, st, lo, hi)) return RSM_E_HIP;
+    // exact bounding box (the sample's extremes are not the cloud's) and the number of finite points: only they take
+    // part in the searches (PCL: the k-d tree skips the others)
+    unsigned int *d_bb = A->get<unsigned int>(8);
+    int *d_cnt = A->get<int>(4);
+    DistStats *d_stats = A->get<DistStats>(1);
+    float *d_dist = A->get<float>((size_t)n);
+    unsigned int *d_redo = A->get<unsigned int>((size_t)n), *d_redo2 = A->get<unsigned int>((size_t)n);
+    unsigned int *d_flag = A->get<unsigned int>((size_t)n), *d_pos = A->get<unsigned int>((size_t)n);
+    if (A->failed) return RSM_E_NOMEM;
+    unsigned int *h_bb = (unsigned int *)((char *)A->h_pinned + 3 * 8192 * sizeof(float));
+    int *h_cnt = (int *)(h_bb + 8);
+    DistStats *h_stats = (DistStats *)(h_cnt + 4);
+    int64_t nv = 0;
     {
         const unsigned int init[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
-        unsigned int bb[7];
-        if (hipMemcpyAsync(d_bb, init, sizeof init, hipMemcpyHostToDevice, st) != hipSuccess) return RSM_E_HIP;
-        hipLaunchKernelGGL(k_bbox, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, st, d_xyz, n, d_bb);
-        if (hipMemcpyAsync(bb, d_bb, sizeof bb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
-        nv = bb[6];
+        memcpy(h_bb, init, sizeof init);
+        if (hipMemcpyAsync(d_bb, h_bb, sizeof init, hipMemcpyHostToDevice, st) != hipSuccess) return RSM_E_HIP;
+        hipLaunchKernelGGL(k_bbox, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st, d_xyz, n, d_bb);
+        if (hipMemcpyAsync(h_bb, d_bb, sizeof init, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
+        nv = h_bb[6];
         for (int a = 0; a < 3; a++) {
-            flo[a] = nv ? ord_to_float(bb[a]) : 0.0f;
-            fhi[a] = nv ? ord_to_float(bb[3 + a]) : 0.0f;
+            flo[a] = nv ? ord_to_float(h_bb[a]) : 0.0f;
+            fhi[a] = nv ? ord_to_float(h_bb[3 + a]) : 0.0f;
         }
     }
     // first cell edge: ~sqrt(k + 1) point spacings of a surface patch whose area is the product of the two largest
     // robust extents; queries that cannot be decided inside their 27 cells (fewer than k + 1 points within h: thick or
-    // sparse parts of the cloud, patch corners, isolated points) are retried on a grid with twice the edge, the few
-    // that remain after KNN_LEVELS grids are searched exhaustively
+    // sparse parts of the cloud, patch corners, isolated points) are retried on a grid with twice the edge; what is left
+    // after KNN_LEVELS grids (or once only a handful remain) is searched against all points by the whole chip
     double e[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
     std::sort(e, e + 3);
     const double area = std::max(e[2] * e[1], 1e-12), spacing = sqrt(area / (0.98 * 0.98 * 0.98 * (double)std::max<int64_t>(nv, 1)));
     float h = (float)(spacing * sqrt((double)(mean_k + 1)));
     if (!(h > 0.0f) || !std::isfinite(h)) h = 1.0f;
-    float *d_dist = b_dist.get<float>((size_t)n);
-    DevBuf b_redo2;
-    unsigned int *d_redo = b_redo.get<unsigned int>((size_t)n), *d_redo2 = b_redo2.get<unsigned int>((size_t)n);
-    int *d_cnt = b_cnt.get<int>(4);
-    if (!d_dist || !d_redo || !d_redo2 || !d_cnt) return RSM_E_NOMEM;
+    // the grid box: the robust extent grown by a few cells, inside the exact bounding box (far outliers are clamped
+    // into the border cells instead of blowing up the cell count)
+    float glo[3], ghi[3];
+    for (int a = 0; a < 3; a++) {
+        glo[a] = std::max(flo[a], lo[a] - 4.0f * h);
+        ghi[a] = std::min(fhi[a], hi[a] + 4.0f * h);
+        if (!(ghi[a] >= glo[a])) ghi[a] = glo[a];
+    }
+    // One cell edge does not fit a whole cloud: a perspective depth map is 25 times denser (per unit of space) in its near
+    // part than in its far part (C2: 1.25 vs 6 units between neighbours), and the surface estimate above is off for a deep
+    // or thick one.  The search therefore runs over a ladder of grids from fine to coarse, h doubling: a query is decided
+    // at the first level whose 27 cells hold its k + 1 nearest (there its candidates number a few hundred whatever the
+    // local density); an undecided attempt costs one table lookup and one count over the few candidates a too-fine grid
+    // offers.  Every level re-sorts the points (0.65 ms for 5.5 M): cheap next to one query pass with a wrong h
+    // (a single level at the surface estimate ran the near part's queries over ~50 000 candidates each: 390 ms).
+    // The ladder starts two octaves below the surface estimate (on C2 the level below that decides nothing).
+    h *= 0.25f;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    const int KNN_LEVELS = 5;
+    const int KNN_LEVELS = 12;
     if (hipMemsetAsync(d_dist, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return RSM_E_HIP; // non-finite points: distance 0, as PCL
     int nq = (int)nv, redo_n = 0;
     const unsigned int *queries = nullptr;
     int s = RSM_OK;
-    {
-        FilterGridDev G; // the last grid also serves the exhaustive search (any ordering of the points does)
-        for (int level = 0; level < KNN_LEVELS && nq > 0; level++, h *= 2.0f) {
-            G = FilterGridDev();
-            s = build_grid(d_xyz, n, h, flo, fhi, st, G);
-            if (s != RSM_OK) return s;
-            if (level == 0) queries = G.vals; // every point, in grid order (coherent waves)
-            if (hipMemsetAsync(d_cnt, 0, sizeof(int) * 4, st) != hipSuccess) return RSM_E_HIP;
-            unsigned int *out_list = (level & 1) ? d_redo2 : d_redo;
-            hipLaunchKernelGGL(k_sor_knn, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_xyz, G.sxyz, G.keys, (int)nv, G.g, h * h, mean_k,
-                               queries, nq, d_dist, out_list, d_cnt);
-            if (hipMemcpyAsync(&redo_n, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-                return RSM_E_HIP;
-            queries = out_list;
-            nq = redo_n;
-            if (nq <= 64) break; // cheaper to finish exhaustively than to sort again
+    const size_t mark = A->off;
+    FilterGridDev G;
+    for (int level = 0; level < KNN_LEVELS && nq > 0; level++, h *= 2.0f) {
+        A->off = mark; // the previous level's grid is done (its kernels are ordered before this level's on the stream)
+        s = build_grid(A, d_xyz, n, nv, h, glo, ghi, st, G);
+        if (s != RSM_OK) return s;
+        if (level == 0) queries = G.vals; // every point, in grid order (coherent waves)
+        unsigned int *out_list = (level & 1) ? d_redo2 : d_redo;
+        launch_knn(d_xyz, G, (int)nv, h, mean_k, queries, nq, d_dist, d_flag, st);
+        { // undecided queries -> the next level's list, in order
+            size_t tb = 0;
+            if (rocprim::exclusive_scan(nullptr, tb, d_flag, d_pos, 0u, (size_t)nq, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
+            void *tp = A->get<uint8_t>(tb);
+            if (!tp) return RSM_E_NOMEM;
+            if (rocprim::exclusive_scan(tp, tb, d_flag, d_pos, 0u, (size_t)nq, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
+            hipLaunchKernelGGL(k_compact_list, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, queries, d_flag, d_pos, nq, out_list, d_cnt);
         }
-        if (nq > 0) hipLaunchKernelGGL(k_sor_knn_all, dim3((unsigned)std::min(nq, 4096)), dim3(256), 0, st, d_xyz, G.sxyz, (int)nv, mean_k, d_dist, queries, d_cnt);
-        if (hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
+        if (hipMemcpyAsync(h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return RSM_E_HIP;
+        redo_n = h_cnt[0];
+        queries = out_list;
+        nq = redo_n;
+        if (nq <= 256) break; // cheaper to finish against all points than to sort again
     }
     redo_n = nq;
-    // mean / stddev exactly as PCL: a sequential host loop over the per-point distances in point order
-    std::vector<float> hd((size_t)n);
-    if (hipMemcpyAsync(hd.data(), d_dist, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return RSM_E_HIP;
+    if (nq > 0) { // against all points; the last grid's sorted copy is still in the arena (any ordering of the points serves)
+        const int XQ_BATCH = 2048; // queries per round (their histograms: 16 MB)
+        XqState *d_xq = A->get<XqState>((size_t)XQ_BATCH);
+        int *d_hist = A->get<int>((size_t)XQ_BATCH * 2048);
+        if (!d_xq || !d_hist) return RSM_E_NOMEM;
+        if (hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)XQ_BATCH * 2048, st) != hipSuccess) return RSM_E_HIP;
+        const int shifts[3] = {20, 9, 0}, widths[3] = {11, 11, 9};
+        for (int q0 = 0; q0 < nq; q0 += XQ_BATCH) {
+            const int cnt = std::min(XQ_BATCH, nq - q0), qy = std::min(cnt, 1024);
+            const unsigned int *list = queries + q0;
+            hipLaunchKernelGGL(k_xq_init, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_xq, cnt, mean_k, (int)nv);
+            for (int pass = 0; pass < 3; pass++) {
+                hipLaunchKernelGGL(k_xq_hist, dim3(XQ_SLICES, (unsigned)qy), dim3(256), 0, st, d_xyz, G.sxyz, (int)nv, list, cnt, d_xq, shifts[pass],
+                                   widths[pass], d_hist);
+                hipLaunchKernelGGL(k_xq_pick, dim3((unsigned)cnt), dim3(64), 0, st, d_xq, cnt, shifts[pass], widths[pass], d_hist);
+            }
+            hipLaunchKernelGGL(k_xq_sum, dim3(XQ_SLICES, (unsigned)qy), dim3(256), 0, st, d_xyz, G.sxyz, (int)nv, list, cnt, d_xq);
+            hipLaunchKernelGGL(k_xq_finish, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_xq, list, cnt, mean_k, (int)nv, d_dist);
+        }
+    }
+    A->off = mark;
+    // mean / stddev exactly as PCL forms them (a sequential loop over the per-point distances in point order): on the
+    // device when no addition can round (k_dist_stats), else on the host
     double sum = 0.0, sq_sum = 0.0;
-    for (int64_t i = 0; i < n; i++) {
-        sum += hd[(size_t)i];
-        sq_sum += hd[(size_t)i] * hd[(size_t)i]; // float * float, as in PCL
+    {
+        DistStats init{0.0, 0.0, 0x7fffffff, 0x7fffffff, 0};
+        *h_stats = init;
+        if (hipMemcpyAsync(d_stats, h_stats, sizeof init, hipMemcpyHostToDevice, st) != hipSuccess) return RSM_E_HIP;
+        hipLaunchKernelGGL(k_dist_stats, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st, d_dist, n, d_stats);
+        if (hipMemcpyAsync(h_stats, d_stats, sizeof init, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return RSM_E_HIP;
+        auto exact = [](double total, int q) { // every partial sum is a multiple of 2^q below 2^(q + 53)
+            if (q == 0x7fffffff) return true;   // all zero
+            return total * (1.0 + 1e-9) < ldexp(1.0, q + 53);
+        };
+        if (!h_stats->bad && exact(h_stats->sum, h_stats->q_sum) && exact(h_stats->sq_sum, h_stats->q_sq)) {
+            sum = h_stats->sum;
+            sq_sum = h_stats->sq_sum;
+        } else {
+            std::vector<float> hd((size_t)n);
+            if (hipMemcpyAsync(hd.data(), d_dist, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                return RSM_E_HIP;
+            for (int64_t i = 0; i < n; i++) {
+                sum += hd[(size_t)i];
+                sq_sum += hd[(size_t)i] * hd[(size_t)i]; // float * float, as in PCL
+            }
+        }
     }
     const double mean = sum / (double)nv; // valid_distances
     const double variance = (sq_sum - sum * sum / (double)nv) / ((double)nv - 1);
@@ -637,34 +968,34 @@ int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mu
         stats[2] = thr;
         stats[3] = (double)redo_n;
     }
-    unsigned int *d_flag = b_flag.get<unsigned int>((size_t)n), *d_pos = b_pos.get<unsigned int>((size_t)n);
-    if (!d_flag || !d_pos) return RSM_E_NOMEM;
     hipLaunchKernelGGL(k_keep_flags, dim3(blocks), dim3(256), 0, st, d_dist, n, thr, d_flag);
     size_t tb = 0;
     if (rocprim::exclusive_scan(nullptr, tb, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
-    void *tp = b_tmp.get<uint8_t>(tb);
+    void *tp = A->get<uint8_t>(tb);
     if (!tp) return RSM_E_NOMEM;
     if (rocprim::exclusive_scan(tp, tb, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
     hipLaunchKernelGGL(k_compact_kept, dim3(blocks), dim3(256), 0, st, d_xyz, d_flag, d_pos, n, d_fxyz, d_kept_index);
-    unsigned int last_pos = 0, last_flag = 0;
-    if (hipMemcpyAsync(&last_pos, d_pos + (n - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(&last_flag, d_flag + (n - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    unsigned int *h_last = (unsigned int *)h_cnt;
+    if (hipMemcpyAsync(&h_last[0], d_pos + (n - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&h_last[1], d_flag + (n - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return RSM_E_HIP;
-    const int64_t m = (int64_t)last_pos + last_flag;
+    const int64_t m = (int64_t)h_last[0] + h_last[1];
     *n_kept = m;
+    A->off = mark;
     if (m == 0 || !d_normals) return RSM_OK;
     // normals of the filtered cloud: grid with cell edge = search radius; the non-finite points (all kept: distance 0)
     // sort behind the finite ones and keep the NaN normal the buffer is filled with
     FilterGridDev G2;
-    s = build_grid(d_fxyz, m, (float)normal_radius, flo, fhi, st, G2);
+    const int64_t mv = m - (n - nv);
+    s = build_grid(A, d_fxyz, m, 0 /* no table: the normals walk their ranges by binary search */, (float)normal_radius, flo, fhi, st, G2);
     if (s != RSM_OK) return s;
     const float r2 = (float)(normal_radius * normal_radius);
-    const int64_t mv = m - (n - nv);
     if (hipMemsetD32Async((hipDeviceptr_t)d_normals, 0x7fc00000, (size_t)4 * m, st) != hipSuccess) return RSM_E_HIP;
     if (mv > 0)
         hipLaunchKernelGGL(k_cloud_normals, dim3((unsigned)((mv + 255) / 256)), dim3(256), 0, st, G2.sxyz, G2.keys, (int)mv, G2.g, r2,
                            cam_center[0], cam_center[1], cam_center[2], d_normals);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return RSM_E_HIP;
+    A->off = mark;
     return RSM_OK;
 }
 

@@ -101,6 +101,7 @@ struct rsm_ctx {
     double *d_q = nullptr, *d_R = nullptr, *d_T = nullptr;
     double *xyz = nullptr;
     uint8_t *bgr = nullptr;
+    FilterArena *filt_arena = nullptr; // the cloud filter's scratch (created on first use, grows with the cloud)
 
     // results
     double *res_disp[2]{};
@@ -255,6 +256,7 @@ extern "C" void rsm_destroy(rsm_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_workspace(c);
+    filter_arena_destroy(c->filt_arena);
     for (auto &e : c->evpool) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -1526,6 +1528,20 @@ static int filter_params_ok(const rsm_filter_params *p) {
     return p && p->sor_mean_k >= 1 && p->sor_mean_k <= 100000 && p->normal_radius > 0.0 && p->sor_std_mul == p->sor_std_mul;
 }
 
+// the filter's buffers come from the context's arena: (re)sized for the cloud at hand, then the caller-visible ones first
+static int filter_buffers(rsm_ctx *c, int64_t n, bool want_normals, float **dx, int32_t **dk, float **df, float4 **dn) {
+    if (!c->filt_arena) c->filt_arena = filter_arena_create();
+    const size_t own = (size_t)n * (12 + 4 + 12 + 16) + 4096;
+    if (filter_arena_reserve(c->filt_arena, own + filter_arena_bytes(n)) != RSM_OK)
+        return set_err(c, RSM_E_NOMEM, "cloud filter: no device memory for %lld points", (long long)n);
+    *dx = (float *)filter_arena_alloc(c->filt_arena, sizeof(float) * 3 * (size_t)n);
+    *dk = (int32_t *)filter_arena_alloc(c->filt_arena, sizeof(int32_t) * (size_t)n);
+    *df = (float *)filter_arena_alloc(c->filt_arena, sizeof(float) * 3 * (size_t)n);
+    *dn = want_normals ? (float4 *)filter_arena_alloc(c->filt_arena, sizeof(float4) * (size_t)n) : nullptr;
+    if (!*dx || !*dk || !*df || (want_normals && !*dn)) return set_err(c, RSM_E_NOMEM, "cloud filter: arena too small");
+    return RSM_OK;
+}
+
 extern "C" int rsm_filter_cloud(rsm_ctx *c, const float *xyz, int64_t n, const rsm_filter_params *prm, int32_t *kept_index,
                                 float *normals, int64_t *n_kept, double *stats) {
     if (!c || n < 0 || (n > 0 && (!xyz || !kept_index)) || !n_kept || !filter_params_ok(prm)) return RSM_E_INVALID;
@@ -1533,13 +1549,14 @@ extern "C" int rsm_filter_cloud(rsm_ctx *c, const float *xyz, int64_t n, const r
     *n_kept = 0;
     if (n == 0) return RSM_OK;
     Tmp t(c);
-    float *dx = t.up(xyz, (size_t)3 * n);
-    int32_t *dk = t.alloc<int32_t>((size_t)n);
-    float *df = t.alloc<float>((size_t)3 * n);
-    float4 *dn = normals ? t.alloc<float4>((size_t)n) : nullptr;
-    if (!t.ok) return finish(c, t);
-    const int s = filter_cloud_device(dx, n, prm->sor_mean_k, prm->sor_std_mul, prm->normal_radius, prm->cam_center, dk, df, dn, n_kept,
-                                      stats, c->stream);
+    float *dx, *df;
+    int32_t *dk;
+    float4 *dn;
+    const int sb = filter_buffers(c, n, normals != nullptr, &dx, &dk, &df, &dn);
+    if (sb != RSM_OK) return sb;
+    HIPCHK(c, hipMemcpyAsync(dx, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    const int s = filter_cloud_device(c->filt_arena, dx, n, prm->sor_mean_k, prm->sor_std_mul, prm->normal_radius, prm->cam_center, dk, df, dn,
+                                      n_kept, stats, c->stream);
     if (s != RSM_OK) return set_err(c, s, "cloud filter failed");
     if (*n_kept > 0) {
         t.down(kept_index, (const int32_t *)dk, (size_t)*n_kept);
@@ -1557,14 +1574,14 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
     const int64_t n = c->n_points;
     if (n == 0) return RSM_OK;
     Tmp t(c);
-    float *dx = t.alloc<float>((size_t)3 * n);
-    int32_t *dk = t.alloc<int32_t>((size_t)n);
-    float *df = t.alloc<float>((size_t)3 * n);
-    float4 *dn = d_normals ? t.alloc<float4>((size_t)n) : nullptr;
-    if (!t.ok) return finish(c, t);
+    float *dx, *df;
+    int32_t *dk;
+    float4 *dn;
+    const int sb = filter_buffers(c, n, d_normals != nullptr, &dx, &dk, &df, &dn);
+    if (sb != RSM_OK) return sb;
     launch_f64_to_f32x3(c->xyz, n, dx, c->stream); // InsertPoint's cast, CCloudOptimization.cpp:61
     int64_t m = 0;
-    const int s = filter_cloud_device(dx, n, prm->sor_mean_k, prm->sor_std_mul, prm->normal_radius, prm->cam_center, dk, df, dn, &m, stats,
+    const int s = filter_cloud_device(c->filt_arena, dx, n, prm->sor_mean_k, prm->sor_std_mul, prm->normal_radius, prm->cam_center, dk, df, dn, &m, stats,
                                       c->stream);
     if (s != RSM_OK) return set_err(c, s, "cloud filter failed");
     if (m > max_points) return set_err(c, RSM_E_INVALID, "rsm_filter_last_cloud: %lld points survive, capacity %lld", (long long)m, (long long)max_points);

@@ -128,7 +128,15 @@ void launch_erode_gray(const uint8_t *src, int W, int H, int ksize, const int *d
                        uint8_t *dst, hipStream_t st_);
 
 // cloud filter (k_filter.hip): SOR + radius normals on a device cloud of n float xyz points
-int filter_cloud_device(const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius, const float cam_center[3],
-                        int32_t *d_kept_index, float *d_fxyz, float4 *d_normals, int64_t *n_kept, double stats[4], hipStream_t st);
+// FilterArena: grow-only device scratch owned by the context (one hipMalloc per cloud size instead of dozens per call)
+struct FilterArena;
+FilterArena *filter_arena_create();
+void filter_arena_destroy(FilterArena *a);
+size_t filter_arena_bytes(int64_t n);                      // scratch one filter call needs for n points
+int filter_arena_reserve(FilterArena *a, size_t bytes);    // makes room, rewinds the arena
+void *filter_arena_alloc(FilterArena *a, size_t bytes);    // caller buffers that live across the call (nullptr: full)
+int filter_cloud_device(FilterArena *a, const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius,
+                        const float cam_center[3], int32_t *d_kept_index, float *d_fxyz, float4 *d_normals, int64_t *n_kept,
+                        double stats[4], hipStream_t st);
 void launch_f64_to_f32x3(const double *src, int64_t n, float *dst, hipStream_t st);
 void launch_pack_filtered16(const double *xyz, const uint8_t *bgr, const int32_t *kept, int64_t m, void *dst16, hipStream_t st);
