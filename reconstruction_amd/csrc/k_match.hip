@@ -340,20 +340,13 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
         if (L > Rr) active = false;
     }
     const bool wide = active && (Rr - L + 1 > NCC_WIDE);
-    { // wave-aggregated append of the wide pixels to the worklist of k_ncc_wide
-        const unsigned long long mm = __ballot(wide);
-        if (mm) {
-            const int leader = __builtin_ctzll(mm);
-            int base = 0;
-            if (lane == leader) {
-                base = atomicAdd(a.ncc_cnt, __popcll(mm));
-                atomicAdd(a.wrow + blockIdx.z * a.H + y, __popcll(mm));
-            }
-            base = __shfl(base, leader);
-            if (wide) a.rf_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
-        }
-    }
+    // append of the wide pixels to the worklist of k_ncc_wide / the row kernels, ONE pair of atomics per workgroup
+    // (per wave, the single list counter -- ~88 same-address atomics per microsecond -- was 2.2 ms of a 12.5 MP frame
+    // of wide pixels)
+    __shared__ int s_wn[NCC_TX / 64], s_wbase;
+    const unsigned long long wmask = __ballot(wide);
     const bool narrow = active && !wide;
+    if (lane == 0) s_wn[tid >> 6] = __popcll(wmask);
     if (tid == 0) {
         s_ctl[0] = 0x7fffffff;
         s_ctl[1] = -1;
@@ -369,8 +362,21 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
             atomicMin(&s_ctl[0], lo);
             atomicMax(&s_ctl[1], hi);
         }
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < NCC_TX / 64; w++) tot += s_wn[w];
+            if (tot) {
+                s_wbase = atomicAdd(a.ncc_cnt, tot);
+                atomicAdd(a.wrow + blockIdx.z * a.H + y, tot);
+            }
+        }
     }
     __syncthreads();
+    if (wide) {
+        int base = s_wbase;
+        for (int w = 0; w < (tid >> 6); w++) base += s_wn[w];
+        a.rf_list[base + __popcll(wmask & ((1ull << lane) - 1ull))] = (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
+    }
     const int cmin = s_ctl[0], cmax = s_ctl[1];
     if (cmax < cmin) return;
 
@@ -455,15 +461,29 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
     __shared__ double s_v[NCC_TX / 64];
     __shared__ int s_c[NCC_TX / 64];
     __shared__ int s_x[NCC_TX / 64]; // bit 0: exact, bit 1: tie
+    __shared__ uint32_t s_items[NCC_TX];
+    __shared__ int s_nitems;
     const int count = *a.ncc_cnt;
     const int W = a.W;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        const uint32_t ent = a.rf_list[item];
+    // 256 list entries at a time: every thread looks at one and keeps it unless its row belongs to the row kernel (a frame
+    // of wide pixels is 12.5 M entries to skip: one entry per workgroup and iteration -- two dependent loads -- was 11 ms)
+    for (int base = blockIdx.x * NCC_TX; base < count; base += gridDim.x * NCC_TX) { // uniform
+    __syncthreads();
+    if (tid == 0) s_nitems = 0;
+    __syncthreads();
+    if (base + tid < count) {
+        const uint32_t e0 = a.rf_list[base + tid];
+        const int y0 = (int)((e0 & 0x7fffffffu) / W);
+        if (a.opt_no_rowgemm == 1 || a.wrow[(e0 >> 31) * a.H + y0] < RG_MIN) s_items[atomicAdd(&s_nitems, 1)] = e0;
+    }
+    __syncthreads();
+    const int nitems = s_nitems;
+    for (int it = 0; it < nitems; it++) { // uniform
+        const uint32_t ent = s_items[it];
         const DirArgs &d = a.d[ent >> 31];
         const size_t pix = ent & 0x7fffffffu;
         const int y = (int)(pix / W), x = (int)(pix % W);
-        if (!a.opt_no_rowgemm && a.wrow[(ent >> 31) * a.H + y] >= RG_MIN) continue; // the row is k_ncc_rowgemm's (uniform)
         int L, Rr;
         if (mode == 0) {
             L = d.oth.XL;
@@ -559,6 +579,7 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
             if (bv > -1.0) d.d16_out[pix] = (int16_t)(bc - x);
             if (tie) a.tie_list[atomicAdd(a.tie_cnt, 1)] = ent;
         }
+    }
     }
 }
 
@@ -938,6 +959,310 @@ __global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
     }
 }
 
+// ---------------------------------------------------------------- rows of wide pixels by sliding window sums
+// The same rows k_ncc_rowgemm takes, without the matrix cores: for a fixed disparity D = c - x the products of two
+// window columns do not depend on the pixel,
+//     Sab(x, x + D) = sum_{i = -R..R} V_D[x + i],      V_D[u] = sum_j <A[j][u], B[j][u + D]>   (one v_dot4_u32_u8 per row j)
+// so a pixel-candidate pair costs 2R + 1 dot4s and a (2R + 1)-term box sum instead of (2R + 1)^2 dot4s (15 x 15: 15 + ~9
+// integer operations against 225 dot4s, or against 4 MFMAs + 20 LDS reads per 16 x 64 tile in k_ncc_rowgemm, which the
+// operand gathers bound).  Wide pixels of a row all scan (nearly) the same candidate range, so the D planes are shared.
+// Mapping: a wave owns SL_COLS = 128 columns (2 per lane: the own-view window columns stay in 2 (2R + 1) registers for
+// the whole tile) and walks D upwards two planes at a time; per row j it reads ONE aligned ds_read_b64 of the other view
+// (the next two dwords of its sliding 4-dword window) for four dot4s; V goes through a small LDS line from which every
+// lane takes the 2R + 2 consecutive values of its two box sums; the per-candidate constants (Sb, 1 / sqrt(vb), validity)
+// slide the same way.  The 4 waves of a workgroup take the quarters of the tile's D range (their own staged chunks of
+// the other view's rows, no workgroup barrier in the loop) and merge their bests at the end; the inner 128 - 2R columns
+// of a tile are its pixels.  Scores, running best, tie flags: exactly k_ncc_rowgemm's epilogue (scaled filter score).
+#define SL_COLS 128
+#define SL_DC 64 // disparity planes per staged chunk (even)
+template <int R>
+__global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
+    constexpr int WS = 2 * R + 1, n = 3 * WS * WS;
+    constexpr int NBC = SL_COLS + SL_DC + 4;         // other-view columns / candidates staged per chunk
+    constexpr int NV = SL_COLS + 2 * R + 2;          // V line
+    constexpr int PXT = SL_COLS - 2 * R;             // pixels of a tile
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // per wave: sB[WS][NBC] u32 | sRvb[NBC] f64 | sSb[NBC] i32 | sV[2][NV] i32
+    constexpr size_t WAVE_BYTES = ((size_t)WS * NBC * 4 + (size_t)NBC * 8 + (size_t)NBC * 4 + (size_t)2 * NV * 4 + 15) & ~(size_t)15;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint8_t *wbase = smem + wv * WAVE_BYTES;
+    double *sRvb = (double *)wbase;                              // -1: not a candidate, 0: zero variance (score exactly 0)
+    uint32_t *sB = (uint32_t *)(wbase + (size_t)NBC * 8);
+    int *sSb = (int *)(sB + WS * NBC);
+    int *sV = sSb + NBC;
+    // merge area behind the four wave regions
+    double *mV = (double *)(smem + 4 * WAVE_BYTES); // [4][SL_COLS]
+    int *mC = (int *)(mV + 4 * SL_COLS);            // [4][SL_COLS]
+    int *mF = mC + 4 * SL_COLS;                     // [4][SL_COLS]: bit 0 exact, bit 1 tie
+    const DirArgs &d = a.d[blockIdx.z];
+    const int W = a.W;
+    const int32_t *rowlist = a.wrow + 2 * a.H + blockIdx.z * (a.H + 1); // [0] = number of rows, then the rows (k_rg_rows)
+    const int nrows = rowlist[0];
+    __shared__ int s_planes[4];
+    for (int q = lane; q < 2 * NV; q += 64) sV[q] = 0;
+    for (int slot = blockIdx.y; slot < nrows; slot += gridDim.y) { // uniform
+        const int y = rowlist[1 + slot];
+        // A workgroup owns FOUR consecutive tiles.  How its 4 waves share them depends on the disparity range the tiles
+        // span (device data: a pre-pass measures it): up to ~2 chunks of planes per tile every wave takes a tile of its own
+        // and walks all its planes (setup and merge amortised over 4 times the work: 257 candidates are 65 planes per
+        // wave otherwise); longer ranges are split 2- or 4-way over the waves, tile after tile.
+        {
+            const int ut = d.own.XL - R + (4 * blockIdx.x + wv) * PXT;
+            int dlo = 0x7fffffff, dhi = -0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int t = 2 * lane + e, x = ut + t;
+                const bool inside = t >= R && t < SL_COLS - R && x <= d.own.XR;
+                const size_t pix = (size_t)y * W + min(max(x, 0), W - 1);
+                if (!(inside && d.mask_own[pix] == 255)) continue;
+                int L = mode == 0 ? d.oth.XL : (int)d.BL[pix], Rr = mode == 0 ? d.oth.XR : (int)d.BR[pix];
+                L = max(L, R);
+                Rr = min(Rr, W - 1 - R);
+                if (Rr - L + 1 > NCC_WIDE) {
+                    dlo = min(dlo, L - x);
+                    dhi = max(dhi, Rr - x);
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                dlo = min(dlo, __shfl_xor(dlo, o));
+                dhi = max(dhi, __shfl_xor(dhi, o));
+            }
+            __syncthreads(); // the previous row is done with s_planes and the merge area
+            if (lane == 0) s_planes[wv] = dhi >= dlo ? dhi - dlo + 1 : 0;
+            __syncthreads();
+        }
+        const int pmax = max(max(s_planes[0], s_planes[1]), max(s_planes[2], s_planes[3]));
+        const int nsplit = pmax > 12 * SL_DC ? 4 : (pmax > 6 * SL_DC ? 2 : 1); // uniform over the workgroup
+        const int part = wv % nsplit;
+        for (int g = 0; g < nsplit; g++) { // uniform
+        const int tile = 4 * blockIdx.x + g * (4 / nsplit) + wv / nsplit;
+        const int u0 = d.own.XL - R + tile * PXT; // image column of tile column 0
+        // ---- this lane's two pixels (tile columns 2 lane, 2 lane + 1)
+        int Lp[2], Rp[2];
+        double Sa[2], sv[2], bestv[2];
+        int bestc[2];
+        unsigned exact = 3u, tie = 0u;
+        int dlo = 0x7fffffff, dhi = -0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int t = 2 * lane + e, x = u0 + t;
+            const bool inside = t >= R && t < SL_COLS - R && x <= d.own.XR;
+            const size_t pix = (size_t)y * W + min(max(x, 0), W - 1);
+            bool active = inside && d.mask_own[pix] == 255;
+            int L = 0x7fffffff, Rr = -1;
+            if (active) {
+                if (mode == 0) {
+                    L = d.oth.XL; // .cpp:207
+                    Rr = d.oth.XR;
+                } else {
+                    L = d.BL[pix];
+                    Rr = d.BR[pix];
+                }
+                L = max(L, R);
+                Rr = min(Rr, W - 1 - R);
+                if (L > Rr) active = false;
+            }
+            const bool wide = active && (Rr - L + 1 > NCC_WIDE); // exactly k_ncc_dot4's test
+            const double s1 = wide ? (double)d.S1_own[pix] : 0.0;
+            const double va = wide ? (double)n * (double)d.S2_own[pix] - s1 * s1 : 0.0;
+            Sa[e] = s1;
+            sv[e] = va > 0.0 ? sqrt(va) : -1.0; // -1: zero variance -- every score is exactly 0, the scale is 1
+            Lp[e] = wide ? L : 0x7fffffff;
+            Rp[e] = wide ? Rr : -1;
+            bestv[e] = sv[e] > 0.0 ? -sv[e] : -1.0; // .cpp:205, scaled
+            bestc[e] = 0x7fffffff;
+            if (wide) {
+                dlo = min(dlo, L - x);
+                dhi = max(dhi, Rr - x);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            dlo = min(dlo, __shfl_xor(dlo, o));
+            dhi = max(dhi, __shfl_xor(dhi, o));
+        }
+        if (dhi >= dlo) { // uniform over the waves that share the tile
+            dlo &= ~1; // even: the sliding reads stay 8-byte aligned
+            int span = (dhi - dlo + 1 + nsplit - 1) / nsplit;
+            span = (span + 1) & ~1;
+            const int D0 = dlo + part * span, D1 = min(dhi, D0 + span - 1); // this wave's planes
+            // own-view window columns of this lane's two tile columns
+            uint32_t a0[WS], a1[WS];
+#pragma unroll
+            for (int j = 0; j < WS; j++) {
+                const int c0 = u0 + 2 * lane, c1 = c0 + 1;
+                const uint32_t *row = d.img4_own + (size_t)(y - R + j) * W;
+                a0[j] = (c0 >= 0 && c0 < W) ? row[c0] : 0u;
+                a1[j] = (c1 >= 0 && c1 < W) ? row[c1] : 0u;
+            }
+            // the wave's planes in equal chunks of at most SL_DC (a last chunk of a few planes would pay a whole staging)
+            const int planes = D1 - D0 + 1;
+            const int nch = planes > 0 ? (planes + SL_DC - 1) / SL_DC : 0;
+            const int per = nch ? (((planes + nch - 1) / nch) + 1) & ~1 : 0; // even
+            for (int Dc = D0; Dc <= D1; Dc += per) { // uniform
+                // ---- stage the chunk: other-view columns u0 + Dc + i, i < NBC, and their candidate constants.  Every
+                // load of the chunk is issued before the first LDS write (one memory round trip, not one per 64 columns).
+                const int cb = u0 + Dc;
+                constexpr int NI = (NBC + 63) / 64;
+                __builtin_amdgcn_wave_barrier();
+                {
+                    uint32_t v[NI][WS];
+                    int sb_[NI], s2_[NI];
+                    uint8_t mk_[NI];
+#pragma unroll
+                    for (int ii = 0; ii < NI; ii++) {
+                        const int i = lane + 64 * ii, col = cb + i;
+                        const bool in = i < NBC && col >= 0 && col < W;
+                        const size_t o = (size_t)y * W + (in ? col : 0);
+#pragma unroll
+                        for (int j = 0; j < WS; j++) v[ii][j] = in ? d.img4_oth[(size_t)(y - R + j) * W + col] : 0u;
+                        sb_[ii] = d.S1_oth[o];
+                        s2_[ii] = d.S2_oth[o];
+                        mk_[ii] = d.mask_oth[o];
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < NI; ii++) {
+                        const int i = lane + 64 * ii, col = cb + i;
+                        if (i >= NBC) continue;
+                        const bool in = col >= 0 && col < W;
+#pragma unroll
+                        for (int j = 0; j < WS; j++) sB[j * NBC + i] = v[ii][j];
+                        const bool ok = in && col >= R && col <= W - 1 - R && mk_[ii] == 255; // .cpp:209
+                        const int Sb = sb_[ii];
+                        const double vb = (double)n * (double)s2_[ii] - (double)Sb * (double)Sb;
+                        double r = __builtin_amdgcn_rsq(vb > 0.0 ? vb : 1.0);
+                        r = __builtin_fma(0.5 * r, __builtin_fma(-(vb * r), r, 1.0), r); // one Newton step: ~2e-16 relative
+                        sSb[i] = Sb;
+                        sRvb[i] = !ok ? -1.0 : (vb > 0.0 ? r : 0.0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // sliding state at plane Dc: other-view dwords at tile columns 2 lane, 2 lane + 1 (shifted by the plane),
+                // candidate constants of c = x_a + D, x_a + D + 1
+                uint32_t b0[WS], b1[WS];
+#pragma unroll
+                for (int j = 0; j < WS; j++) {
+                    const uint2 v = *(const uint2 *)&sB[j * NBC + 2 * lane];
+                    b0[j] = v.x;
+                    b1[j] = v.y;
+                }
+                int2 sb01 = *(const int2 *)&sSb[2 * lane];
+                double2 rv01 = *(const double2 *)&sRvb[2 * lane];
+                const int kmax = min(per, D1 - Dc + 1); // planes of this chunk (may be odd: the surplus plane is masked by Rp)
+#pragma unroll 1
+                for (int k = 0; k < kmax; k += 2) {
+                    const int D = Dc + k;
+                    uint32_t v00 = 0u, v10 = 0u, v01 = 0u, v11 = 0u; // V[tile column][plane]
+                    const int io = 2 * lane + k + 2;
+#pragma unroll
+                    for (int j = 0; j < WS; j++) {
+                        const uint2 nx = *(const uint2 *)&sB[j * NBC + io];
+                        v00 = __builtin_amdgcn_udot4(a0[j], b0[j], v00, false);
+                        v10 = __builtin_amdgcn_udot4(a1[j], b1[j], v10, false);
+                        v01 = __builtin_amdgcn_udot4(a0[j], b1[j], v01, false);
+                        v11 = __builtin_amdgcn_udot4(a1[j], nx.x, v11, false);
+                        b0[j] = nx.x;
+                        b1[j] = nx.y;
+                    }
+                    const int2 sb23 = *(const int2 *)&sSb[io];
+                    const double2 rv23 = *(const double2 *)&sRvb[io];
+                    // ---- box sums over the tile columns: V line index = tile column + R
+                    sV[2 * lane + R] = (int)v00;
+                    sV[2 * lane + 1 + R] = (int)v10;
+                    sV[NV + 2 * lane + R] = (int)v01;
+                    sV[NV + 2 * lane + 1 + R] = (int)v11;
+                    __builtin_amdgcn_wave_barrier();
+                    int S[2][2]; // [plane][pixel]
+#pragma unroll
+                    for (int pl = 0; pl < 2; pl++) {
+                        int w[2 * R + 2];
+#pragma unroll
+                        for (int m = 0; m < R + 1; m++) {
+                            const int2 v = *(const int2 *)&sV[pl * NV + 2 * lane + 2 * m];
+                            w[2 * m] = v.x;
+                            w[2 * m + 1] = v.y;
+                        }
+                        int s0 = 0;
+#pragma unroll
+                        for (int m = 0; m < 2 * R + 1; m++) s0 += w[m];
+                        S[pl][0] = s0;
+                        S[pl][1] = s0 - w[0] + w[2 * R + 1];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // ---- scores: pixel e, plane pl -> candidate c = x_a + e + D + pl, constants index e + pl of (01 | 23)
+                    const int sbv[3] = {sb01.x, sb01.y, sb23.x};
+                    const double rvv[3] = {rv01.x, rv01.y, rv23.x};
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const double tol = NCC_TIE_TOL * (sv[e] > 0.0 ? sv[e] : 1.0);
+                        const int Sai = (int)Sa[e];
+#pragma unroll
+                        for (int pl = 0; pl < 2; pl++) { // ascending candidates
+                            const int c = u0 + 2 * lane + e + D + pl;
+                            const double rvb = rvv[e + pl];
+                            if (rvb < 0.0 || c < Lp[e] || c > Rp[e]) continue;
+                            const int Sb = sbv[e + pl];
+                            (void)Sai;
+                            const double sc = ((double)n * (double)S[pl][e] - Sa[e] * (double)Sb) * rvb; // score * sqrt(va)
+                            const bool exc = rvb == 0.0 || !(sv[e] > 0.0); // a zero-variance window on either side: exactly 0
+                            if (fabs(sc - bestv[e]) <= tol && !(exc && ((exact >> e) & 1u))) tie |= 1u << e;
+                            if (sc > bestv[e]) { // .cpp:213
+                                bestv[e] = sc;
+                                bestc[e] = c;
+                                exact = (exact & ~(1u << e)) | ((unsigned)exc << e);
+                            }
+                        }
+                    }
+                    sb01 = sb23;
+                    rv01 = rv23;
+                }
+            }
+        }
+        // ---- merge the waves that shared the tile (ascending plane ranges = ascending candidates): largest score, then
+        // smallest column
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            mV[wv * SL_COLS + 2 * lane + e] = bestv[e];
+            mC[wv * SL_COLS + 2 * lane + e] = bestc[e];
+            mF[wv * SL_COLS + 2 * lane + e] = (int)(((exact >> e) & 1u) | (((tie >> e) & 1u) << 1));
+        }
+        __syncthreads();
+        if (part == 0) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (Rp[e] < 0) continue; // not a wide pixel of this tile
+                const int t = 2 * lane + e, x = u0 + t;
+                const double tol = NCC_TIE_TOL * (sv[e] > 0.0 ? sv[e] : 1.0);
+                double bv = bestv[e];
+                int bc = bestc[e];
+                bool bx = (exact >> e) & 1u, tt = (tie >> e) & 1u;
+                for (int w2 = wv + 1; w2 < wv + nsplit; w2++) {
+                    const double ov = mV[w2 * SL_COLS + t];
+                    const int oc = mC[w2 * SL_COLS + t], of = mF[w2 * SL_COLS + t];
+                    const bool ox = of & 1;
+                    tt |= (of >> 1) & 1;
+                    if (bc != 0x7fffffff && oc != 0x7fffffff && fabs(ov - bv) <= tol && !(ox && bx)) tt = true;
+                    if (oc != 0x7fffffff && (ov > bv || (ov == bv && oc < bc))) {
+                        bv = ov;
+                        bc = oc;
+                        bx = ox;
+                    }
+                }
+                const size_t pix = (size_t)y * W + x;
+                if (bc != 0x7fffffff) d.d16_out[pix] = (int16_t)(bc - x); // .cpp:219-222 / 301-302
+                if (tt) a.tie_list[atomicAdd(a.tie_cnt, 1)] = (uint32_t)pix | ((uint32_t)blockIdx.z << 31);
+            }
+        }
+        } // tile groups
+    }
+}
+template <int R>
+static size_t slide_lds_bytes() {
+    constexpr int WS = 2 * R + 1, NBC = SL_COLS + SL_DC + 4, NV = SL_COLS + 2 * R + 2;
+    const size_t wave = ((size_t)WS * NBC * 4 + (size_t)NBC * 8 + (size_t)NBC * 4 + (size_t)2 * NV * 4 + 15) & ~(size_t)15;
+    return 4 * wave + (size_t)4 * SL_COLS * (8 + 4 + 4);
+}
+
 template <int R>
 static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st) {
     constexpr int WS = 2 * R + 1, SA = NCC_TX + 2 * R, SB = NCC_CH + 2 * R + NCC_G + 3;
@@ -953,9 +1278,28 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
     if (ldsw > 65536) // radii 6 and 7 stage more than the default 64 KB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void *)k_ncc_wide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
     hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), ldsw, st, a, mode);
-    if (!a.opt_no_rowgemm) hipLaunchKernelGGL(k_rg_rows, dim3(a.ndir), dim3(64), 0, st, a);
-    if (!a.opt_no_rowgemm) // grid.y = row SLOTS: rows with many wide pixels are few (all of them only at a wide lowest level)
+    // rows of wide pixels (opt_no_rowgemm: 1 = no row kernel, 2 = the int8 row GEMM on the matrix cores, 3 = sliding window
+    // sums, 0 = by the candidate range: measured on a 12.5 MP frame the sliding sums win up to a few hundred candidates
+    // (15 x 15 / 257: 9.8 ms against 10.5), the row GEMM beyond (15 x 15 / 1025: 28.0 ms against 31.3))
+    int kind = a.opt_no_rowgemm;
+    if (kind == 0) {
+        int cands = 0;
+        for (int v = 0; v < a.ndir; v++) cands = max(cands, a.d[v].oth.XR - a.d[v].oth.XL + 1);
+        kind = (mode == 0 && cands <= 512) ? 3 : 2;
+    }
+    if (kind != 1) hipLaunchKernelGGL(k_rg_rows, dim3(a.ndir), dim3(64), 0, st, a);
+    if (kind == 2) // grid.y = row SLOTS: rows with many wide pixels are few (all of them only at a wide lowest level)
         hipLaunchKernelGGL(k_ncc_rowgemm<R>, dim3((grid.x * NCC_TX + RG_PX - 1) / RG_PX, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), 0, st, a, mode);
+    if (kind == 3) {
+        const size_t lds_s = slide_lds_bytes<R>();
+        static bool attr_set = false; // per instantiation
+        if (!attr_set && lds_s > 65536) {
+            (void)hipFuncSetAttribute((const void *)k_ncc_slide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            attr_set = true;
+        }
+        const int tiles = (grid.x * NCC_TX + (SL_COLS - 2 * R) - 1) / (SL_COLS - 2 * R);
+        hipLaunchKernelGGL(k_ncc_slide<R>, dim3((tiles + 3) / 4, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), lds_s, st, a, mode);
+    }
     if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
 }
 

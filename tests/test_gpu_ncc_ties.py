@@ -137,3 +137,27 @@ def test_perfectly_anticorrelated_candidate_follows_the_reference(ctx):
     want = orc.lowest_level_initial_match(img0, img1, m, m1, r, mg0, mg1)
     got = ctx.initial_match(img0, img1, m, m1, r, 2, mg0, mg1, None)
     assert np.array_equal(got, want), diff_report("anticorrelated", got, want)
+
+
+WIDE_CASES = [c for c in CASES if c[1] >= 420] + [("saturated", 460, 40, 1, 5, 31, -6), ("2level_rgb", 700, 36, 1, 2, 32, 7)]
+
+
+@pytest.mark.parametrize("wide_rows", [1, 2, 3], ids=["workgroup_per_pixel", "int8_row_gemm", "sliding_window_sums"])
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "%s_%dx%d_r%d" % (c[0], c[1], c[2], c[4]))
+def test_every_wide_row_kernel_picks_the_reference_columns(ctx, case, wide_rows):
+    """Rows whose pixels scan more than NCC_WIDE candidates have three interchangeable kernels (option wide_rows: the
+    workgroup-per-pixel scan, the int8 row GEMM on the matrix cores, the sliding window sums); on tie-ridden textures
+    each of them must hand the same pixels to the reference-order re-evaluation and end on the oracle's columns."""
+    kind, W, H, levels, radius, seed, shift = case
+    cfg = make_case(kind, W, H, levels, radius, seed, shift, flips=W * H // 50)
+    mask = [np.ascontiguousarray(m) for m in cfg.mask]
+    mg = [orc.find_margin(mask[v], radius).astuple() for v in range(2)]
+    ctx.set_option("wide_rows", wide_rows)
+    try:
+        for v in range(2):
+            want = orc.lowest_level_initial_match(cfg.image[v], cfg.image[1 - v], mask[v], mask[1 - v], radius, mg[v], mg[1 - v])
+            got = ctx.initial_match(cfg.image[v], cfg.image[1 - v], mask[v], mask[1 - v], radius, 2, mg[v], mg[1 - v], None)
+            assert (mg[1 - v][3] - mg[1 - v][2] + 1) > 160          # every pixel is a wide pixel
+            assert np.array_equal(got, want), diff_report("wide_rows=%d v%d" % (wide_rows, v), got, want)
+    finally:
+        ctx.set_option("wide_rows", 0)
