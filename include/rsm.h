@@ -206,6 +206,8 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *   "no_exact" = 1         (timing A/B only) skip the reference-order re-evaluation of near-tie pixels
  *   "refine_band_mb" / "refine_band_rows"   time-skewed band schedule of the refine sweeps (0 = whole-frame, default)
  *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)
+ *   "refine_defer_from" / "refine_defer_to" / "refine_defer_min_px"   sweeps whose data-term cache misses are listed and served
+ *                          by a second kernel, a lane per miss, instead of inside the sweep (to = 0 = never, default)
  *   "heavy_exclusive" = 0 | 1 | 2   contexts sharing a GPU: no turns / the top level's refine sweeps take turns (default) /
  *                          every large level's; "heavy_min_px", "heavy_from_sweep" bound the sections that take turns */
 int rsm_set_option(rsm_ctx *ctx, const char *name, long long value);

@@ -292,7 +292,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // routine in every second wave for one or two lanes.
 // TOP only gives the top level's launches (the dominant kernel) their own name in rocprof traces.
 #define RFW_CAP (64 * RF_PPT) // every pixel of a wave may miss
-template <int TOP>
+// DEFER = 1: the sweep only LISTS its misses (miss_list, sized so that no shard can overflow) and leaves those pixels to
+// k_refine_fixup; without the service code the kernel needs half the registers.
+template <int TOP, int DEFER>
 __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     // Misses are served per WAVE (own list, own results, no workgroup barrier): a wave that has none -- nearly all of
     // them once the iteration has settled -- never waits for a neighbour's ~3 us service chain.
@@ -357,6 +359,21 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
         live |= (unsigned)lv << i;
         miss |= (unsigned)ms << i;
     }
+    unsigned deferred = 0; // pixels whose update k_refine_fixup will write
+    if (DEFER) {
+        if (n) { // wave-uniform: one append per wave; consecutive workgroups go to consecutive shards, and a shard holds every
+                 // pixel of its workgroups (rsm_api.hip: miss_cap), so nothing is ever dropped
+            const unsigned shard = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) & (RF_UPD_SHARDS - 1);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS + shard, n);
+            base = __shfl(base, 0);
+#pragma unroll
+            for (int i = 0; i < RF_PPT; i++)
+                if (((miss >> i) & 1u) && base + pos[i] < a.miss_cap)
+                    a.miss_list[(size_t)shard * a.miss_cap + base + pos[i]] = RfMiss{(uint32_t)((size_t)(y0 + i) * W + x) | ((uint32_t)blockIdx.z << 31), rel[i]};
+            deferred = miss;
+        }
+    } else
     if (n) { // wave-uniform
         __builtin_amdgcn_wave_barrier();
         for (int done = 0; done < n;) { // uniform
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < RF_PPT; i++) {
-        if (!((live >> i) & 1u)) continue;
+        if (!((live >> i) & 1u) || ((deferred >> i) & 1u)) continue;
         const size_t pix = (size_t)(y0 + i) * W + x;
         if ((miss >> i) & 1u) {
             pwp[i] = s_res[wid][pos[i]][0];
@@ -541,6 +558,39 @@ __global__ __launch_bounds__(256) void k_refine_multi(StageArgs a) {
     }
 }
 
+// Deferred miss service (a.defer sweeps): a lane per listed pixel -- every lane of the launch computes a data term, where
+// the in-sweep service runs the ~1000-instruction routine in nearly every wave for a handful of lanes (sweeps ~4..40 of a
+// level: 1-10 % of the pixels miss, scattered over all waves).  Writes the cache entry and the pixel's update exactly as
+// the sweep would have, and clears the other counter set for the next deferring sweep.
+__global__ __launch_bounds__(256) void k_refine_fixup(StageArgs a) {
+    const int32_t *cnt = a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < RF_UPD_SHARDS) a.upd_cnt[((a.flag3 + 1) & 1) * RF_UPD_SHARDS + threadIdx.x] = 0;
+    const int W = a.W, H = a.H;
+    for (int sh = blockIdx.y; sh < RF_UPD_SHARDS; sh += gridDim.y) {
+        const int n = min(cnt[sh], a.miss_cap);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const RfMiss u = a.miss_list[(size_t)sh * a.miss_cap + i];
+            const DirArgs &d = a.d[u.pix >> 31];
+            const size_t pix = (size_t)(u.pix & 0x7fffffffu);
+            const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+            const double *__restrict__ in = d.f64_a;
+            const double dC = in[pix], dE = in[pix + 1], dW = in[pix - 1], dN = in[pix - W], dS = in[pix + W];
+            const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                             (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620 (never 0 for a listed pixel)
+            double pwp, delta;
+            refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, u.rel + x, pwp, delta);
+            const size_t cpix = pix + (size_t)(u.rel & 1) * a.rf_stride;
+            d.rf_key[cpix] = (int16_t)u.rel;
+            d.rf_pwp[cpix] = pwp;
+            d.rf_delta[cpix] = delta;
+            d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+        }
+    }
+}
+void launch_refine_fixup(const StageArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(k_refine_fixup, dim3(64, RF_UPD_SHARDS), dim3(256), 0, st, a);
+}
+
 // scatters the update list of the k_refine_multi launch a.flag3 into the cache and clears the other counter set
 __global__ __launch_bounds__(256) void k_refine_apply(StageArgs a) {
     const int32_t *cnt = a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS;
@@ -593,8 +643,13 @@ void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hip
         hipLaunchKernelGGL(k_refine_first, grid, dim3(256), 0, st, a);
     } else {
         const dim3 sgrid(grid.x, (grid.y + RF_PPT - 1) / RF_PPT, grid.z);
-        if (a.flag) hipLaunchKernelGGL(k_refine_sweep<1>, sgrid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_refine_sweep<0>, sgrid, dim3(256), 0, st, a);
+        if (a.defer) {
+            if (a.flag) hipLaunchKernelGGL((k_refine_sweep<1, 1>), sgrid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_refine_sweep<0, 1>), sgrid, dim3(256), 0, st, a);
+        } else {
+            if (a.flag) hipLaunchKernelGGL((k_refine_sweep<1, 0>), sgrid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_refine_sweep<0, 0>), sgrid, dim3(256), 0, st, a);
+        }
     }
     if (ev1) (void)hipEventRecord(ev1, st);
 }

@@ -85,6 +85,8 @@ struct rsm_ctx {
     uint32_t *tie_list = nullptr; // NCC tie pixels (k_ncc_exact)
     int32_t *tie_cnt = nullptr;   // [2 * level + (Rematch ? 1 : 0)]
     double *rf_pwp[2]{}, *rf_delta[2]{};
+    RfMiss *miss_list = nullptr; // deferred refine misses (k_refine_fixup)
+    int miss_cap = 0;
     RfUpd *upd_list = nullptr; // k_refine_multi's cache updates
     int32_t *upd_cnt = nullptr;
     int upd_cap = 0;
@@ -115,6 +117,8 @@ struct rsm_ctx {
     int opt_heavy_from_sweep = 1;  // ... from this sweep of the level on
     int opt_heavy_min_px = 400000; // ... from this many margin pixels on (smaller levels are launch-bound themselves)
     int opt_heavy_exclusive = 1; // refine sections of contexts sharing a GPU take turns (heavy_begin): 1 = the top level's, 2 = every large level's, 0 = none
+    int opt_refine_defer_from = 4, opt_refine_defer_to = 0;  // sweeps whose cache misses go to k_refine_fixup (to = 0: never -- the default: measured slower)
+    double opt_refine_defer_min_px = 1.0e6;                  // ... on levels with at least this many margin pixels per direction
     int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
     int opt_refine_multi_from = 0;  // first sweep of a level that may run in the two-sweeps-per-launch kernel (0: never = default: measured slower, k_refine.hip)
     int opt_refine_multi_min_px = 400000; // ... at levels with at least this many margin pixels
@@ -345,6 +349,9 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     c->upd_cap = (int)std::min<size_t>(65536, std::max<size_t>(1024, px / 8));
     DALLOC(c, c->upd_list, (size_t)RF_UPD_SHARDS * c->upd_cap);
     DALLOC(c, c->upd_cnt, 2 * RF_UPD_SHARDS);
+    // every pixel of the sweep workgroups (256 x RF_PPT pixels each, both directions) that can hash to one shard
+    c->miss_cap = (int)((((size_t)(in->width / 256 + 2) * (size_t)(in->height / RF_PPT + 2) * 2) / RF_UPD_SHARDS + 2) * 256 * RF_PPT);
+    DALLOC(c, c->miss_list, (size_t)RF_UPD_SHARDS * c->miss_cap);
     DALLOC(c, c->tie_cnt, 2 * RSM_MAX_LEVELS);
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->blk, CLOUD_BLOCKS(in->width, in->height));
@@ -444,6 +451,9 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "heavy_min_px")) c->opt_heavy_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = (int)std::max(0LL, std::min(value, 2LL));
     else if (!strcmp(name, "no_rowgemm")) c->opt_no_rowgemm = value != 0 ? 1 : 0;
+    else if (!strcmp(name, "refine_defer_from")) c->opt_refine_defer_from = (int)value;
+    else if (!strcmp(name, "refine_defer_to")) c->opt_refine_defer_to = (int)value;
+    else if (!strcmp(name, "refine_defer_min_px")) c->opt_refine_defer_min_px = (double)value;
     else if (!strcmp(name, "wide_rows")) c->opt_no_rowgemm = (value >= 0 && value <= 3) ? (int)value : 0;
     else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
     else if (!strcmp(name, "refine_multi_from")) c->opt_refine_multi_from = (int)std::max(0LL, std::min(value, 100000LL));
@@ -497,6 +507,8 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.upd_list = c->upd_list;
     a.upd_cnt = c->upd_cnt;
     a.upd_cap = c->upd_cap;
+    a.miss_list = c->miss_list;
+    a.miss_cap = c->miss_cap;
     a.rf_stride = c->cap_px;
     a.row_lo = 0;
     a.row_hi = INT_MAX;
@@ -608,6 +620,10 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         const bool multi = c && c->opt_refine_multi_from > 0 && a.upd_list && px / a.ndir >= c->opt_refine_multi_min_px;
         if (multi) (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
         int nmulti = 0;
+        // sweeps whose cache misses are deferred to k_refine_fixup (a lane per miss) instead of being served inside the sweep
+        const bool may_defer = c && c->opt_refine_defer_to > 0 && a.miss_list && !multi && px / a.ndir >= c->opt_refine_defer_min_px;
+        if (may_defer) (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
+        int ndefer = 0;
         // the section that takes turns with the other contexts of this GPU starts once the sweeps have settled into pure
         // streaming: the first ones are busy computing data terms (VALU) and run well beside another pair's streaming sweeps
         bool held = false;
@@ -619,7 +635,15 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
                 launch(t, 0, INT_MAX, true);
                 t += 2;
             } else {
+                const bool defer = may_defer && t >= c->opt_refine_defer_from && t <= c->opt_refine_defer_to;
+                a.defer = defer;
+                if (defer) a.flag3 = ndefer++;
                 launch(t, 0, INT_MAX, false);
+                if (defer) { // a.f64_a / f64_b are still bound as for the sweep
+                    launch_refine_fixup(a, st);
+                    launches++;
+                }
+                a.defer = 0;
                 t += 1;
             }
         }
@@ -1323,6 +1347,8 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.rf_delta = t.alloc<double>(2 * px);
     a.rf_stride = px;
     a.upd_cap = 4096;
+    a.miss_cap = (int)((((size_t)(W / 256 + 2) * (size_t)(H / RF_PPT + 2)) / RF_UPD_SHARDS + 2) * 256 * RF_PPT);
+    a.miss_list = t.alloc<RfMiss>((size_t)RF_UPD_SHARDS * a.miss_cap);
     a.upd_list = t.alloc<RfUpd>((size_t)RF_UPD_SHARDS * a.upd_cap);
     a.upd_cnt = t.alloc<int32_t>(2 * RF_UPD_SHARDS);
     if (!t.ok) return finish(c, t);

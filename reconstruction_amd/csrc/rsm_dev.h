@@ -43,6 +43,11 @@ struct RfUpd {
     int32_t rel;  // iMatch - x of the entry (its parity selects the way)
     double pwp, delta;
 };
+// A pixel a deferring refine sweep (StageArgs::defer) leaves to k_refine_fixup.
+struct RfMiss {
+    uint32_t pix; // pixel index | direction << 31
+    int32_t rel;  // iMatch - x the pixel needs
+};
 #define RF_UPD_SHARDS 32 // append counters (one counter serialises at ~88 appends per microsecond)
 
 struct StageArgs {
@@ -60,7 +65,10 @@ struct StageArgs {
     RfUpd *upd_list;   // refine (k_refine_multi): RF_UPD_SHARDS regions of upd_cap records
     int32_t *upd_cnt;  // [2][RF_UPD_SHARDS]: append counters, the set in use alternates per launch (flag3 & 1)
     int upd_cap;
-    int flag3;         // refine multi: launch index (counter set)
+    int flag3;         // refine multi / deferred misses: launch index (counter set)
+    int defer;         // refine sweep: 1 = cache misses go to miss_list for k_refine_fixup instead of being served in the sweep
+    RfMiss *miss_list; // RF_UPD_SHARDS regions of miss_cap records (counters: upd_cnt); nullptr = never defer
+    int miss_cap;      // >= 1024 x the workgroups a shard can receive: a deferring sweep never overflows
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int opt_no_exact;               // skip k_ncc_exact (timing A/B only: ties then follow the integer form)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
@@ -101,6 +109,8 @@ void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// serves the misses a deferring sweep (a.defer) listed: data term, cache entry, the pixel's update f64_a -> f64_b
+void launch_refine_fixup(const StageArgs &a, hipStream_t st);
 // TWO sweeps f64_a -> f64_b in one launch (a.flag3 = launch index) + the launch that applies its cache updates
 void launch_refine_multi(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 

@@ -386,6 +386,34 @@ def test_whole_pair_against_the_libm_exp_oracle(ctx):
     assert res.n_points == ref["n_points"]
 
 
+@pytest.mark.parametrize("span", [(1, 1000), (2, 5), (4, 48), (30, 31)])
+def test_refine_deferred_miss_service_is_bit_identical(ctx, span):
+    """Sweeps `from..to` hand their cache misses to k_refine_fixup (a lane per listed pixel computes the data term, the
+    cache entry and the pixel's update) instead of serving them inside the sweep: the same values, bit for bit --
+    from the first cached sweep (nearly every pixel listed) to the settled regime, odd and even sweep counts."""
+    ctx.set_option("refine_defer_from", span[0])
+    ctx.set_option("refine_defer_to", span[1])
+    ctx.set_option("refine_defer_min_px", 0)
+    try:
+        for name in ("s512x384_5levels", "s192x128_ellipse", "s320x160_occluded_neg_r4"):
+            cfg, rec, fin = stages(name)
+            for q in rec:
+                if q["stage"] != "refine":
+                    continue
+                k, v = q["level"], q["v"]
+                for iters in (q["iters"], q["iters"] - 1):
+                    want = q["out"] if iters == q["iters"] else orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
+                    g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
+                    assert np.array_equal(g, want), diff_report("defer %s %s L%d v%d iters %d" % (span, name, k, v, iters), g, want)
+            res = ctx.match_pair(cfg)
+            for v in range(2):
+                assert np.array_equal(res.disparity[v], fin["disparity"][v])
+    finally:
+        ctx.set_option("refine_defer_from", 4)
+        ctx.set_option("refine_defer_to", 0)
+        ctx.set_option("refine_defer_min_px", 1000000)
+
+
 @pytest.mark.parametrize("first", [1, 2, 7, 32])
 def test_refine_two_sweeps_per_launch_is_bit_identical(ctx, first):
     """k_refine_multi (two Jacobi sweeps per launch on an LDS-resident tile, deferred cache updates) from sweep
