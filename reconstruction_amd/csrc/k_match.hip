@@ -1002,12 +1002,15 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
     for (int q = lane; q < 2 * NV; q += 64) sV[q] = 0;
     for (int slot = blockIdx.y; slot < nrows; slot += gridDim.y) { // uniform
         const int y = rowlist[1 + slot];
-        // A workgroup owns FOUR consecutive tiles.  How its 4 waves share them depends on the disparity range the tiles
-        // span (device data: a pre-pass measures it): up to ~2 chunks of planes per tile every wave takes a tile of its own
-        // and walks all its planes (setup and merge amortised over 4 times the work: 257 candidates are 65 planes per
-        // wave otherwise); longer ranges are split 2- or 4-way over the waves, tile after tile.
+        // Four consecutive workgroups form a group that owns four consecutive tiles.  How the tiles are shared depends on
+        // the disparity range they span (device data: a pre-pass measures it, identically in the four workgroups): up to
+        // ~6 chunks of planes per tile ONE workgroup takes all four tiles, a wave each, walking all planes (setup and
+        // merge amortised over 4 times the work: 257 candidates are 65 planes per wave otherwise) and the other three
+        // leave; longer ranges are split over 2 or 4 waves per tile, two or four workgroups sharing the tiles -- a
+        // handful of rows with 2000 candidates (C2's rows below an empty parent row) still fills the chip.
+        const int grp = blockIdx.x >> 2, gj = blockIdx.x & 3;
         {
-            const int ut = d.own.XL - R + (4 * blockIdx.x + wv) * PXT;
+            const int ut = d.own.XL - R + (4 * grp + wv) * PXT;
             int dlo = 0x7fffffff, dhi = -0x7fffffff;
 #pragma unroll
             for (int e = 0; e < 2; e++) {
@@ -1034,8 +1037,9 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
         const int pmax = max(max(s_planes[0], s_planes[1]), max(s_planes[2], s_planes[3]));
         const int nsplit = pmax > 12 * SL_DC ? 4 : (pmax > 6 * SL_DC ? 2 : 1); // uniform over the workgroup
         const int part = wv % nsplit;
-        for (int g = 0; g < nsplit; g++) { // uniform
-        const int tile = 4 * blockIdx.x + g * (4 / nsplit) + wv / nsplit;
+        if (gj >= nsplit) continue; // uniform: this workgroup has no tile in this row
+        {
+        const int tile = 4 * grp + gj * (4 / nsplit) + wv / nsplit;
         const int u0 = d.own.XL - R + tile * PXT; // image column of tile column 0
         // ---- this lane's two pixels (tile columns 2 lane, 2 lane + 1)
         int Lp[2], Rp[2];
@@ -1298,7 +1302,7 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
             attr_set = true;
         }
         const int tiles = (grid.x * NCC_TX + (SL_COLS - 2 * R) - 1) / (SL_COLS - 2 * R);
-        hipLaunchKernelGGL(k_ncc_slide<R>, dim3((tiles + 3) / 4, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), lds_s, st, a, mode);
+        hipLaunchKernelGGL(k_ncc_slide<R>, dim3((tiles + 3) & ~3, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), lds_s, st, a, mode);
     }
     if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
 }
