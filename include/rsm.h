@@ -201,8 +201,8 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
 
 /* Tuning / validation knobs.  None of them changes a result (every alternative path is held bit-identical by the tests):
  *   "ncc_bytes" = 1        the generic byte-wise NCC kernel instead of the dot4 one
- *   "wide_rows" = 0 | 1 | 2 | 3   rows of wide pixels: chosen by the candidate range (default) / the one-workgroup-per-pixel
- *                          kernel / the int8 row GEMM on the matrix cores / sliding window sums;  "no_rowgemm" = 1 is wide_rows = 1
+ *   "wide_rows" = 0 | 1 | 2 | 3   rows of wide pixels: default (= 2) / the one-workgroup-per-pixel kernel / the int8 row GEMM
+ *                          on the matrix cores / sliding window sums;  "no_rowgemm" = 1 is wide_rows = 1
  *   "no_exact" = 1         (timing A/B only) skip the reference-order re-evaluation of near-tie pixels
  *   "refine_band_mb" / "refine_band_rows"   time-skewed band schedule of the refine sweeps (0 = whole-frame, default)
  *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)

@@ -1002,15 +1002,12 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
     for (int q = lane; q < 2 * NV; q += 64) sV[q] = 0;
     for (int slot = blockIdx.y; slot < nrows; slot += gridDim.y) { // uniform
         const int y = rowlist[1 + slot];
-        // Four consecutive workgroups form a group that owns four consecutive tiles.  How the tiles are shared depends on
-        // the disparity range they span (device data: a pre-pass measures it, identically in the four workgroups): up to
-        // ~6 chunks of planes per tile ONE workgroup takes all four tiles, a wave each, walking all planes (setup and
-        // merge amortised over 4 times the work: 257 candidates are 65 planes per wave otherwise) and the other three
-        // leave; longer ranges are split over 2 or 4 waves per tile, two or four workgroups sharing the tiles -- a
-        // handful of rows with 2000 candidates (C2's rows below an empty parent row) still fills the chip.
-        const int grp = blockIdx.x >> 2, gj = blockIdx.x & 3;
+        // A workgroup owns FOUR consecutive tiles.  How its 4 waves share them depends on the disparity range the tiles
+        // span (device data: a pre-pass measures it): up to ~2 chunks of planes per tile every wave takes a tile of its own
+        // and walks all its planes (setup and merge amortised over 4 times the work: 257 candidates are 65 planes per
+        // wave otherwise); longer ranges are split 2- or 4-way over the waves, tile after tile.
         {
-            const int ut = d.own.XL - R + (4 * grp + wv) * PXT;
+            const int ut = d.own.XL - R + (4 * blockIdx.x + wv) * PXT;
             int dlo = 0x7fffffff, dhi = -0x7fffffff;
 #pragma unroll
             for (int e = 0; e < 2; e++) {
@@ -1037,9 +1034,8 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
         const int pmax = max(max(s_planes[0], s_planes[1]), max(s_planes[2], s_planes[3]));
         const int nsplit = pmax > 12 * SL_DC ? 4 : (pmax > 6 * SL_DC ? 2 : 1); // uniform over the workgroup
         const int part = wv % nsplit;
-        if (gj >= nsplit) continue; // uniform: this workgroup has no tile in this row
-        {
-        const int tile = 4 * grp + gj * (4 / nsplit) + wv / nsplit;
+        for (int g = 0; g < nsplit; g++) { // uniform
+        const int tile = 4 * blockIdx.x + g * (4 / nsplit) + wv / nsplit;
         const int u0 = d.own.XL - R + tile * PXT; // image column of tile column 0
         // ---- this lane's two pixels (tile columns 2 lane, 2 lane + 1)
         int Lp[2], Rp[2];
@@ -1282,15 +1278,12 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
     if (ldsw > 65536) // radii 6 and 7 stage more than the default 64 KB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void *)k_ncc_wide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
     hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), ldsw, st, a, mode);
-    // rows of wide pixels (opt_no_rowgemm: 1 = no row kernel, 2 = the int8 row GEMM on the matrix cores, 3 = sliding window
-    // sums, 0 = by the candidate range: measured on a 12.5 MP frame the sliding sums win up to a few hundred candidates
-    // (15 x 15 / 257: 9.8 ms against 10.5), the row GEMM beyond (15 x 15 / 1025: 28.0 ms against 31.3))
-    int kind = a.opt_no_rowgemm;
-    if (kind == 0) {
-        int cands = 0;
-        for (int v = 0; v < a.ndir; v++) cands = max(cands, a.d[v].oth.XR - a.d[v].oth.XL + 1);
-        kind = (mode == 0 && cands <= 512) ? 3 : 2;
-    }
+    // rows of wide pixels (opt_no_rowgemm: 1 = no row kernel, 3 = sliding window sums, 0 / 2 = the int8 row GEMM on the
+    // matrix cores).  Measured on a 12.5 MP frame of wide pixels (profiles/r03_ncc_micro.log) the two formulations end
+    // within ~10 % of each other -- 15 x 15 / 257 candidates: 9.3 ms sliding, 10.5 ms row GEMM; 15 x 15 / 1025: 33.2 / 29.2 ms;
+    // whole pairs: C5 initial match 2.05 / 1.95 ms, C2 1.83 / 1.43 ms -- both are bound by the fp64 score epilogue
+    // (~25 VALU operations per pixel-candidate pair) rather than by how Sab is formed; the row GEMM is the default.
+    int kind = a.opt_no_rowgemm == 0 ? 2 : a.opt_no_rowgemm;
     if (kind != 1) hipLaunchKernelGGL(k_rg_rows, dim3(a.ndir), dim3(64), 0, st, a);
     if (kind == 2) // grid.y = row SLOTS: rows with many wide pixels are few (all of them only at a wide lowest level)
         hipLaunchKernelGGL(k_ncc_rowgemm<R>, dim3((grid.x * NCC_TX + RG_PX - 1) / RG_PX, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), 0, st, a, mode);
@@ -1302,7 +1295,7 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
             attr_set = true;
         }
         const int tiles = (grid.x * NCC_TX + (SL_COLS - 2 * R) - 1) / (SL_COLS - 2 * R);
-        hipLaunchKernelGGL(k_ncc_slide<R>, dim3((tiles + 3) & ~3, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), lds_s, st, a, mode);
+        hipLaunchKernelGGL(k_ncc_slide<R>, dim3((tiles + 3) / 4, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), lds_s, st, a, mode);
     }
     if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
 }
