@@ -213,6 +213,10 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
     // LDS list (about a third of the 27 cells' points for a surface, a sixth for a volume) and read back into registers,
     // lane l holding entries l, l + 64, ...; the asm fence keeps the compiler from re-deriving them from memory in
     // every bisection step (the first version did: 120 ns per query).
+    if (M < want) { // fewer points in the 27 cells than neighbours wanted: undecidable without looking at them
+        if (lane == 0) undecided[qi] = 1u;
+        return;
+    }
     float *mine = s_d2[threadIdx.x >> 6];
     const unsigned long long lt = (1ull << lane) - 1ull;
     int K = 0; // candidates within h so far (uniform)
@@ -878,8 +882,9 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     // local density); an undecided attempt costs one table lookup and one count over the few candidates a too-fine grid
     // offers.  Every level re-sorts the points (0.65 ms for 5.5 M): cheap next to one query pass with a wrong h
     // (a single level at the surface estimate ran the near part's queries over ~50 000 candidates each: 390 ms).
-    // The ladder starts two octaves below the surface estimate (on C2 the level below that decides nothing).
-    h *= 0.25f;
+    // The ladder starts one octave below the surface estimate (on C2 two octaves below decides 10 % of the queries for
+    // a quarter of the search time, three octaves below nothing).
+    h *= 0.5f;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const int KNN_LEVELS = 12;
     if (hipMemsetAsync(d_dist, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return RSM_E_HIP; // non-finite points: distance 0, as PCL
@@ -908,7 +913,8 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
         redo_n = h_cnt[0];
         queries = out_list;
         nq = redo_n;
-        if (nq <= 256) break; // cheaper to finish against all points than to sort again
+        if (nq <= 48) break; // cheaper to finish against all points than to sort again (a coarser level costs ~0.8 ms, the
+                             // whole-chip search ~25 us per query)
     }
     redo_n = nq;
     if (nq > 0) { // against all points; the last grid's sorted copy is still in the arena (any ordering of the points serves)
