@@ -84,3 +84,33 @@ def test_filter_of_a_matched_pair_on_device_equals_the_host_entry(ctx):
     sm.MatchAllLayer()
     fx, fn = opt.cloud_normals[0]
     assert np.array_equal(fx, res.xyz[kept].astype(np.float32)) and np.array_equal(fn, nrm, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,k", [(150, 100), (101, 100), (50, 100), (7, 100), (2, 5), (1, 3)])
+def test_tiny_clouds_follow_the_oracle(ctx, n, k):
+    """Clouds around and below k + 1 points (every query ends in the whole-cloud search; with fewer than k + 1 points the
+    sum runs over the neighbours that exist, as oracle/cloud_oracle.c states PCL's loop), a non-finite point among them,
+    a single point (PCL's variance divides by n - 1 = 0: the NaN threshold removes nothing)."""
+    rng = np.random.default_rng(100 + n)
+    xyz = (rng.normal(0, 3.0, (n, 3)) + [0, 0, 500]).astype(np.float32)
+    if n >= 7:
+        xyz[3] = [np.nan, 1.0, 2.0]
+    cam = np.array([1.0, 2.0, 0.0], np.float32)
+    keep_o, dist_o, (mean_o, std_o, thr_o) = orc.sor_filter(xyz, k, 1.0)
+    kept, nrm, st = ctx.filter_cloud(xyz, k, 1.0, 2.5, cam)
+    for a, b in ((st["mean"], mean_o), (st["stddev"], std_o), (st["threshold"], thr_o)):
+        assert a == b or (np.isnan(a) and np.isnan(b)), (st, mean_o, std_o, thr_o)
+    assert np.array_equal(kept, np.nonzero(keep_o)[0])
+    nrm_o = orc.cloud_normals(xyz[keep_o], 2.5, cam)
+    assert np.array_equal(np.isnan(nrm[:, 0]), np.isnan(nrm_o[:, 0]))
+    ok = ~np.isnan(nrm_o[:, 0])
+    if ok.any():
+        assert np.abs(nrm[ok, :3] - nrm_o[ok, :3]).max() < 1e-3
+
+
+def test_filter_of_an_empty_and_an_all_nonfinite_cloud(ctx):
+    kept, nrm, st = ctx.filter_cloud(np.zeros((0, 3), np.float32), 100, 1.0, 2.5, (0, 0, 0))
+    assert len(kept) == 0 and len(nrm) == 0
+    xyz = np.full((9, 3), np.nan, np.float32)
+    kept, nrm, st = ctx.filter_cloud(xyz, 100, 1.0, 2.5, (0, 0, 0))
+    assert list(kept) == list(range(9)) and np.isnan(nrm).all()      # distance 0 for every point, nothing exceeds a NaN threshold
