@@ -250,6 +250,8 @@ int rsm_stage_median(rsm_ctx *ctx, int16_t *disp, const uint8_t *mask_own, int W
 int rsm_stage_refine(rsm_ctx *ctx, const int16_t *disp_in, const uint8_t *img_own,
                      const uint8_t *img_oth, int W, int H, int iterations, double ws,
                      const rsm_boundary *own, double *disp_out);
+/* the specified exp(-t) of DisparityRefine's weights (CStereoMatching.cpp:665-666 call exp) on n values */
+int rsm_stage_exp_neg(rsm_ctx *ctx, const double *t, int64_t n, double *out);
 int rsm_stage_cloud(rsm_ctx *ctx, const double *disp, const uint8_t *mask_org, const uint8_t *img_own,
                     int W, int H, const double *Q, double scale, const double *R_final,
                     const double *T_final, const rsm_boundary *own, double *xyz, uint8_t *bgr,

@@ -351,6 +351,21 @@ def exp_neg(t: float) -> float:
     return float(L.orc_exp_neg(float(t)))
 
 
+def exp_neg_array(t, soft_fma: bool = False) -> np.ndarray:
+    """orc_exp_neg over an array; soft_fma forces the C library's fma() instead of the CPU instruction."""
+    L = lib()
+    t = np.ascontiguousarray(t, np.float64).ravel()
+    out = np.zeros(t.shape, np.float64)
+    L.orc_exp_neg_array.restype = None
+    L.orc_exp_neg_array.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p]
+    L.orc_set_exp_soft_fma(1 if soft_fma else 0)
+    try:
+        L.orc_exp_neg_array(t.ctypes.data, t.size, out.ctypes.data)
+    finally:
+        L.orc_set_exp_soft_fma(0)
+    return out
+
+
 def set_exp_mode(libm: int) -> None:
     """1: the refine weights use the host libm's exp instead of the specified one (sensitivity experiments only)."""
     lib().orc_set_exp_mode(int(libm))

@@ -46,32 +46,61 @@ static double wall_now(void) {
  * exp on one side and the device library's on the other, 1.8 percent of the pixels of a 5-level test pair differ by
  * up to 7e-3 after the top level's 150 sweeps although the first 20 sweeps agree to 1e-15.  So that a comparison
  * shows implementation errors and not libm differences, the oracle and the GPU kernels evaluate ONE fully specified
- * exp: x = -t = k ln2 + r with |r| <= 0.5 ln2 (Cody-Waite, ln2 split so that k * ln2HI is exact), exp(r) by the
- * Taylor polynomial of degree 13 in Horner form (coefficients = 1/n! correctly rounded; truncation 4e-18), times 2^k
- * by exponent arithmetic.  Only + - * on doubles, compiled without contraction: the same bits on every IEEE-754
- * machine; within 1 ulp of glibc's exp on every sampled argument (tests/test_oracle_known_answers.py).
+ * exp: x = -t = k ln2 + r, k = trunc(fma(1/ln2, x, -0.5)), r = fma(-k, ln2LO, fma(-k, ln2HI, x)) (Cody-Waite, ln2
+ * split so that k * ln2HI is exact; |r| <= 0.35), exp(r) by the Taylor polynomial of degree 13 as a Horner chain of
+ * 13 fused multiply-adds (coefficients = 1/n! correctly rounded; truncation 4e-18), times 2^k with one rounding
+ * (exact unless the result is subnormal).  Every step is a correctly rounded IEEE-754 operation -- fma() is one,
+ * whether the host has the instruction (then this file uses it) or the C library emulates it -- so the bits are the
+ * same on every conforming machine; within 1 ulp of glibc's exp on every sampled argument
+ * (tests/test_oracle_known_answers.py), and equal to the GPU's evaluation bit for bit (tests/test_gpu_golden.py runs
+ * rsm_stage_exp_neg over the whole argument range incl. the subnormal results).
  * orc_set_exp_mode(1) switches the oracle to the host libm for comparison. */
 static int g_exp_mode = 0;
 void orc_set_exp_mode(int libm) { g_exp_mode = libm != 0; }
-double orc_exp_neg(double t) {
+
+/* The polynomial part with the hardware instruction where the CPU has it (same values as fma() by definition). */
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target("fma"))) static double exp_core_hw(double r, int *kout) {
+    static const double ln2HI = 0x1.62e42feep-1, ln2LO = 0x1.a39ef35793c76p-33, invln2 = 0x1.71547652b82fep+0;
+    static const double C[14] = {1.0, 1.0, 0x1.0000000000000p-1, 0x1.5555555555555p-3, 0x1.5555555555555p-5, 0x1.1111111111111p-7, 0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-16, 0x1.71de3a556c734p-19, 0x1.27e4fb7789f5cp-22, 0x1.ae64567f544e4p-26, 0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33}; /* 1/n! */
+    const int k = (int)__builtin_fma(invln2, r, -0.5);
+    const double tk = (double)k;
+    r = __builtin_fma(-tk, ln2LO, __builtin_fma(-tk, ln2HI, r));
+    double p = C[13];
+    for (int n = 12; n >= 0; n--) p = __builtin_fma(p, r, C[n]);
+    *kout = k;
+    return p;
+}
+#endif
+static double exp_core_sw(double r, int *kout) {
     static const double ln2HI = 0x1.62e42feep-1,          /* 6.93147180369123816490e-01 */
         ln2LO = 0x1.a39ef35793c76p-33,                    /* 1.90821492927058770002e-10 */
         invln2 = 0x1.71547652b82fep+0;                    /* 1.44269504088896338700e+00 */
     static const double C[14] = {1.0, 1.0, 0x1.0000000000000p-1, 0x1.5555555555555p-3, 0x1.5555555555555p-5, 0x1.1111111111111p-7, 0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-16, 0x1.71de3a556c734p-19, 0x1.27e4fb7789f5cp-22, 0x1.ae64567f544e4p-26, 0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33}; /* 1/n! */
+    const int k = (int)fma(invln2, r, -0.5);
+    const double tk = (double)k;
+    r = fma(-tk, ln2LO, fma(-tk, ln2HI, r));              /* tk * ln2HI is exact */
+    double p = C[13];
+    for (int n = 12; n >= 0; n--) p = fma(p, r, C[n]);
+    *kout = k;
+    return p;
+}
+static int g_have_fma = -1;
+void orc_set_exp_soft_fma(int soft) { g_have_fma = soft ? 0 : -1; } /* tests: force the C library's fma() */
+
+double orc_exp_neg(double t) {
     if (g_exp_mode || !(t >= 0.0)) return exp(-t);        /* (t is a square: never negative or NaN on this path) */
     if (t > 745.13321910194110842) return 0.0;            /* underflow threshold of exp */
-    double r = -t;
-    int k = 0;
-    if (t > 0.34657359027997264) {                        /* |x| > 0.5 ln2 */
-        k = (int)(invln2 * r - 0.5);
-        const double tk = (double)k;
-        const double hi = r - tk * ln2HI;                 /* tk * ln2HI is exact */
-        const double lo = tk * ln2LO;
-        r = hi - lo;
-    }
-    double p = C[13];
-    for (int n = 12; n >= 0; n--) p = p * r + C[n];
-    /* p * 2^k by exponent arithmetic; results below the normal range go through an exact power-of-two product */
+    int k;
+    double p;
+#if defined(__x86_64__) && defined(__GNUC__)
+    if (g_have_fma < 0) g_have_fma = __builtin_cpu_supports("fma") ? 1 : 0;
+    if (g_have_fma) p = exp_core_hw(-t, &k);
+    else
+#endif
+        p = exp_core_sw(-t, &k);
+    /* p * 2^k, rounded once: p is in [0.70, 1.42], so exponent arithmetic is exact while the result is normal;
+     * below that the product goes through one exact power-of-two scaling and ONE rounding multiply */
     union {
         double d;
         uint64_t u;
@@ -83,6 +112,10 @@ double orc_exp_neg(double t) {
     }
     v.u += (uint64_t)(int64_t)(k + 1000) << 52;
     return v.d * 0x1p-1000;
+}
+
+void orc_exp_neg_array(const double *t, long long n, double *out) {
+    for (long long i = 0; i < n; i++) out[i] = orc_exp_neg(t[i]);
 }
 
 int orc_num_threads(void) {

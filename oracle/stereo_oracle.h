@@ -143,6 +143,8 @@ void orc_rectify_pair(const double *K0, const double *K1, const double *E0, cons
 /* the fully specified exp(-t) of the refine weights (see stereo_oracle.c); mode 1 = host libm instead */
 double orc_exp_neg(double t);
 void orc_set_exp_mode(int libm);
+void orc_set_exp_soft_fma(int soft); /* 1: evaluate fma() through the C library even where the CPU has the instruction */
+void orc_exp_neg_array(const double *t, long long n, double *out);
 
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

@@ -401,6 +401,13 @@ class Context:
                                              C.c_double(ws), C.byref(_bd(own)), _p(out)))
         return out
 
+    def exp_neg(self, t):
+        """The specified exp(-t) of DisparityRefine's smoothness weights, evaluated on the device."""
+        t = np.ascontiguousarray(t, np.float64).ravel()
+        out = np.zeros(t.shape, np.float64)
+        self._chk(self._lib.rsm_stage_exp_neg(self._h, _p(t), C.c_int64(t.size), _p(out)))
+        return out
+
     def disparity_to_cloud(self, disp, mask_org, img_own, Q, scale, R, T, own):
         d = np.ascontiguousarray(disp, np.float64); mask_org = _u8(mask_org); img_own = _u8(img_own)
         H, W = d.shape

@@ -20,41 +20,46 @@
 // bit is not specified, and the sweep amplifies one-ulp differences chaotically (a 5-level test pair: agreement to
 // 1e-15 after 20 sweeps, 1.8 percent of the pixels off by up to 7e-3 after 150, between glibc's exp and the device
 // library's).  So the weights come from ONE fully specified evaluation, restated identically in the CPU oracle
-// (oracle/stereo_oracle.c: orc_exp_neg): x = -t = k ln2 + r, |r| <= 0.5 ln2 (ln2 split so that k * ln2HI is exact),
-// exp(r) by the degree-13 Taylor polynomial in Horner form (coefficients 1/n! correctly rounded), times 2^k by
-// exponent arithmetic.  Only + - * on doubles, no contraction (-ffp-contract=off): the same bits on every IEEE-754
-// machine, within 1 ulp of glibc's exp.  With it DisparityRefine is bit-identical to the oracle.
+// (oracle/stereo_oracle.c: orc_exp_neg): x = -t = k ln2 + r, k = trunc(fma(1/ln2, x, -0.5)), r = fma(-k, ln2LO,
+// fma(-k, ln2HI, x)) (ln2 split so that k * ln2HI is exact; |r| <= 0.35), exp(r) by the degree-13 Taylor polynomial
+// as a Horner chain of 13 fused multiply-adds (coefficients 1/n! correctly rounded), times 2^k with one rounding
+// (exact unless the result is subnormal).  Every operation is a correctly rounded IEEE-754 operation (fma included),
+// so the bits are the same on every conforming machine; within 1 ulp of glibc's exp.  With it DisparityRefine is
+// bit-identical to the oracle.  (Rounds 1-2 specified the same polynomial with separate multiplies and adds: 44
+// instead of 22 fp64 instructions per call, two calls per pixel update.)
 __device__ __forceinline__ double exp_neg(double t) {
     const double ln2HI = 0x1.62e42feep-1, ln2LO = 0x1.a39ef35793c76p-33, invln2 = 0x1.71547652b82fep+0;
-    if (!(t >= 0.0)) return exp(-t);           // never on this path (t is a square)
-    if (t > 745.13321910194110842) return 0.0; // underflow threshold of exp
     double r = -t;
-    int k = 0;
-    if (t > 0.34657359027997264) {             // |x| > 0.5 ln2
-        k = (int)(invln2 * r - 0.5);
-        const double tk = (double)k;
-        const double hi = r - tk * ln2HI;      // tk * ln2HI is exact
-        const double lo = tk * ln2LO;
-        r = hi - lo;
-    }
-    double p = 0x1.6124613a86d09p-33; // 1/13!
-    p = p * r + 0x1.1eed8eff8d898p-29; // 1/12!
-    p = p * r + 0x1.ae64567f544e4p-26; // 1/11!
-    p = p * r + 0x1.27e4fb7789f5cp-22; // 1/10!
-    p = p * r + 0x1.71de3a556c734p-19; // 1/9!
-    p = p * r + 0x1.a01a01a01a01ap-16; // 1/8!
-    p = p * r + 0x1.a01a01a01a01ap-13; // 1/7!
-    p = p * r + 0x1.6c16c16c16c17p-10; // 1/6!
-    p = p * r + 0x1.1111111111111p-7; // 1/5!
-    p = p * r + 0x1.5555555555555p-5; // 1/4!
-    p = p * r + 0x1.5555555555555p-3; // 1/3!
-    p = p * r + 0x1.0000000000000p-1; // 1/2!
-    p = p * r + 1.0; // 1/1!
-    p = p * r + 1.0; // 1/0!
-    // p * 2^k by exponent arithmetic; results below the normal range go through an exact power-of-two product
-    const unsigned long long u = (unsigned long long)__double_as_longlong(p);
-    if (k >= -1021) return __longlong_as_double((long long)(u + ((unsigned long long)(long long)k << 52)));
-    return __longlong_as_double((long long)(u + ((unsigned long long)(long long)(k + 1000) << 52))) * 0x1p-1000;
+    const int k = (int)__builtin_fma(invln2, r, -0.5); // saturates for huge t; the result is 0 then anyway (below)
+    const double tk = (double)k;
+    r = __builtin_fma(-tk, ln2LO, __builtin_fma(-tk, ln2HI, r)); // tk * ln2HI is exact
+    double p = 0x1.6124613a86d09p-33;                 // 1/13!
+    p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);   // 1/12!
+    p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);   // 1/11!
+    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);   // 1/10!
+    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);   // 1/9!
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);   // 1/8!
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);   // 1/7!
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);   // 1/6!
+    p = __builtin_fma(p, r, 0x1.1111111111111p-7);    // 1/5!
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);    // 1/4!
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);    // 1/3!
+    p = __builtin_fma(p, r, 0x1.0000000000000p-1);    // 1/2!
+    p = __builtin_fma(p, r, 1.0);                     // 1/1!
+    p = __builtin_fma(p, r, 1.0);                     // 1/0!
+    // p * 2^k, rounded once: v_ldexp_f64 (fp64 denormals are on).  p is in [0.70, 1.42], so the product is exact
+    // whenever it is normal (k >= -1021) and a single round-to-nearest-even into the subnormal range otherwise.
+    const double v = __builtin_ldexp(p, k);
+    return (t > 745.13321910194110842) ? 0.0 : v;     // underflow threshold of exp; also covers the saturated k
+}
+
+// test entry: the specified exp on an array (rsm_stage_exp_neg)
+__global__ void k_exp_neg(const double *t, double *out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = exp_neg(t[i]);
+}
+void launch_exp_neg(const double *t, double *out, long long n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_exp_neg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, out, n);
 }
 
 __global__ void k_refine_init(StageArgs a) {
@@ -606,6 +611,164 @@ __global__ __launch_bounds__(256) void k_refine_apply(StageArgs a) {
             d.rf_delta[cpix] = u.delta;
         }
     }
+}
+
+// k_refine_skew's miss path: the lane computes its own data
+// term, installs it in the LDS copy of the cache row and -- for a pixel its workgroup owns, once per (pixel, way) and
+// launch -- appends it to the update list.
+__device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, int W, int H, int x, int r, int rel, int way, int e, int lane,
+                                       bool owned, int32_t *cnt, unsigned shard, double2 &pd, double2 *ent_row, uint32_t *key_row,
+                                       uint8_t *emit_row, uint32_t kk) {
+    refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, r, rel + x, pd.x, pd.y);
+    ent_row[lane] = pd;
+    key_row[lane] = way ? ((kk & 0xffffu) | ((uint32_t)(rel & 0xffff) << 16)) : ((kk & 0xffff0000u) | (uint32_t)(rel & 0xffff));
+    const unsigned fl = emit_row[lane];
+    const bool emit = owned && !((fl >> way) & 1u);
+    const unsigned long long em = __ballot(emit);
+    if (em) {
+        const int leader = __builtin_ctzll(em);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(cnt, __popcll(em));
+        base = __shfl(base, leader) + __popcll(em & ((1ull << lane) - 1ull));
+        if (emit && base < a.upd_cap) {
+            RfUpd u;
+            u.pix = (uint32_t)((size_t)r * W + x) | ((uint32_t)blockIdx.z << 31);
+            u.rel = rel;
+            u.pwp = pd.x;
+            u.delta = pd.y;
+            a.upd_list[(size_t)shard * a.upd_cap + base] = u;
+            emit_row[lane] = (uint8_t)(fl | (1u << way));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// T Jacobi sweeps per launch, time-skewed down the rows (option refine_skew_from).
+// A workgroup of T waves owns a strip of 64 columns and a chunk of rows and streams down it: in step s it stages row
+// s + 1 of the input (the state and BOTH cache ways, 44 B per pixel, every load a full row segment) while wave t - 1
+// advances sweep t on row s - 2t + 1, so a row's values cross the fabric once per T sweeps instead of once per sweep,
+// and the cache ways of a pixel are fetched once however the pixel alternates between them.  The levels are two rows
+// apart, so within a step no wave needs what another one writes: one workgroup barrier per step, none inside.  The
+// state lives in T rings of 4 rows in LDS (E / W neighbours come from the ring), the cache entries of the 2T + 1 rows
+// in flight beside them; no tile load phase.  Redundant work: T columns either side of a strip (64 / (64 - 2T)) and
+// T (T - 1) row updates per chunk.  The region that sweep t can compute shrinks by one pixel per sweep from the staged
+// region (a trapezoid in space-time); pixels outside it copy through and are never consumed by a valid update.  Rows
+// and columns on the margin border (never updated by the reference, .cpp:592,608) copy through at every level.
+// Cache misses (rare once the iteration has settled, which is when this kernel is used) are served by the lane
+// itself; the new entry lives in LDS for the rest of the launch and goes to the update list that k_refine_apply
+// scatters afterwards (another strip may be staging the same pixel's entries at that moment: an in-place write could
+// be read torn).  At most one record per (pixel, way) and launch, so k_refine_apply never sees two writers of a slot.
+// Values are those of T single sweeps, bit for bit (tests/test_gpu_parity.py).
+template <int T, int TOP>
+__global__ __launch_bounds__(64 * T) void k_refine_skew(StageArgs a) {
+    constexpr int NE = 2 * T + 1;  // rows of cache entries resident: row r is staged in step r - 1 and last used in step r + 2T - 1
+    constexpr int UW = 64 - 2 * T; // columns a strip owns
+    __shared__ double s_d[T][4][66];       // [level][row & 3][lane + 1]
+    __shared__ double2 s_ent[NE][2][64];   // [row slot][way][lane] = (pwp, delta)
+    __shared__ uint32_t s_key[NE][64];     // key of way 0 | key of way 1 << 16
+    __shared__ uint8_t s_emit[NE][64];     // bit way: this launch already listed a new entry for that cache slot
+    const DirArgs &d = a.d[blockIdx.z];
+    const int W = a.W, H = a.H;
+    const int XL = d.own.XL, XR = d.own.XR, YL = d.own.YL, YR = d.own.YR;
+    const int xa = XL + 1 + (int)blockIdx.x * UW, xb = min(xa + UW, XR);                 // owned columns [xa, xb)
+    const int ya = YL + 1 + (int)blockIdx.y * a.skew_rows, yb = min(ya + a.skew_rows, YR); // owned rows [ya, yb)
+    if (xa >= XR || ya >= YR) return; // workgroup-uniform
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = wid + 1; // this wave's sweep within the launch
+    const int x = xa - T + lane;
+    const int xc = min(max(x, 0), W - 1);
+    const int y0 = max(YL, ya - T), y1 = min(YR, yb - 1 + T); // staged rows [y0, y1]
+    const double *__restrict__ in = d.f64_a;
+    double *__restrict__ out = d.f64_b;
+    const size_t way1 = a.rf_stride;
+    const bool xown = x >= xa && x < xb;
+    const unsigned shard = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7u) & (RF_UPD_SHARDS - 1);
+    int32_t *cnt = a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS + shard;
+    // what sweep t can compute here
+    const int cy_lo = max(YL + 1, ya - (T - t)), cy_hi = min(YR - 1, yb - 1 + (T - t));
+    const int cx_lo = max(XL + 1, xa - (T - t)), cx_hi = min(XR - 1, xb - 1 + (T - t));
+    const bool colok = x >= cx_lo && x <= cx_hi;
+    // A row is loaded two steps before it is needed (its loads are issued in step row - 2, it goes to LDS at the end of
+    // step row - 1 and is first read in step row): one step of update math does not cover the memory latency under
+    // load.  Waves 0 and 1 take the even and the odd rows, so a wave's staging registers are busy for two steps and the
+    // loop stays rolled.
+    double nd = 0, np0 = 0, nq0 = 0, np1 = 0, nq1 = 0;
+    uint32_t nk0 = 0, nk1 = 0; // packed only when they go to LDS: nothing may consume a loaded value in the step that issues the load
+    const uint16_t *__restrict__ keys = (const uint16_t *)d.rf_key;
+    auto load_row = [&](int row) {
+        const size_t p = (size_t)row * W + xc;
+        nd = in[p];
+        nk0 = keys[p];
+        nk1 = keys[p + way1];
+        np0 = d.rf_pwp[p];
+        nq0 = d.rf_delta[p];
+        np1 = d.rf_pwp[p + way1];
+        nq1 = d.rf_delta[p + way1];
+    };
+    if (wid == (y0 & 1)) load_row(y0);
+#pragma unroll 1
+    for (int s = y0 - 1; s <= y1 + 2 * T - 1; s++) {
+        if (wid == (s & 1) && s + 2 <= y1) load_row(s + 2);
+        const int r = s - 2 * t + 1;
+        if (r >= y0 && r <= y1) { // wave-uniform
+            const double dC = s_d[t - 1][r & 3][lane + 1];
+            double val = dC;
+            if (r >= cy_lo && r <= cy_hi) { // wave-uniform: rows sweep t can compute here
+                const double dN = s_d[t - 1][(r - 1) & 3][lane + 1], dS = s_d[t - 1][(r + 1) & 3][lane + 1];
+                const double dE = s_d[t - 1][r & 3][lane + 2], dW = s_d[t - 1][r & 3][lane];
+                const bool lv = colok && dC != (double)NOMATCH; // .cpp:613
+                const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
+                                 (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
+                const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
+                const int way = rel & 1;
+                const int e = (r - y0) % NE;
+                const uint32_t kk = s_key[e][lane];
+                const int crel = (int)(int16_t)(way ? (kk >> 16) : (kk & 0xffffu));
+                double2 pd = s_ent[e][way][lane];
+                if (lv && mode != 0 && crel != rel) // miss: the lane computes its own data term
+                    skew_miss(a, d, W, H, x, r, rel, way, e, lane, xown && r >= ya && r < yb, cnt, shard, pd, s_ent[e][way], s_key[e], s_emit[e], kk);
+                if (lv) {
+                    if (mode != 0 && !(a.skew_exp & 2)) val = refine_update(mode, dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
+                    if (t == T && xown) out[(size_t)r * W + x] = val; // sweep T's computable rows are the owned rows
+                }
+            }
+            if (t < T) s_d[t][r & 3][lane + 1] = val;
+        }
+        if (wid == ((s + 1) & 1) && s + 1 <= y1) {
+            const int e = (s + 1 - y0) % NE;
+            s_d[0][(s + 1) & 3][lane + 1] = nd;
+            s_key[e][lane] = nk0 | (nk1 << 16);
+            s_emit[e][lane] = 0;
+            s_ent[e][0][lane] = make_double2(np0, nq0);
+            s_ent[e][1][lane] = make_double2(np1, nq1);
+        }
+        if (!(a.skew_exp & 4)) __syncthreads();
+    }
+}
+
+// T sweeps f64_a -> f64_b in one launch (a.flag3 = launch index, a.skew_rows = rows per chunk) + the launch that applies
+// its cache updates.  T in {2, 3, 4}.
+void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    int rows = 0, cols = 0;
+    for (int v = 0; v < a.ndir; v++) {
+        rows = max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
+        cols = max(cols, a.d[v].own.XR - a.d[v].own.XL - 1);
+    }
+    if (rows <= 0 || cols <= 0 || a.skew_rows <= 0) return;
+    const int uw = 64 - 2 * T;
+    const dim3 grid((cols + uw - 1) / uw, (rows + a.skew_rows - 1) / a.skew_rows, a.ndir);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    if (T == 2) {
+        if (a.flag) hipLaunchKernelGGL((k_refine_skew<2, 1>), grid, dim3(128), 0, st, a);
+        else hipLaunchKernelGGL((k_refine_skew<2, 0>), grid, dim3(128), 0, st, a);
+    } else if (T == 3) {
+        if (a.flag) hipLaunchKernelGGL((k_refine_skew<3, 1>), grid, dim3(192), 0, st, a);
+        else hipLaunchKernelGGL((k_refine_skew<3, 0>), grid, dim3(192), 0, st, a);
+    } else {
+        if (a.flag) hipLaunchKernelGGL((k_refine_skew<4, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_refine_skew<4, 0>), grid, dim3(256), 0, st, a);
+    }
+    if (ev1) (void)hipEventRecord(ev1, st);
+    hipLaunchKernelGGL(k_refine_apply, dim3(8, RF_UPD_SHARDS), dim3(256), 0, st, a);
 }
 
 void launch_refine_multi(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {

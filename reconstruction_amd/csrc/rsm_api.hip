@@ -123,6 +123,12 @@ struct rsm_ctx {
     int opt_refine_multi_from = 0;  // first sweep of a level that may run in the two-sweeps-per-launch kernel (0: never = default: measured slower, k_refine.hip)
     int opt_refine_multi_min_px = 400000; // ... at levels with at least this many margin pixels
     int opt_refine_band_rows = 0; // > 0: band height in rows, overrides refine_band_mb (tests)
+    int opt_refine_skew_from = 0;  // first sweep of a level that may run in the time-skewed kernel (k_refine_skew; 0: never)
+    int opt_refine_skew_T = 3;     // sweeps per time-skewed launch (2..4)
+    int opt_refine_skew_min_px = 400000; // ... at levels with at least this many margin pixels per direction
+    int opt_refine_skew_waves = 2048;    // waves a time-skewed launch aims at (sets the rows per chunk)
+    int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
+    int opt_refine_skew_exp = 0;         // timing experiments (StageArgs::skew_exp)
 
     // profiling
     bool profile = false;
@@ -458,6 +464,12 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
     else if (!strcmp(name, "refine_multi_from")) c->opt_refine_multi_from = (int)std::max(0LL, std::min(value, 100000LL));
     else if (!strcmp(name, "refine_multi_min_px")) c->opt_refine_multi_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
+    else if (!strcmp(name, "refine_skew_from")) c->opt_refine_skew_from = (int)std::max(0LL, std::min(value, 100000LL));
+    else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
+    else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
+    else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
+    else if (!strcmp(name, "refine_skew_exp")) c->opt_refine_skew_exp = (int)value;
+    else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
     else if (!strcmp(name, "refine_band_rows")) c->opt_refine_band_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
@@ -578,22 +590,26 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         }
         return bytes;
     };
-    auto launch = [&](int t, int lo, int hi, bool multi) { // sweep t (and t + 1 if multi) over the rows [lo, hi)
+    int nlaunch = 0;
+    auto launch = [&](int t, int lo, int hi, int multi) { // sweeps t .. t + (multi ? multi : 1) - 1 over the rows [lo, hi); multi = 2: k_refine_multi, < 0: k_refine_skew with T = -multi
+        const int skewT = multi < 0 ? -multi : 0;
+        if (skewT) multi = skewT;
         bind(t);
         a.row_lo = lo;
         a.row_hi = hi;
-        const bool timed = c && c->profile && top && (multi ? (launches & 7) == 4 || (launches & 7) == 5 : (launches & 7) == 4);
+        const bool timed = c && c->profile && top && (nlaunch++ & 7) == 4;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) { // every 8th sweep of the dominant kernel
             const int es = prof_slot(c, multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP);
             e0 = c->evpool[es].a;
             e1 = c->evpool[es].b;
             c->prof_launches[multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP] += 1;
-            c->prof_bytes[multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP] += (multi ? 2.0 : 1.0) * window_bytes(lo, hi);
+            c->prof_bytes[multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP] += (multi ? (double)multi : 1.0) * window_bytes(lo, hi);
         }
-        if (multi) launch_refine_multi(a, st, e0, e1);
+        if (skewT) launch_refine_skew(a, skewT, st, e0, e1);
+        else if (multi) launch_refine_multi(a, st, e0, e1);
         else launch_refine_sweep(a, st, e0, e1);
-        launches += multi ? 2 : 1;
+        launches += multi ? multi : 1;
         curB = !curB;
     };
     *final_in_B = false;
@@ -621,7 +637,22 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         if (multi) (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
         int nmulti = 0;
         // sweeps whose cache misses are deferred to k_refine_fixup (a lane per miss) instead of being served inside the sweep
-        const bool may_defer = c && c->opt_refine_defer_to > 0 && a.miss_list && !multi && px / a.ndir >= c->opt_refine_defer_min_px;
+        // settled sweeps of the large levels T per launch, time-skewed (k_refine_skew)
+        const bool skew = c && c->opt_refine_skew_from > 0 && a.upd_list && !multi && px / a.ndir >= c->opt_refine_skew_min_px;
+        const int skewT = skew ? c->opt_refine_skew_T : 0;
+        if (skew) {
+            (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
+            int rows = 1, strips = 0;
+            for (int v = 0; v < a.ndir; v++) {
+                rows = std::max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
+                strips += (std::max(1, a.d[v].own.XR - a.d[v].own.XL - 1) + (64 - 2 * skewT) - 1) / (64 - 2 * skewT);
+            }
+            const int chunks = std::max(1, c->opt_refine_skew_waves / std::max(1, strips));
+            a.skew_exp = c->opt_refine_skew_exp;
+            a.skew_rows = c->opt_refine_skew_rows > 0 ? c->opt_refine_skew_rows : std::max(4 * skewT, (rows + chunks - 1) / chunks);
+        }
+        int nskew = 0;
+        const bool may_defer = c && c->opt_refine_defer_to > 0 && a.miss_list && !multi && !skew && px / a.ndir >= c->opt_refine_defer_min_px;
         if (may_defer) (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
         int ndefer = 0;
         // the section that takes turns with the other contexts of this GPU starts once the sweeps have settled into pure
@@ -632,13 +663,17 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
             if (t >= turn_from && !held) held = heavy_begin(c, heavy_px, top);
             if (multi && t >= c->opt_refine_multi_from && t + 1 < iters) {
                 a.flag3 = nmulti++;
-                launch(t, 0, INT_MAX, true);
+                launch(t, 0, INT_MAX, 2);
                 t += 2;
+            } else if (skew && t >= c->opt_refine_skew_from && t + skewT <= iters) {
+                a.flag3 = nskew++;
+                launch(t, 0, INT_MAX, -skewT);
+                t += skewT;
             } else {
                 const bool defer = may_defer && t >= c->opt_refine_defer_from && t <= c->opt_refine_defer_to;
                 a.defer = defer;
                 if (defer) a.flag3 = ndefer++;
-                launch(t, 0, INT_MAX, false);
+                launch(t, 0, INT_MAX, 0);
                 if (defer) { // a.f64_a / f64_b are still bound as for the sweep
                     launch_refine_fixup(a, st);
                     launches++;
@@ -654,7 +689,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
                 const int lo = std::max(Y0 + j * B - u, Y0), hi = std::min(Y0 + (j + 1) * B - u, Y1);
                 if (lo >= hi) continue;
                 curB = (u & 1) == 0; // sweep u + 1 reads B for even u
-                launch(u + 1, lo, hi, false);
+                launch(u + 1, lo, hi, 0);
             }
         curB = (iters & 1) != 0;
     }
@@ -1326,6 +1361,21 @@ extern "C" int rsm_stage_median(rsm_ctx *c, int16_t *disp, const uint8_t *mask_o
     launch_fill_i16(a.d[0].d16_out, px, (int16_t)NOMATCH, c->stream);
     launch_median(a, c->stream);
     t.down(disp, a.d[0].d16_out, px);
+    return finish(c, t);
+}
+
+// The specified exp(-t) of DisparityRefine's smoothness weights (k_refine.hip: exp_neg) on an array: lets the parity
+// tests hold the device evaluation to the oracle's bit for bit over the whole argument range.
+extern "C" int rsm_stage_exp_neg(rsm_ctx *c, const double *t_in, int64_t n, double *out) {
+    if (!c || !t_in || !out || n < 0) return RSM_E_INVALID;
+    if (n == 0) return RSM_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return set_err(c, RSM_E_HIP, "hipSetDevice");
+    Tmp t(c);
+    const double *dt = t.up(t_in, (size_t)n);
+    double *dout = t.alloc<double>((size_t)n);
+    if (!t.ok) return finish(c, t);
+    launch_exp_neg(dt, dout, (long long)n, c->stream);
+    t.down(out, dout, (size_t)n);
     return finish(c, t);
 }
 

@@ -69,6 +69,8 @@ struct StageArgs {
     int defer;         // refine sweep: 1 = cache misses go to miss_list for k_refine_fixup instead of being served in the sweep
     RfMiss *miss_list; // RF_UPD_SHARDS regions of miss_cap records (counters: upd_cnt); nullptr = never defer
     int miss_cap;      // >= 1024 x the workgroups a shard can receive: a deferring sweep never overflows
+    int skew_rows;     // refine (k_refine_skew): rows per chunk
+    int skew_exp;      // timing experiments only (results invalid): 1 no staging loads, 2 no update math, 4 no barrier
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int opt_no_exact;               // skip k_ncc_exact (timing A/B only: ties then follow the integer form)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
@@ -106,6 +108,7 @@ void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, h
 // d16_in, mask_own -> BL, BR; emit_list: also fill rf_list / ncc_cnt with the pixels Rematch has to evaluate
 void launch_set_boundary(const StageArgs &a, hipStream_t st, bool emit_list = false);
 void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out (pre-filled NOMATCH)
+void launch_exp_neg(const double *t, double *out, long long n, hipStream_t st); // the specified exp(-t) (tests)
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
@@ -113,6 +116,8 @@ void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nu
 void launch_refine_fixup(const StageArgs &a, hipStream_t st);
 // TWO sweeps f64_a -> f64_b in one launch (a.flag3 = launch index) + the launch that applies its cache updates
 void launch_refine_multi(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// T (2..4) sweeps f64_a -> f64_b in one time-skewed launch (a.flag3 = launch index, a.skew_rows) + the cache-update launch
+void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // cloud: returns nothing; *d_npoints (device int64) receives the point count; `flags` = W*H bytes of scratch,
 // `blk` = launch_bad_blocks' map (CLOUD_BLOCKS(W,H) bytes)

@@ -82,3 +82,15 @@ test_oracle_order_constraint_on_the_gpu_box = cpu_side.test_order_constraint
 test_oracle_uniqueness_on_the_gpu_box = cpu_side.test_uniqueness_three_passes
 test_oracle_ncc_argmax_on_the_gpu_box = cpu_side.test_lowest_level_match_against_reference_scores
 test_oracle_high_level_argmax_on_the_gpu_box = cpu_side.test_high_level_match_against_reference_scores
+
+
+def test_hip_specified_exp_equals_the_oracle_bit_for_bit(ctx):
+    """DisparityRefine's only transcendental: the device evaluation of the specified exp(-t) (k_refine.hip: exp_neg; fma
+    chain + v_ldexp_f64) against the oracle's (explicit exponent arithmetic and one rounding multiply for subnormal
+    results) over 0.5 M arguments incl. every k switch point and the whole subnormal range -- equal bit patterns."""
+    from oracle import oracle as orc
+    from test_oracle_known_answers import exp_test_arguments
+    t = exp_test_arguments()
+    g, w = ctx.exp_neg(t), orc.exp_neg_array(t)
+    bad = g.view(np.int64) != w.view(np.int64)
+    assert not bad.any(), (int(bad.sum()), t[bad][:5], g[bad][:5], w[bad][:5])

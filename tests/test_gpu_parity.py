@@ -438,3 +438,35 @@ def test_refine_two_sweeps_per_launch_is_bit_identical(ctx, first):
     finally:
         ctx.set_option("refine_multi_from", 0)
         ctx.set_option("refine_multi_min_px", 400000)
+
+
+@pytest.mark.parametrize("T,first,rows", [(2, 1, 0), (3, 1, 7), (4, 1, 16), (3, 5, 0), (4, 9, 33), (2, 30, 12), (3, 2, 1000)])
+def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows):
+    """k_refine_skew (T Jacobi sweeps per launch: a wave streams down a 64-column strip with sweep t on row y - t, the
+    state rings and both cache ways in its LDS slice, cache updates deferred to the update list) from sweep `first` on
+    -- from the first cached sweep, where nearly every pixel misses, to the settled regime -- gives the single-sweep
+    result, i.e. the oracle's, bit for bit; chunk heights from 4T rows to the whole level, sweep counts that leave 0..T-1
+    single sweeps at the end."""
+    ctx.set_option("refine_skew_from", first)
+    ctx.set_option("refine_skew_T", T)
+    ctx.set_option("refine_skew_min_px", 0)
+    ctx.set_option("refine_skew_rows", rows)
+    try:
+        for name in ("s512x384_5levels", "s192x128_ellipse", "s320x160_occluded_neg_r4"):
+            cfg, rec, fin = stages(name)
+            for q in rec:
+                if q["stage"] != "refine":
+                    continue
+                k, v = q["level"], q["v"]
+                for iters in (q["iters"], q["iters"] - 1):
+                    want = q["out"] if iters == q["iters"] else orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
+                    g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
+                    assert np.array_equal(g, want), diff_report("skew T %d from %d rows %d %s L%d v%d iters %d" % (T, first, rows, name, k, v, iters), g, want)
+            res = ctx.match_pair(cfg)
+            for v in range(2):
+                assert np.array_equal(res.disparity[v], fin["disparity"][v])
+    finally:
+        ctx.set_option("refine_skew_from", 0)
+        ctx.set_option("refine_skew_T", 3)
+        ctx.set_option("refine_skew_min_px", 400000)
+        ctx.set_option("refine_skew_rows", 0)

@@ -167,3 +167,27 @@ def test_specified_exp_is_a_faithful_exp():
         worst = max(worst, abs(ia - ib))
     assert worst <= 1
     assert orc.exp_neg(0.0) == 1.0 and orc.exp_neg(746.0) == 0.0 and orc.exp_neg(1e300) == 0.0
+
+
+def exp_test_arguments():
+    """Arguments of the specified exp: dense over [0, 2], the whole range up to and beyond the underflow threshold, the
+    k switch points n * ln2 / 2 and their neighbours, the subnormal results (t in [708.4, 745.14]), tiny and huge t."""
+    rng = np.random.default_rng(7)
+    ln2 = float(np.log(2.0))
+    sw = np.arange(1, 2200) * (ln2 / 2)
+    return np.concatenate([rng.random(200000) * 2, rng.random(100000) * 40, rng.random(100000) * 800, 708.0 + rng.random(100000) * 38,
+                           10.0 ** rng.uniform(-300, 0, 20000), 10.0 ** rng.uniform(0, 300, 2000), np.arange(0, 800, 0.25),
+                           sw, np.nextafter(sw, 0), np.nextafter(sw, 1e9),
+                           [0.0, 5e-324, 1e-9, 0.34657359027997264, 0.3465735902799727, 708.3, 709.0, 710.0, 745.0, 745.13,
+                            745.13321910194110842, 745.1332191019412, 745.2, 1e19, 1e300, np.inf]])
+
+
+def test_specified_exp_does_not_depend_on_the_fma_implementation():
+    """Every step of orc_exp_neg is a correctly rounded operation, so the CPU instruction and the C library's fma() must
+    give the same bits (the property that makes the specification portable)."""
+    t = exp_test_arguments()
+    a, b = orc.exp_neg_array(t), orc.exp_neg_array(t, soft_fma=True)
+    assert np.array_equal(a.view(np.int64), b.view(np.int64))
+    assert a[np.isinf(t)].tolist() == [0.0] and (a >= 0).all() and (a <= 1).all()
+    ulp = np.abs(a.view(np.int64) - np.exp(-t).view(np.int64))
+    assert ulp.max() <= 1, ulp.max()

@@ -12,3 +12,4 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_W
 done
 python tests/tools/rocpd_pmc.py --filter=$filt $(find $base -name "*.db") > gpurun_out/pmc2_summary.csv 2>gpurun_out/pmc2_err.log
 cat gpurun_out/pmc2_summary.csv | head -60; tail -3 gpurun_out/pmc2_err.log
+rm -rf $base  # the .db files exceed what gpurun merges back
