@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="rsm_set_option name=value (tuning knobs)")
     ap.add_argument("--stage-events", type=int, default=0, help="1: per-stage events inside the timed region too")
+    ap.add_argument("--measure-traffic", type=int, default=1,
+                    help="1 (default, N = 1): two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one pair in a child process give "
+                         "roofline.traffic; 0: quote profiles/pmc_traffic.json while it still describes this kernel source")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -93,6 +97,12 @@ def main():
         c.upload_pair_device(cfg, [t.data_ptr() for t in t_img], [t.data_ptr() for t in t_msk])
         ctxs.append(c); cfgs.append(cfg); keep.append((t_img, t_msk))
     ctx, cfg = ctxs[0], cfgs[0]
+    if args.pmc_child:  # the profiled child of measure_traffic(): one pair, nothing else
+        ctx.run_pair()
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.close()
+        return
 
     # N > 1: every context free-runs its K steps on its own host thread exactly as at N = 1 (run -> pack the cloud as
     # 16-byte records), handing each step's records to this thread, which posts the fan-in gathers in a fixed order
@@ -221,30 +231,50 @@ def main():
         value = v_total / (dt / args.steps) / 1e6
         # ---- roofline of the dominant kernel: the top level's Jacobi sweep (k_refine_sweep<1>, one launch per sweep)
         # (hipEvents recorded by the library right around every 8th k_refine_sweep<1> launch, on its own stream)
-        multi = prof_acc.get("refine_multi_top", {"launches": 0})["launches"] > 0
-        top = prof_acc["refine_multi_top" if multi else "refine_light_top"]
-        kname = ("k_refine_multi<1> (DisparityRefine, two Jacobi sweeps per launch, top level)" if multi
-                 else "k_refine_sweep<1> (DisparityRefine Jacobi sweep, top level)")
+        # which kernel carries the top level's sweeps: k_refine_skew<T,1> (T time-skewed sweeps per launch, the default
+        # once the iteration has settled), k_refine_multi<1> (option) or the single-sweep k_refine_sweep<1>
+        light_b = prof_acc["refine_light_top"]["bytes"] / max(1, prof_acc["refine_light_top"]["launches"])
+        dom = "refine_light_top"
+        for k in ("refine_multi_top", "refine_skew_top"):
+            if prof_acc.get(k, {"launches": 0})["launches"] > 0:
+                dom = k
+        top = prof_acc[dom]
+        spl = int(round(top["bytes"] / max(1, top["launches"]) / light_b)) if light_b > 0 else 1  # sweeps per launch
+        kname = {"refine_skew_top": "k_refine_skew<%d,1> (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level)" % (spl, spl),
+                 "refine_multi_top": "k_refine_multi<1> (DisparityRefine, two Jacobi sweeps per launch, top level)",
+                 "refine_light_top": "k_refine_sweep<1,0> (DisparityRefine Jacobi sweep, top level)"}[dom]
+        multi = dom != "refine_light_top"
         launches = max(1, top["launches"])
         avg_ms = top["ms"] / launches
         bytes_per_launch = top["bytes"] / launches  # 16 B x 2 directions x P_top
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot share a run with the timing);
-        # the committed summary is only quoted while it still describes THIS kernel source and workload
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pj = json.load(f)
-            if pj.get("kernel_src_sha256") == kernel_src_sha() and pj.get("workload") == cfg.name and pj.get("kernel") == kname.split(" ")[0]:
-                traffic = pj["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        # HBM bytes per launch: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass, and neither can
+        # share a run with the timing) of one pair in a child process, summed per dispatch of the dominant kernel and
+        # corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2).  If the profiler is not usable here,
+        # the committed summary is quoted instead -- only while it still describes THIS kernel source and workload.
+        traffic, traffic_source, traffic_detail = None, None, None
+        if world == 1 and args.measure_traffic:
+            try:
+                traffic_detail = measure_traffic(kname.split(" ")[0], args)
+                traffic = traffic_detail["traffic_bytes_per_launch"]
+                traffic_source = "measured"
+            except Exception as e:  # noqa: BLE001
+                traffic_detail = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if traffic is None:
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pj = json.load(f)
+                if pj.get("kernel_src_sha256") == kernel_src_sha() and pj.get("workload") == cfg.name and pj.get("kernel") == kname.split(" ")[0]:
+                    traffic = pj["traffic_bytes_per_launch"]
+                    traffic_source = "quoted"
+            except Exception:
+                traffic = None
         stage_ms = {k: round(v["ms"], 3) for k, v in stage_prof.items()}  # one untimed step with stage events
         # the same kernel with the GPU to itself (the untimed single-pair run): what the other pair in flight costs it
-        alone = stage_prof["refine_multi_top" if multi else "refine_light_top"]
+        alone = stage_prof[dom]
         alone_ms = alone["ms"] / max(1, alone["launches"])
         alone_gbs = (alone["bytes"] / max(1, alone["launches"])) / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else 0.0
-        total_alg_bytes = sum(v["bytes"] for k, v in stage_prof.items() if k not in ("refine_light_top", "refine_multi_top"))
+        total_alg_bytes = sum(v["bytes"] for k, v in stage_prof.items() if k not in ("refine_light_top", "refine_multi_top", "refine_skew_top"))
         out = {
             "metric": "Mdisparities/s per GPU (11x11 NCC, 128 disp)" if args.config == "c2" else "Mdisparities/s",
             "value": round(value, 3), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
@@ -266,13 +296,18 @@ def main():
                                    "frac": round(alone_gbs / HBM_PEAK_GBS, 4),
                                    "note": "one pair in flight (untimed extra run): no other pair's kernels beside the launch"},
                          "launches_timed_per_step": launches // args.steps // F, "concurrent_pairs": F,
+                         "sweeps_per_launch": spl,
+                         # the first sweeps of the level (cache still filling) run one per launch in k_refine_sweep<1>
+                         "single_sweep_kernel": {"kernel": "k_refine_sweep<1>", "avg_launch_ms": round(prof_acc["refine_light_top"]["ms"] / max(1, prof_acc["refine_light_top"]["launches"]), 5),
+                                                 "alone_avg_launch_ms": round(stage_prof["refine_light_top"]["ms"] / max(1, stage_prof["refine_light_top"]["launches"]), 5)} if multi else None,
                          "sweeps_per_step": stage_prof["refine_sweep_top"]["launches"],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_pair_algorithmic_GB": round(total_alg_bytes / 1e9, 3),
                          "whole_pair_frac": round(total_alg_bytes * F / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
             "stage_ms_per_step": stage_ms,
         }
-        out["roofline"]["traffic_source"] = "quoted" if traffic else None  # quoted = profiles/pmc_traffic.json (separate --pmc passes)
+        out["roofline"]["traffic_source"] = traffic_source  # measured = this run's own --pmc passes; quoted = profiles/pmc_traffic.json
+        out["roofline"]["traffic_detail"] = traffic_detail
         if single is not None:
             out["value_single_pair"] = round(res.v_top / single / 1e6, 3)   # one pair in flight, inputs resident in HBM
             out["ms_single_pair"] = round(single * 1e3, 3)
@@ -320,6 +355,50 @@ def self_launch(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def measure_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` (a prefix of its name, e.g. k_refine_skew<4,1>): rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, one pass each with --kernel-trace only, of `bench.py --pmc-child` (one pair of the same workload
+    with the same options); counter values summed over the instances of a dispatch, averaged over the dispatches."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    want = kernel.replace(" ", "")
+    tmp = tempfile.mkdtemp(prefix="rsm_pmc_", dir="/tmp")
+    res = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--inflight", "1", "--config", args.config, "--no-cpu-baseline"]
+            for o in args.opt:
+                cmd += ["--opt", o]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            per = {}
+            for path in glob.glob(os.path.join(out, "**", "*.db"), recursive=True):
+                db = sqlite3.connect(path)
+                cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+                name_col = [c for c in cols if c in ("kernel_name", "name")][0]
+                for kn, cn, val, did in db.execute("select %s, counter_name, value, dispatch_id from counters_collection" % name_col):
+                    if cn == ctr and kn.replace("void ", "").replace(" ", "").startswith(want):
+                        per[(path, did)] = per.get((path, did), 0.0) + val
+                db.close()
+            if not per:
+                raise RuntimeError("no %s rows for %s" % (ctr, kernel))
+            res[ctr] = (sum(per.values()) / len(per), len(per))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    f, w = res["FETCH_SIZE"][0], res["WRITE_SIZE"][0]
+    return {"fetch_size_kib_per_launch": round(f, 1), "write_size_kib_per_launch": round(w, 1), "dispatches": res["FETCH_SIZE"][1],
+            "correction": "gfx950: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM), WRITE_SIZE as reported",
+            "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0}
 
 
 def kernel_src_sha():

@@ -53,6 +53,31 @@ __device__ __forceinline__ double exp_neg(double t) {
     return (t > 745.13321910194110842) ? 0.0 : v;     // underflow threshold of exp; also covers the saturated k
 }
 
+// exp_neg of two arguments with the two (independent) operation chains interleaved in program order: a 13-step Horner
+// chain of dependent fp64 fmas leaves the pipe idle between steps unless another wave fills in.  Same operations, same
+// values as two exp_neg calls.
+__device__ __forceinline__ void exp_neg2(double t1, double t2, double &w1, double &w2) {
+    const double ln2HI = 0x1.62e42feep-1, ln2LO = 0x1.a39ef35793c76p-33, invln2 = 0x1.71547652b82fep+0;
+    double r1 = -t1, r2 = -t2;
+    const int k1 = (int)__builtin_fma(invln2, r1, -0.5), k2 = (int)__builtin_fma(invln2, r2, -0.5);
+    const double tk1 = (double)k1, tk2 = (double)k2;
+    r1 = __builtin_fma(-tk1, ln2HI, r1);
+    r2 = __builtin_fma(-tk2, ln2HI, r2);
+    r1 = __builtin_fma(-tk1, ln2LO, r1);
+    r2 = __builtin_fma(-tk2, ln2LO, r2);
+    double p1 = 0x1.6124613a86d09p-33, p2 = 0x1.6124613a86d09p-33;
+#define RF_H(c)                      \
+    p1 = __builtin_fma(p1, r1, (c)); \
+    p2 = __builtin_fma(p2, r2, (c));
+    RF_H(0x1.1eed8eff8d898p-29) RF_H(0x1.ae64567f544e4p-26) RF_H(0x1.27e4fb7789f5cp-22) RF_H(0x1.71de3a556c734p-19)
+    RF_H(0x1.a01a01a01a01ap-16) RF_H(0x1.a01a01a01a01ap-13) RF_H(0x1.6c16c16c16c17p-10) RF_H(0x1.1111111111111p-7)
+    RF_H(0x1.5555555555555p-5) RF_H(0x1.5555555555555p-3) RF_H(0x1.0000000000000p-1) RF_H(1.0) RF_H(1.0)
+#undef RF_H
+    const double v1 = __builtin_ldexp(p1, k1), v2 = __builtin_ldexp(p2, k2);
+    w1 = (t1 > 745.13321910194110842) ? 0.0 : v1;
+    w2 = (t2 > 745.13321910194110842) ? 0.0 : v2;
+}
+
 // test entry: the specified exp on an array (rsm_stage_exp_neg)
 __global__ void k_exp_neg(const double *t, double *out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,11 +117,26 @@ __device__ __forceinline__ double refine_update(int mode, double dC, double dE, 
     if (mode == 2) return (pdp * pwp + ws * (dN + dS) / 2) / (pwp + ws); // .cpp:661
     const double ex = fabs(dE - dC) - fabs(dW - dC);
     const double ey = fabs(dS - dC) - fabs(dN - dC);
-    const double wx = exp_neg(ex * ex); // .cpp:665-666
-    const double wy = exp_neg(ey * ey);
+    double wx, wy;
+    exp_neg2(ex * ex, ey * ey, wx, wy); // .cpp:665-666
     double ds;
     if (wx + wy == 0) ds = (dE + dW + dS + dN) / 4;
     else ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));
+    return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
+}
+
+// refine_update for mode 3 without a branch (k_refine_skew's straight-line path): the same operations on the same
+// operands; the quotient of the unused alternative is computed and discarded (0 / 0 when wx + wy == 0).
+__device__ __forceinline__ double refine_update3(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws) {
+    const double pdp = (pwp == 0) ? 0.0 : dC + delta;
+    const double ex = fabs(dE - dC) - fabs(dW - dC);
+    const double ey = fabs(dS - dC) - fabs(dN - dC);
+    double wx, wy;
+    exp_neg2(ex * ex, ey * ey, wx, wy); // .cpp:665-666
+    const double sw = wx + wy;
+    const double ds0 = (dE + dW + dS + dN) / 4;
+    const double ds1 = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
+    const double ds = (sw == 0) ? ds0 : ds1;
     return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
 }
 
@@ -660,7 +700,7 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
 // be read torn).  At most one record per (pixel, way) and launch, so k_refine_apply never sees two writers of a slot.
 // Values are those of T single sweeps, bit for bit (tests/test_gpu_parity.py).
 template <int T, int TOP>
-__global__ __launch_bounds__(64 * T) void k_refine_skew(StageArgs a) {
+__global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_refine_skew(StageArgs a) {
     constexpr int NE = 2 * T + 1;  // rows of cache entries resident: row r is staged in step r - 1 and last used in step r + 2T - 1
     constexpr int UW = 64 - 2 * T; // columns a strip owns
     __shared__ double s_d[T][4][66];       // [level][row & 3][lane + 1]
@@ -694,53 +734,69 @@ __global__ __launch_bounds__(64 * T) void k_refine_skew(StageArgs a) {
     double nd = 0, np0 = 0, nq0 = 0, np1 = 0, nq1 = 0;
     uint32_t nk0 = 0, nk1 = 0; // packed only when they go to LDS: nothing may consume a loaded value in the step that issues the load
     const uint16_t *__restrict__ keys = (const uint16_t *)d.rf_key;
+    const unsigned xcu0 = (unsigned)xc; // row pointers are wave-uniform, the column a 32-bit lane offset: no 64-bit address arithmetic per lane
     auto load_row = [&](int row) {
-        const size_t p = (size_t)row * W + xc;
-        nd = in[p];
-        nk0 = keys[p];
-        nk1 = keys[p + way1];
-        np0 = d.rf_pwp[p];
-        nq0 = d.rf_delta[p];
-        np1 = d.rf_pwp[p + way1];
-        nq1 = d.rf_delta[p + way1];
+        const size_t p = (size_t)row * W;
+        unsigned xcu = xcu0;
+        asm volatile("" : "+v"(xcu)); // keeps (array + column) from being hoisted into seven 64-bit lane addresses
+        nd = (in + p)[xcu];
+        nk0 = (keys + p)[xcu];
+        nk1 = (keys + p + way1)[xcu];
+        np0 = (d.rf_pwp + p)[xcu];
+        nq0 = (d.rf_delta + p)[xcu];
+        np1 = (d.rf_pwp + p + way1)[xcu];
+        nq1 = (d.rf_delta + p + way1)[xcu];
     };
     if (wid == (y0 & 1)) load_row(y0);
+    // This wave's row in step s is r = s - 2t + 1; e = (r - y0) % NE is kept as a counter.
+    int r = y0 - 2 * t, e = ((r - y0) % NE + NE) % NE;
 #pragma unroll 1
     for (int s = y0 - 1; s <= y1 + 2 * T - 1; s++) {
-        if (wid == (s & 1) && s + 2 <= y1) load_row(s + 2);
-        const int r = s - 2 * t + 1;
+        if (wid == (s & 1) && s + 2 <= y1 && !(a.skew_exp & 1)) load_row(s + 2);
         if (r >= y0 && r <= y1) { // wave-uniform
+            // one LDS round trip: the five state values, the keys and BOTH ways' entries (the way depends on dC)
             const double dC = s_d[t - 1][r & 3][lane + 1];
+            const double dN = s_d[t - 1][(r - 1) & 3][lane + 1], dS = s_d[t - 1][(r + 1) & 3][lane + 1];
+            const double dE = s_d[t - 1][r & 3][lane + 2], dW = s_d[t - 1][r & 3][lane];
+            const uint32_t kk = s_key[e][lane];
+            const double2 e0 = s_ent[e][0][lane], e1 = s_ent[e][1][lane];
             double val = dC;
             if (r >= cy_lo && r <= cy_hi) { // wave-uniform: rows sweep t can compute here
-                const double dN = s_d[t - 1][(r - 1) & 3][lane + 1], dS = s_d[t - 1][(r + 1) & 3][lane + 1];
-                const double dE = s_d[t - 1][r & 3][lane + 2], dW = s_d[t - 1][r & 3][lane];
                 const bool lv = colok && dC != (double)NOMATCH; // .cpp:613
-                const int mode = (int)(dE != (double)NOMATCH && dW != (double)NOMATCH) +
-                                 (int)(dS != (double)NOMATCH && dN != (double)NOMATCH) * 2; // .cpp:620
+                const bool ew = dE != (double)NOMATCH && dW != (double)NOMATCH, ns = dS != (double)NOMATCH && dN != (double)NOMATCH;
                 const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
                 const int way = rel & 1;
-                const int e = (r - y0) % NE;
-                const uint32_t kk = s_key[e][lane];
-                const int crel = (int)(int16_t)(way ? (kk >> 16) : (kk & 0xffffu));
-                double2 pd = s_ent[e][way][lane];
-                if (lv && mode != 0 && crel != rel) // miss: the lane computes its own data term
+                const int crel = (int)(int16_t)(kk >> (way << 4));
+                double2 pd = way ? e1 : e0;
+                if (lv && (ew || ns) && crel != rel && !(a.skew_exp & 8)) // miss: the lane computes its own data term
                     skew_miss(a, d, W, H, x, r, rel, way, e, lane, xown && r >= ya && r < yb, cnt, shard, pd, s_ent[e][way], s_key[e], s_emit[e], kk);
-                if (lv) {
-                    if (mode != 0 && !(a.skew_exp & 2)) val = refine_update(mode, dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
-                    if (t == T && xown) out[(size_t)r * W + x] = val; // sweep T's computable rows are the owned rows
+                if (!(a.skew_exp & 2)) {
+                    if (!__ballot(lv && !(ew && ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
+                        const double u = refine_update3(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
+                        val = lv ? u : dC;
+                    } else if (lv) {
+                        const int mode = (int)ew + (int)ns * 2; // .cpp:620
+                        if (mode != 0) val = refine_update(mode, dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
+                    }
+                }
+                if (t == T && lv && xown) { // sweep T's computable rows are the owned rows (xc == x there)
+                    unsigned xo = xcu0;
+                    asm volatile("" : "+v"(xo)); // no hoisted (and then spilled) 64-bit lane address
+                    (out + (size_t)r * W)[xo] = val;
                 }
             }
             if (t < T) s_d[t][r & 3][lane + 1] = val;
         }
         if (wid == ((s + 1) & 1) && s + 1 <= y1) {
-            const int e = (s + 1 - y0) % NE;
+            const int es = (s + 1 - y0) % NE;
             s_d[0][(s + 1) & 3][lane + 1] = nd;
-            s_key[e][lane] = nk0 | (nk1 << 16);
-            s_emit[e][lane] = 0;
-            s_ent[e][0][lane] = make_double2(np0, nq0);
-            s_ent[e][1][lane] = make_double2(np1, nq1);
+            s_key[es][lane] = nk0 | (nk1 << 16);
+            s_emit[es][lane] = 0;
+            s_ent[es][0][lane] = make_double2(np0, nq0);
+            s_ent[es][1][lane] = make_double2(np1, nq1);
         }
+        r++;
+        e = (e + 1 == NE) ? 0 : e + 1;
         if (!(a.skew_exp & 4)) __syncthreads();
     }
 }

@@ -38,14 +38,15 @@ enum Stage {
     ST_REFINE_SWEEP,     // all levels below the top
     ST_REFINE_SWEEP_TOP, // the top level's sweeps (light + worklist kernels)
     ST_REFINE_LIGHT_TOP, // only the k_refine_sweep<1> launches of the top level
-    ST_REFINE_MULTI_TOP, // only the k_refine_multi<1> launches of the top level (two sweeps each; the dominant kernel)
+    ST_REFINE_MULTI_TOP, // only the k_refine_multi<1> launches of the top level (two sweeps each)
+    ST_REFINE_SKEW_TOP,  // only the k_refine_skew<T,1> launches of the top level (T sweeps each; the dominant kernel)
     ST_UNIQ64,
     ST_CLOUD,
     ST_COUNT
 };
 static const char *kStageNames[ST_COUNT] = {"pyramid", "margin", "boxsum", "initial_match", "smooth", "order",
                                             "uniqueness_s16", "rematch", "median", "refine_init",
-                                            "refine_sweep", "refine_sweep_top", "refine_light_top", "refine_multi_top", "uniqueness_f64", "cloud"};
+                                            "refine_sweep", "refine_sweep_top", "refine_light_top", "refine_multi_top", "refine_skew_top", "uniqueness_f64", "cloud"};
 
 struct EvPair {
     hipEvent_t a, b;
@@ -123,10 +124,10 @@ struct rsm_ctx {
     int opt_refine_multi_from = 0;  // first sweep of a level that may run in the two-sweeps-per-launch kernel (0: never = default: measured slower, k_refine.hip)
     int opt_refine_multi_min_px = 400000; // ... at levels with at least this many margin pixels
     int opt_refine_band_rows = 0; // > 0: band height in rows, overrides refine_band_mb (tests)
-    int opt_refine_skew_from = 0;  // first sweep of a level that may run in the time-skewed kernel (k_refine_skew; 0: never)
-    int opt_refine_skew_T = 3;     // sweeps per time-skewed launch (2..4)
-    int opt_refine_skew_min_px = 400000; // ... at levels with at least this many margin pixels per direction
-    int opt_refine_skew_waves = 2048;    // waves a time-skewed launch aims at (sets the rows per chunk)
+    int opt_refine_skew_from = 38; // first sweep of a level that may run in the time-skewed kernel (k_refine_skew; 0: never): before that too many pixels still miss the data-term cache for its lane-serial miss service
+    int opt_refine_skew_T = 4;     // sweeps per time-skewed launch (2..4)
+    int opt_refine_skew_min_px = 2500000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
+    int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
     int opt_refine_skew_exp = 0;         // timing experiments (StageArgs::skew_exp)
 
@@ -600,11 +601,12 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         const bool timed = c && c->profile && top && (nlaunch++ & 7) == 4;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) { // every 8th sweep of the dominant kernel
-            const int es = prof_slot(c, multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP);
+            const int stg = skewT ? ST_REFINE_SKEW_TOP : multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP;
+            const int es = prof_slot(c, stg);
             e0 = c->evpool[es].a;
             e1 = c->evpool[es].b;
-            c->prof_launches[multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP] += 1;
-            c->prof_bytes[multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP] += (multi ? (double)multi : 1.0) * window_bytes(lo, hi);
+            c->prof_launches[stg] += 1;
+            c->prof_bytes[stg] += (multi ? (double)multi : 1.0) * window_bytes(lo, hi);
         }
         if (skewT) launch_refine_skew(a, skewT, st, e0, e1);
         else if (multi) launch_refine_multi(a, st, e0, e1);

@@ -9,16 +9,17 @@ run() {
   python -u bench.py --no-cpu-baseline --steps 6 --warmup 2 "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stage_ms_per_step']
-print('$*'.ljust(70), d['value'], d['ms_per_step'], 'single', d.get('ms_single_pair'), 'top', s['refine_sweep_top'], 'low', s['refine_sweep'], 'light', s['refine_light_top'], 'multi', s['refine_multi_top'], 'frac', d['roofline']['frac'], d['roofline'].get('alone',{}).get('avg_launch_ms'))"
+print('$*'.ljust(70), d['value'], d['ms_per_step'], 'single', d.get('ms_single_pair'), 'top', s['refine_sweep_top'], 'low', s['refine_sweep'], 'light', s['refine_light_top'], 'skew', s.get('refine_skew_top'), 'frac', d['roofline']['frac'], d['roofline'].get('alone',{}).get('avg_launch_ms'))"
 }
 {
 run
-for T in 2 3 4; do
-  for wv in 1024 2048; do
-    run --opt refine_skew_from=38 --opt refine_skew_T=$T --opt refine_skew_waves=$wv
-  done
-done
-run --opt refine_skew_from=38 --opt refine_skew_T=4 --opt refine_skew_waves=2048 --opt refine_skew_exp=2
+run --opt refine_skew_from=0
+run --opt refine_skew_from=30
+run --opt refine_skew_from=46
+run --opt refine_skew_from=54
+run --opt refine_skew_min_px=1000000
+run --opt refine_skew_min_px=1000000 --opt refine_skew_waves=640
+run --opt refine_skew_T=3
 run
 } > gpurun_out/skew_ab.log 2>&1
 cat gpurun_out/skew_ab.log
