@@ -6,7 +6,7 @@
    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path (ConstructPyrm -> MatchOneLayer x PyrmNum, both directions ->
-DisparityToCloud) over a batch of --inflight (2) stereo pairs per GPU, inputs already resident in HBM, followed (N > 1)
+DisparityToCloud) over a batch of --inflight (3) stereo pairs per GPU, inputs already resident in HBM, followed (N > 1)
 by the RCCL fan-in gather of the per-pair clouds to rank 0 (in flight while the next step's pairs are matched; all
 gathers complete inside the timed region).  Workload at every N: BASELINE.json
 configs[1] = C2 (4096x3072, 5 levels, 11x11 NCC, 128 disparities at the lowest level), differently-seeded pairs on
@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=["c2", "c2s", "c1", "c3", "c5"])
-    ap.add_argument("--inflight", type=int, default=2, help="pairs in flight per GPU (contexts run concurrently by rsm_run_pairs)")
+    ap.add_argument("--inflight", type=int, default=3, help="pairs in flight per GPU (contexts run concurrently by rsm_run_pairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="rsm_set_option name=value (tuning knobs)")
     ap.add_argument("--stage-events", type=int, default=0, help="1: per-stage events inside the timed region too")

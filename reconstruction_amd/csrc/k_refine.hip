@@ -653,17 +653,42 @@ __global__ __launch_bounds__(256) void k_refine_apply(StageArgs a) {
     }
 }
 
-// k_refine_skew's miss path: the lane computes its own data
-// term, installs it in the LDS copy of the cache row and -- for a pixel its workgroup owns, once per (pixel, way) and
-// launch -- appends it to the update list.
-__device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, int W, int H, int x, int r, int rel, int way, int e, int lane,
-                                       bool owned, int32_t *cnt, unsigned shard, double2 &pd, double2 *ent_row, uint32_t *key_row,
-                                       uint8_t *emit_row, uint32_t kk) {
-    refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, r, rel + x, pd.x, pd.y);
-    ent_row[lane] = pd;
-    key_row[lane] = way ? ((kk & 0xffffu) | ((uint32_t)(rel & 0xffff) << 16)) : ((kk & 0xffff0000u) | (uint32_t)(rel & 0xffff));
-    const unsigned fl = emit_row[lane];
-    const bool emit = owned && !((fl >> way) & 1u);
+// k_refine_skew's miss path, entered by the whole wave when any of its lanes misses.  A handful of misses per row is the
+// usual case once the iteration has settled: they are listed in LDS and computed four lanes per entry, 16 entries per
+// round (a third of the instructions of a lane computing its own).  The new entries are
+// installed in the LDS copy of the cache row and -- for pixels the workgroup owns, once per (pixel, way) and launch --
+// appended to the update list.
+__device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, int W, int H, int x, int x_lane0, int r, int rel, int way, int lane, bool miss,
+                                          bool owned, int32_t *cnt, unsigned shard, double2 (*ent_rows)[64], uint32_t *key_row,
+                                          uint8_t *emit_row, uint32_t kk, uint8_t *mlist) {
+    const unsigned long long mm = __ballot(miss);
+    const int n = __popcll(mm);
+    const int rank = __popcll(mm & ((1ull << lane) - 1ull));
+    if (miss) mlist[rank] = (uint8_t)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double2 pd = make_double2(0.0, 0.0);
+#pragma unroll 1
+    for (int done = 0; done < n; done += 16) { // 16 entries per round, four lanes each
+        const int j = done + (lane >> 2);
+        const int ml = mlist[j < n ? j : done]; // the lane this quad works for
+        const int mrel = __shfl(rel, ml);
+        const int mx = x_lane0 + ml;
+        double p, q;
+        refine_data_term_quad(d.img4_own, d.img4_oth, W, H, mx, r, mrel + mx, lane & 3, p, q);
+        // lane ml picks up the result of the quad that served it (every lane of a quad holds it)
+        const double mp = __shfl(p, (rank & 15) << 2), mq = __shfl(q, (rank & 15) << 2);
+        if (miss && rank >= done && rank < done + 16) {
+            pd.x = mp;
+            pd.y = mq;
+        }
+    }
+    if (miss) {
+        ent_rows[way][lane] = pd;
+        key_row[lane] = way ? ((kk & 0xffffu) | ((uint32_t)(rel & 0xffff) << 16)) : ((kk & 0xffff0000u) | (uint32_t)(rel & 0xffff));
+    }
+    const unsigned fl = miss ? emit_row[lane] : 0u;
+    const bool emit = miss && owned && !((fl >> way) & 1u);
     const unsigned long long em = __ballot(emit);
     if (em) {
         const int leader = __builtin_ctzll(em);
@@ -707,6 +732,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     __shared__ double2 s_ent[NE][2][64];   // [row slot][way][lane] = (pwp, delta)
     __shared__ uint32_t s_key[NE][64];     // key of way 0 | key of way 1 << 16
     __shared__ uint8_t s_emit[NE][64];     // bit way: this launch already listed a new entry for that cache slot
+    __shared__ uint8_t s_ml[T][64];        // per wave: the lanes of a row's misses, for the four-lanes-per-entry service
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W, H = a.H;
     const int XL = d.own.XL, XR = d.own.XR, YL = d.own.YL, YR = d.own.YR;
@@ -748,28 +774,80 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         nq1 = (d.rf_delta + p + way1)[xcu];
     };
     if (wid == (y0 & 1)) load_row(y0);
+    // Waves of different workgroups share a SIMD; with equal priorities they fall into step (all in their update math at
+    // once, sharing the pipe, then all waiting at once).  Unequal static priorities keep them staggered.
+    if (a.skew_prio) {
+        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned pr = (a.skew_prio == 1 ? id : a.skew_prio == 2 ? id >> 3 : a.skew_prio == 3 ? id >> 8 : a.skew_prio == 4 ? id >> 5 : id / 5u) & 3u;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
     // This wave's row in step s is r = s - 2t + 1; e = (r - y0) % NE is kept as a counter.
     int r = y0 - 2 * t, e = ((r - y0) % NE + NE) % NE;
+#ifdef RF_SKEW_TIMING
+    unsigned long long tm[5] = {0, 0, 0, 0, 0}, tq0, tq1;
+    int nsteps = 0;
+#define RF_TICK(i)                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    tq1 = __builtin_amdgcn_s_memtime();                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    tm[i] += tq1 - tq0;                                \
+    tq0 = tq1;
+#else
+#define RF_TICK(i)
+#endif
 #pragma unroll 1
     for (int s = y0 - 1; s <= y1 + 2 * T - 1; s++) {
+#ifdef RF_SKEW_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tq0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        nsteps++;
+#endif
         if (wid == (s & 1) && s + 2 <= y1 && !(a.skew_exp & 1)) load_row(s + 2);
+        RF_TICK(0) // staging loads issued
         if (r >= y0 && r <= y1) { // wave-uniform
             // one LDS round trip: the five state values, the keys and BOTH ways' entries (the way depends on dC)
-            const double dC = s_d[t - 1][r & 3][lane + 1];
-            const double dN = s_d[t - 1][(r - 1) & 3][lane + 1], dS = s_d[t - 1][(r + 1) & 3][lane + 1];
-            const double dE = s_d[t - 1][r & 3][lane + 2], dW = s_d[t - 1][r & 3][lane];
-            const uint32_t kk = s_key[e][lane];
-            const double2 e0 = s_ent[e][0][lane], e1 = s_ent[e][1][lane];
+            double dC, dN, dS, dE, dW;
+            uint32_t kk;
+            double2 e0, e1;
+            auto operands = [&]() {
+                dC = s_d[t - 1][r & 3][lane + 1];
+                dN = s_d[t - 1][(r - 1) & 3][lane + 1];
+                dS = s_d[t - 1][(r + 1) & 3][lane + 1];
+                dE = s_d[t - 1][r & 3][lane + 2];
+                dW = s_d[t - 1][r & 3][lane];
+                e0 = s_ent[e][0][lane];
+                e1 = s_ent[e][1][lane];
+                kk = s_key[e][lane];
+            };
+            operands();
             double val = dC;
+            RF_TICK(1) // LDS operands arrived
             if (r >= cy_lo && r <= cy_hi) { // wave-uniform: rows sweep t can compute here
                 const bool lv = colok && dC != (double)NOMATCH; // .cpp:613
                 const bool ew = dE != (double)NOMATCH && dW != (double)NOMATCH, ns = dS != (double)NOMATCH && dN != (double)NOMATCH;
                 const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
                 const int way = rel & 1;
                 const int crel = (int)(int16_t)(kk >> (way << 4));
-                double2 pd = way ? e1 : e0;
-                if (lv && (ew || ns) && crel != rel && !(a.skew_exp & 8)) // miss: the lane computes its own data term
-                    skew_miss(a, d, W, H, x, r, rel, way, e, lane, xown && r >= ya && r < yb, cnt, shard, pd, s_ent[e][way], s_key[e], s_emit[e], kk);
+                const bool miss = lv && (ew || ns) && crel != rel && !(a.skew_exp & 8);
+                // (keeps both entry reads in the first LDS batch: they are dead on the miss path, which reloads them, and
+                // would otherwise sink below it and add a second LDS round trip to every row)
+                asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
+                if (__ballot(miss)) { // wave-uniform, rare
+                    skew_miss(a, d, W, H, x, xa - T, r, rel, way, lane, miss, xown && r >= ya && r < yb, cnt, shard, s_ent[e], s_key[e], s_emit[e], kk, s_ml[wid]);
+                    // the operands come from LDS again (the entries now with the new ones) instead of living in
+                    // registers across the data-term routine: the common path keeps its 96 registers unspilled
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    operands();
+                    // (pins the reloads inside this rare block: merged into the join below they would run for every row)
+                    asm volatile("" : "+v"(dC), "+v"(dN), "+v"(dS), "+v"(dE), "+v"(dW), "+v"(kk));
+                    asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
+                    val = dC;
+                }
+                const double2 pd = way ? e1 : e0;
                 if (!(a.skew_exp & 2)) {
                     if (!__ballot(lv && !(ew && ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
                         const double u = refine_update3(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
@@ -787,6 +865,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             }
             if (t < T) s_d[t][r & 3][lane + 1] = val;
         }
+        RF_TICK(2) // update math + result write
         if (wid == ((s + 1) & 1) && s + 1 <= y1) {
             const int es = (s + 1 - y0) % NE;
             s_d[0][(s + 1) & 3][lane + 1] = nd;
@@ -797,8 +876,15 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         }
         r++;
         e = (e + 1 == NE) ? 0 : e + 1;
+        RF_TICK(3) // staged row written to LDS (waits for its loads)
         if (!(a.skew_exp & 4)) __syncthreads();
+        RF_TICK(4) // barrier
     }
+#ifdef RF_SKEW_TIMING
+    if (TOP && lane == 0 && a.flag3 == 12 && blockIdx.z == 0 && (blockIdx.x % 9) == 4 && (blockIdx.y % 5) == 2)
+        printf("skewtime wg %d %d wave %d steps %d: issue %llu lds %llu math %llu stage %llu barrier %llu\n", (int)blockIdx.x, (int)blockIdx.y, wid, nsteps,
+               tm[0] / nsteps, tm[1] / nsteps, tm[2] / nsteps, tm[3] / nsteps, tm[4] / nsteps);
+#endif
 }
 
 // T sweeps f64_a -> f64_b in one launch (a.flag3 = launch index, a.skew_rows = rows per chunk) + the launch that applies

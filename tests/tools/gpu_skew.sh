@@ -13,13 +13,11 @@ print('$*'.ljust(70), d['value'], d['ms_per_step'], 'single', d.get('ms_single_p
 }
 {
 run
-run --opt refine_skew_from=0
-run --opt refine_skew_from=30
-run --opt refine_skew_from=46
-run --opt refine_skew_from=54
-run --opt refine_skew_min_px=1000000
-run --opt refine_skew_min_px=1000000 --opt refine_skew_waves=640
-run --opt refine_skew_T=3
-run
+run --inflight 3
+run --inflight 3 --opt heavy_exclusive=0
+run --inflight 4
+run --inflight 4 --opt heavy_exclusive=0
+run --inflight 2 --opt heavy_exclusive=0
+run --inflight 3
 } > gpurun_out/skew_ab.log 2>&1
 cat gpurun_out/skew_ab.log
