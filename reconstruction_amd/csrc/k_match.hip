@@ -466,13 +466,17 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_wide(StageArgs a, int mode) {
     const int count = *a.ncc_cnt;
     const int W = a.W;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // 256 list entries at a time: every thread looks at one and keeps it unless its row belongs to the row kernel (a frame
-    // of wide pixels is 12.5 M entries to skip: one entry per workgroup and iteration -- two dependent loads -- was 11 ms)
-    for (int base = blockIdx.x * NCC_TX; base < count; base += gridDim.x * NCC_TX) { // uniform
+    // Up to 256 list entries at a time: every thread looks at one and keeps it unless its row belongs to the row kernel (a
+    // frame of wide pixels is 12.5 M entries to skip: one entry per workgroup and iteration -- two dependent loads -- was
+    // 11 ms).  The chunk shrinks with the list, so that a short list of kept pixels (each costs its workgroup a whole
+    // candidate scan) still spreads over the grid: with fixed 256-entry chunks a 20 k-entry list kept 80 workgroups busy with
+    // up to 256 scans each (C3's elliptic masks: 4.4 ms instead of 0.3).
+    const int chunk = min(NCC_TX, max(1, (count + (int)gridDim.x - 1) / (int)gridDim.x));
+    for (int base = blockIdx.x * chunk; base < count; base += gridDim.x * chunk) { // uniform
     __syncthreads();
     if (tid == 0) s_nitems = 0;
     __syncthreads();
-    if (base + tid < count) {
+    if (tid < chunk && base + tid < count) {
         const uint32_t e0 = a.rf_list[base + tid];
         const int y0 = (int)((e0 & 0x7fffffffu) / W);
         if (a.opt_no_rowgemm == 1 || a.wrow[(e0 >> 31) * a.H + y0] < RG_MIN) s_items[atomicAdd(&s_nitems, 1)] = e0;
