@@ -763,6 +763,9 @@ __global__ __launch_bounds__(256) void k_ncc_exact(StageArgs a, int mode) {
 #define RG_PX (4 * 16 * RG_T)   // pixels per workgroup: 4 waves x RG_T tiles
 #define RG_CC 512 // candidates per staged chunk (the staging latency is exposed once per chunk)
 typedef int rg_v4i __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) RgQuad {
+    uint32_t a, b, c, d;
+};
 // the rows of a direction with at least RG_MIN wide pixels, in order: wrow[2H + dir (H + 1)] = count, then the rows
 __global__ __launch_bounds__(64) void k_rg_rows(StageArgs a) {
     const DirArgs &d = a.d[blockIdx.x];
@@ -858,12 +861,14 @@ __global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
         }
         for (int lo = cmin; lo <= cmax; lo += RG_CC) { // uniform (no trip when the chunk holds no wide pixel)
             __syncthreads();
-            for (int i = tid; i < SB; i += 256) {
+            // only the 64-candidate blocks the chunk really has are staged (a 257-candidate row fills half a chunk)
+            const int ncs = min(RG_CC, (cmax - lo + 64) & ~63);
+            for (int i = tid; i < ncs + 4 * PQ; i += 256) {
                 const int col = lo - R + i;
 #pragma unroll
                 for (int j = 0; j < WS; j++) sB[j * SB + i] = ((col >= 0 && col < W) ? d.img4_oth[(size_t)(y - R + j) * W + col] : 0u) ^ 0x00808080u;
             }
-            for (int ci = tid; ci < RG_CC; ci += 256) {
+            for (int ci = tid; ci < ncs; ci += 256) {
                 const int c = lo + ci;
                 const bool ok = c <= cmax && c >= R && c <= W - 1 - R && d.mask_oth[(size_t)y * W + c] == 255; // .cpp:209
                 const size_t o = (size_t)y * W + (ok ? c : min(max(lo, 0), W - 1));
@@ -887,17 +892,23 @@ __global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
                 for (int ks = 0; ks < KS; ks++) {
                     const int p = 4 * ks + lg, j = min(p / PQ, WS - 1), q = p % PQ;
                     rg_v4i fa[RG_T], fb[4];
+                    // a K piece = four consecutive dwords of a staged row: one 16-byte load (two ds_read2_b32: the start is
+                    // only dword-aligned), the own-view piece masked where it runs past the window (or past the last piece)
+                    const bool live = p < NP;
 #pragma unroll
                     for (int t = 0; t < RG_T; t++) {
                         const int xl = wv * (16 * RG_T) + t * 16 + lr;
-#pragma unroll
-                        for (int m = 0; m < 4; m++) fa[t][m] = (p < NP && 4 * q + m < WS) ? (int)sA[j * SA + xl + 4 * q + m] : 0;
+                        const RgQuad v = *(const RgQuad *)&sA[j * SA + xl + 4 * q];
+                        fa[t][0] = live ? (int)v.a : 0;
+                        fa[t][1] = (live && 4 * q + 1 < WS) ? (int)v.b : 0;
+                        fa[t][2] = (live && 4 * q + 2 < WS) ? (int)v.c : 0;
+                        fa[t][3] = (live && 4 * q + 3 < WS) ? (int)v.d : 0;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int cl = cb * 64 + u * 16 + lr;
-#pragma unroll
-                        for (int m = 0; m < 4; m++) fb[u][m] = (p < NP) ? (int)sB[j * SB + cl + 4 * q + m] : 0;
+                        const RgQuad v = *(const RgQuad *)&sB[j * SB + cl + 4 * q];
+                        fb[u] = rg_v4i{(int)v.a, (int)v.b, (int)v.c, (int)v.d}; // (a dead piece is zeroed on the own-view side)
                     }
 #pragma unroll
                     for (int t = 0; t < RG_T; t++)
