@@ -125,8 +125,8 @@ __device__ __forceinline__ double refine_update(int mode, double dC, double dE, 
     return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
 }
 
-// refine_update for mode 3 without a branch (k_refine_skew's straight-line path): the same operations on the same
-// operands; the quotient of the unused alternative is computed and discarded (0 / 0 when wx + wy == 0).
+// refine_update for mode 3 without a divergent branch (k_refine_skew's straight-line path, entered by all lanes): the same
+// operations on the same operands; where wx + wy == 0 the quotient is computed (0 / 0) and replaced.
 __device__ __forceinline__ double refine_update3(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws) {
     const double pdp = (pwp == 0) ? 0.0 : dC + delta;
     const double ex = fabs(dE - dC) - fabs(dW - dC);
@@ -134,9 +134,9 @@ __device__ __forceinline__ double refine_update3(double dC, double dE, double dW
     double wx, wy;
     exp_neg2(ex * ex, ey * ey, wx, wy); // .cpp:665-666
     const double sw = wx + wy;
-    const double ds0 = (dE + dW + dS + dN) / 4;
-    const double ds1 = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
-    const double ds = (sw == 0) ? ds0 : ds1;
+    double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
+    if (__ballot(sw == 0)) // both weights underflowed somewhere in the row (|ex|, |ey| > 27): .cpp:667-668, wave-uniform and rare
+        ds = (sw == 0) ? (dE + dW + dS + dN) / 4 : ds;
     return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
 }
 

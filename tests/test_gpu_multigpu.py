@@ -116,7 +116,7 @@ def test_bench_runs_with_two_ranks_on_the_gloo_stand_in(launcher):
     assert len(lines) == 1                      # ONE json line, from rank 0
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "roofline" in d
-    assert d["config"]["pairs_per_gpu"] == 2
+    assert d["config"]["pairs_per_gpu"] == 3  # bench.py's default --inflight
 
 
 def test_bench_refuses_to_measure_fewer_gpus_than_asked():

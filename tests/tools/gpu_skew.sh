@@ -13,11 +13,10 @@ print('$*'.ljust(70), d['value'], d['ms_per_step'], 'single', d.get('ms_single_p
 }
 {
 run
-run --inflight 3
-run --inflight 3 --opt heavy_exclusive=0
-run --inflight 4
-run --inflight 4 --opt heavy_exclusive=0
-run --inflight 2 --opt heavy_exclusive=0
-run --inflight 3
+run --opt refine_skew_waves=1024
+run --opt refine_skew_waves=1152
+run --opt refine_skew_waves=896
+run --opt refine_skew_waves=1024 --inflight 4
+run
 } > gpurun_out/skew_ab.log 2>&1
 cat gpurun_out/skew_ab.log

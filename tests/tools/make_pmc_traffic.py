@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""profiles/pmc_traffic.json from the PMC summary of tests/tools/gpu_profile_r02.sh (run on the GPU box), keyed by the hash of
-the dominant kernel's source so that bench.py stops quoting it once the kernel changes."""
+"""profiles/pmc_traffic.json from the PMC summary of tests/tools/gpu_profile_r03b.sh (run on the GPU box), keyed by the hash
+of the dominant kernel's source so that bench.py stops quoting it once the kernel changes.  Only a fallback: bench.py
+measures FETCH_SIZE / WRITE_SIZE of the dominant kernel itself (roofline.traffic_source = "measured")."""
 import csv
 import hashlib
 import json
@@ -8,11 +9,11 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_pmc_main_kernels.csv")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03b_pmc_main_kernels.csv")
 rows = list(csv.DictReader(open(src)))
 
 
-def get(c, k="void k_refine_sweep<1"):  # <1> in round 2, <1, 0> (TOP, DEFER) since round 3
+def get(c, k="void k_refine_skew<4, 1>"):
     r = [r for r in rows if r["kernel"].startswith(k) and r["counter"] == c][0]
     return float(r["mean"]), int(r["dispatches"])
 
@@ -23,14 +24,16 @@ hit, miss = get("TCC_HIT_sum")[0], get("TCC_MISS_sum")[0]
 h = hashlib.sha256()
 for fn in ("k_refine.hip", "rsm_dev.h"):
     h.update(open(os.path.join(ROOT, "reconstruction_amd", "csrc", fn), "rb").read())
-out = {"kernel": "k_refine_sweep<1>", "workload": "C2_4096x3072_r5_d128", "kernel_src_sha256": h.hexdigest(),
+out = {"kernel": "k_refine_skew<4,1>", "workload": "C2_4096x3072_r5_d128", "kernel_src_sha256": h.hexdigest(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python bench.py "
-                 "--no-cpu-baseline --steps 1 --warmup 0 --inflight 1; tests/tools/gpu_profile_r03.sh, summarised by "
-                 "tests/tools/rocpd_pmc.py -> " + os.path.relpath(src, ROOT),
+                 "--no-cpu-baseline --measure-traffic 0 --steps 1 --warmup 0 --inflight 1; tests/tools/gpu_profile_r03b.sh, "
+                 "summarised by tests/tools/rocpd_pmc.py -> " + os.path.relpath(src, ROOT) + ".  Only the fallback: bench.py "
+                 "measures the same two counters itself (roofline.traffic_source = measured)",
        "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "dispatches": nd,
-       "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: the counter tallies 128-byte requests at 64 "
-                     "bytes; calibrated in round 1 on a 37.7 MB device copy of the same run: FETCH_SIZE 18.4 MB); WRITE_SIZE as "
-                     "reported (92 MB of fp64 stores + the cache entries written on misses)",
+       "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section); a launch stages 44 B per pixel over 64 / 56 "
+                     "columns and (rows + 8) / rows rows = 608 MB at least, so the raw 412 MB cannot be the byte count; "
+                     "WRITE_SIZE as reported (92 MB of fp64 stores + 21 MB of scratch for the miss path's parked registers + "
+                     "the update list)",
        "traffic_bytes_per_launch": (2 * f + w) * 1024.0, "l2_hit_rate": round(hit / (hit + miss), 4)}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
