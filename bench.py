@@ -253,7 +253,11 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2).  If the profiler is not usable here,
         # the committed summary is quoted instead -- only while it still describes THIS kernel source and workload.
         traffic, traffic_source, traffic_detail = None, None, None
-        if world == 1 and args.measure_traffic:
+        # (not under a profiler of its own: a rocprofv3 inside a rocprofv3 run is not a supported arrangement)
+        profiled = any(k.startswith(("ROCPROF", "ROCPROFILER_", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if world == 1 and args.measure_traffic and profiled:
+            traffic_detail = {"skipped": "bench.py itself runs under a profiler"}
+        if world == 1 and args.measure_traffic and not profiled:
             try:
                 traffic_detail = measure_traffic(kname.split(" ")[0], args)
                 traffic = traffic_detail["traffic_bytes_per_launch"]
@@ -380,7 +384,7 @@ def measure_traffic(kernel, args):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k, None)
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             per = {}
             for path in glob.glob(os.path.join(out, "**", "*.db"), recursive=True):
                 db = sqlite3.connect(path)
