@@ -209,7 +209,6 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          sweeps (k_refine_skew): T (2..4, default 4) sweeps per launch from that sweep of a level on (default
  *                          38; 0 = never) at levels with at least min_px margin pixels per direction (default 1 M: the two
  *                          largest levels of a 12 MP pair), aiming at `waves` workgroups (default 1280) or `rows` rows per chunk
- *                          (`refine_skew_min_rows`: a lower bound on the chunk height)
  *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)
  *   "refine_defer_from" / "refine_defer_to" / "refine_defer_min_px"   sweeps whose data-term cache misses are listed and served
  *                          by a second kernel, a lane per miss, instead of inside the sweep (to = 0 = never, default)

@@ -774,17 +774,15 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         nq1 = (d.rf_delta + p + way1)[xcu];
     };
     if (wid == (y0 & 1)) load_row(y0);
-    // Waves of different workgroups share a SIMD; with equal priorities they fall into step (all in their update math at
-    // once, sharing the pipe, then all waiting at once).  Unequal static priorities keep them staggered.
-    if (a.skew_prio) {
-        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned pr = (a.skew_prio == 1 ? id : a.skew_prio == 2 ? id >> 3 : a.skew_prio == 3 ? id >> 8 : a.skew_prio == 4 ? id >> 5 : id / 5u) & 3u;
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
     // This wave's row in step s is r = s - 2t + 1; e = (r - y0) % NE is kept as a counter.
     int r = y0 - 2 * t, e = ((r - y0) % NE + NE) % NE;
+// Timing experiments (results invalid; -DRF_SKEW_EXP=bits: 1 no staging loads, 2 no update math, 4 no barrier, 8 misses
+// ignored) and the per-phase shader-clock split (-DRF_SKEW_TIMING) exist at compile time only: DESIGN.md 4 quotes them.
+#ifdef RF_SKEW_EXP
+#define RF_EXP(b) ((RF_SKEW_EXP) & (b))
+#else
+#define RF_EXP(b) 0
+#endif
 #ifdef RF_SKEW_TIMING
     unsigned long long tm[5] = {0, 0, 0, 0, 0}, tq0, tq1;
     int nsteps = 0;
@@ -805,7 +803,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         nsteps++;
 #endif
-        if (wid == (s & 1) && s + 2 <= y1 && !(a.skew_exp & 1)) load_row(s + 2);
+        if (wid == (s & 1) && s + 2 <= y1 && !RF_EXP(1)) load_row(s + 2);
         RF_TICK(0) // staging loads issued
         if (r >= y0 && r <= y1) { // wave-uniform
             // one LDS round trip: the five state values, the keys and BOTH ways' entries (the way depends on dC)
@@ -831,7 +829,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
                 const int way = rel & 1;
                 const int crel = (int)(int16_t)(kk >> (way << 4));
-                const bool miss = lv && (ew || ns) && crel != rel && !(a.skew_exp & 8);
+                const bool miss = lv && (ew || ns) && crel != rel && !RF_EXP(8);
                 // (keeps both entry reads in the first LDS batch: they are dead on the miss path, which reloads them, and
                 // would otherwise sink below it and add a second LDS round trip to every row)
                 asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
@@ -848,7 +846,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     val = dC;
                 }
                 const double2 pd = way ? e1 : e0;
-                if (!(a.skew_exp & 2)) {
+                if (!RF_EXP(2)) {
                     if (!__ballot(lv && !(ew && ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
                         const double u = refine_update3(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
                         val = lv ? u : dC;
@@ -877,7 +875,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         r++;
         e = (e + 1 == NE) ? 0 : e + 1;
         RF_TICK(3) // staged row written to LDS (waits for its loads)
-        if (!(a.skew_exp & 4)) __syncthreads();
+        if (!RF_EXP(4)) __syncthreads();
         RF_TICK(4) // barrier
     }
 #ifdef RF_SKEW_TIMING

@@ -129,9 +129,6 @@ struct rsm_ctx {
     int opt_refine_skew_min_px = 1000000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
     int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
-    int opt_refine_skew_min_rows = 0;    // chunks are at least this high (a chunk pays 4T fill steps)
-    int opt_refine_skew_exp = 0;         // timing experiments (StageArgs::skew_exp)
-    int opt_refine_skew_prio = 0;        // static wave priorities per workgroup (StageArgs::skew_prio)
 
     // profiling
     bool profile = false;
@@ -471,9 +468,6 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
-    else if (!strcmp(name, "refine_skew_exp")) c->opt_refine_skew_exp = (int)value;
-    else if (!strcmp(name, "refine_skew_prio")) c->opt_refine_skew_prio = (int)value;
-    else if (!strcmp(name, "refine_skew_min_rows")) c->opt_refine_skew_min_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
     else if (!strcmp(name, "refine_band_rows")) c->opt_refine_band_rows = (int)std::max(0LL, std::min(value, 1000000LL));
@@ -654,9 +648,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
                 strips += (std::max(1, a.d[v].own.XR - a.d[v].own.XL - 1) + (64 - 2 * skewT) - 1) / (64 - 2 * skewT);
             }
             const int chunks = std::max(1, c->opt_refine_skew_waves / std::max(1, strips));
-            a.skew_exp = c->opt_refine_skew_exp;
-            a.skew_prio = c->opt_refine_skew_prio;
-            a.skew_rows = c->opt_refine_skew_rows > 0 ? c->opt_refine_skew_rows : std::max(std::max(4 * skewT, c->opt_refine_skew_min_rows), (rows + chunks - 1) / chunks);
+            a.skew_rows = c->opt_refine_skew_rows > 0 ? c->opt_refine_skew_rows : std::max(4 * skewT, (rows + chunks - 1) / chunks);
         }
         int nskew = 0;
         const bool may_defer = c && c->opt_refine_defer_to > 0 && a.miss_list && !multi && !skew && px / a.ndir >= c->opt_refine_defer_min_px;
