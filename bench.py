@@ -200,6 +200,11 @@ def main():
         t1 = time.perf_counter()
         ctx.download_pair()                      # both fp64 disparity maps + the cloud (fp64 xyz + BGR)
         d2h = time.perf_counter() - t1
+        pres = ctx.download_pair(pinned=True)    # the same into page-locked buffers (rsm_host_alloc), allocated once
+        t1 = time.perf_counter()
+        ctx.download_pair(into=pres)             # one DMA per buffer
+        d2h_pinned = time.perf_counter() - t1
+        del pres
         # the per-pair cloud filter on the cloud just made (statistical outlier removal k = 100 / 1 sigma +
         # radius-2.5 normals, CReconstruction.cpp:18), on the GPU, output = the RCCL payload without the outliers
         n_pts = ctx.n_points
@@ -318,6 +323,8 @@ def main():
             out["h2d_ms"] = round(h2d * 1e3, 2)
             out["d2h_ms"] = round(d2h * 1e3, 2)
             out["value_single_pair_pcie_inclusive"] = round(res.v_top / (single + h2d + d2h) / 1e6, 3)
+            out["d2h_ms_pinned"] = round(d2h_pinned * 1e3, 2)   # into page-locked buffers the caller keeps (rsm_host_alloc)
+            out["value_single_pair_pcie_inclusive_pinned"] = round(res.v_top / (single + h2d + d2h_pinned) / 1e6, 3)
             out["filter_ms"] = round(filt[0] * 1e3, 2)
             out["filter_points"] = {"in": int(n_pts), "kept": int(filt[1])}
         if world == 1 and args.config in ("c2", "c5"):

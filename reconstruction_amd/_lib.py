@@ -82,7 +82,7 @@ EXPORTS = [
     "rsm_stage_remap", "rsm_stage_erode_gray", "rsm_run_pairs", "rsm_run_pairs_repeat", "rsm_match_pairs", "rsm_match_pairs_multi_gpu",
     "rsm_pack_cloud16", "rsm_comm_unique_id", "rsm_comm_create", "rsm_comm_destroy", "rsm_comm_last_error",
     "rsm_gather_clouds", "rsm_gather_counts", "rsm_gather_meta_fill", "rsm_gather_plan", "rsm_comm_create_transport",
-    "rsm_filter_cloud", "rsm_filter_last_cloud",
+    "rsm_filter_cloud", "rsm_filter_last_cloud", "rsm_host_alloc", "rsm_host_free", "rsm_host_register", "rsm_host_unregister",
 ]
 
 _lib = None
@@ -102,6 +102,12 @@ def load():
     lib.rsm_version.restype = C.c_char_p
     lib.rsm_profile_stage_name.restype = C.c_char_p
     lib.rsm_destroy.restype = None
+    lib.rsm_host_alloc.restype = C.c_void_p
+    lib.rsm_host_alloc.argtypes = [C.c_size_t]
+    lib.rsm_host_free.restype = None
+    lib.rsm_host_free.argtypes = [C.c_void_p]
+    lib.rsm_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.rsm_host_unregister.argtypes = [C.c_void_p]
     lib.rsm_destroy.argtypes = [C.c_void_p]
     lib.rsm_comm_last_error.restype = C.c_char_p
     lib.rsm_comm_last_error.argtypes = [C.c_void_p]

@@ -22,6 +22,37 @@ from . import _lib
 from ._lib import Boundary, FilterParams, NOMATCH, PairIn, PairOut, RectifyIn, RectifyOut, RsmError  # noqa: F401
 
 
+class _Pinned:
+    """Owner of one rsm_host_alloc block (freed with the last array that views it)."""
+    def __init__(self, nbytes):
+        self._lib = _lib.load()
+        self.ptr = self._lib.rsm_host_alloc(C.c_size_t(max(1, nbytes)))
+        if not self.ptr:
+            raise RsmError(-3, "rsm_host_alloc(%d) failed" % nbytes)
+
+    def __del__(self):
+        try:
+            self._lib.rsm_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def host_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory (rsm_host_alloc): uploads from / downloads into it are single DMAs."""
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    own = _Pinned(n)
+    buf = (C.c_uint8 * max(1, n)).from_address(own.ptr)
+    buf._owner = own  # keeps the block alive as long as any view of `buf` lives
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
+def _filled(a, v):
+    a[...] = v
+    return a
+
+
 def _u8(a):
     return np.ascontiguousarray(a, dtype=np.uint8)
 
@@ -202,9 +233,23 @@ class Context:
     def run_pair(self):
         self._chk(self._lib.rsm_run_pair(self._h))
 
-    def download_pair(self, want_cloud=True, want_disparity=True) -> PairResult:
+    def download_pair(self, want_cloud=True, want_disparity=True, pinned=False, into=None) -> PairResult:
+        """pinned: the results land in page-locked arrays (host_empty) instead of pageable ones; into: a PairResult of an
+        earlier download of a result of the same size whose buffers are reused (no allocation)."""
         H, W = self._shape
-        d = [np.zeros((H, W), np.float64), np.zeros((H, W), np.float64)] if want_disparity else [None, None]
+        if into is not None:
+            pout = PairOut()
+            if want_disparity:
+                pout.disparity[0] = into.disparity[0].ctypes.data
+                pout.disparity[1] = into.disparity[1].ctypes.data
+            if want_cloud:
+                pout.max_points = into.xyz.shape[0]
+                pout.xyz = into.xyz.ctypes.data
+                pout.bgr = into.bgr.ctypes.data
+            self._chk(self._lib.rsm_download_pair(self._h, C.byref(pout)))
+            return into
+        new = (lambda shape, dt: host_empty(shape, dt)) if pinned else (lambda shape, dt: np.zeros(shape, dt))
+        d = [new((H, W), np.float64), new((H, W), np.float64)] if want_disparity else [None, None]
         pout = PairOut()
         if want_disparity:
             pout.disparity[0] = d[0].ctypes.data
@@ -213,8 +258,8 @@ class Context:
         pout.max_points = 0
         self._chk(self._lib.rsm_download_pair(self._h, C.byref(pout)))
         n = int(pout.n_points)
-        xyz = np.zeros((n, 3), np.float64)
-        bgr = np.zeros((n, 3), np.uint8)
+        xyz = new((n, 3), np.float64) if want_cloud else np.zeros((n, 3), np.float64)
+        bgr = new((n, 3), np.uint8) if want_cloud else np.zeros((n, 3), np.uint8)
         if want_cloud and n > 0:
             p2 = PairOut()
             p2.max_points = n
@@ -433,13 +478,14 @@ def run_pairs(ctxs, repeats=1):
         raise RsmError(st, "; ".join(m for m in msgs if m))
 
 
-def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True, timing=None):
+def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True, timing=None, pinned=False):
     """rsm_match_pairs: the pair loop of MatchAllLayer (.cpp:17-33) for a list of pair configs over a pool of
     contexts (same or different GPUs), pairs in flight together.  Returns (results in pair order, statuses).
     timing (optional dict) receives "call_s": seconds inside the C call alone (output buffers pre-faulted, the
-    slicing of the results outside)."""
+    slicing of the results outside).  pinned: the output buffers are page-locked (host_empty)."""
     lib = _lib.load()
     n = len(cfgs)
+    full = (lambda shape, v, dt=np.float64: _filled(host_empty(shape, dt), v)) if pinned else (lambda shape, v, dt=np.float64: np.full(shape, v, dt))
     ins = (PairIn * n)()
     outs = (PairOut * n)()
     keep, bufs = [], []
@@ -448,9 +494,9 @@ def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True, timing=None):
         ins[p] = pin
         keep.append(k)
         H, W = cfg.height, cfg.width
-        d = [np.full((H, W), 0.0), np.full((H, W), 0.0)] if want_disparity else [None, None]   # full(): pages touched now
-        xyz = np.full((W * H, 3), 0.0) if want_cloud else None
-        bgr = np.full((W * H, 3), 0, np.uint8) if want_cloud else None
+        d = [full((H, W), 0.0), full((H, W), 0.0)] if want_disparity else [None, None]   # full(): pages touched now
+        xyz = full((W * H, 3), 0.0) if want_cloud else None
+        bgr = full((W * H, 3), 0, np.uint8) if want_cloud else None
         if want_disparity:
             outs[p].disparity[0] = d[0].ctypes.data
             outs[p].disparity[1] = d[1].ctypes.data

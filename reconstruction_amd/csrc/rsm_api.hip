@@ -930,6 +930,28 @@ extern "C" int rsm_download_pair(rsm_ctx *c, rsm_pair_out *out) {
     return RSM_OK;
 }
 
+// Page-locked host memory for the buffers that cross the boundary.  The reference's pipeline keeps its images and results
+// in pageable cv::Mat memory (CManageData.cpp:75-78, CStereoMatching.cpp:682-761); a download into such memory goes through
+// the runtime's staging copy at ~10 GB/s (34 ms for a C2 pair's two fp64 maps and cloud), into page-locked memory it is one
+// DMA at the link's rate.  A cv::Mat can wrap memory from rsm_host_alloc (its user-data constructor), or memory the
+// caller already owns can be page-locked in place (rsm_host_register).
+extern "C" void *rsm_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void rsm_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+extern "C" int rsm_host_register(void *p, size_t bytes) {
+    if (!p || bytes == 0) return RSM_E_INVALID;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? RSM_OK : RSM_E_HIP;
+}
+extern "C" int rsm_host_unregister(void *p) {
+    if (!p) return RSM_E_INVALID;
+    return hipHostUnregister(p) == hipSuccess ? RSM_OK : RSM_E_HIP;
+}
+
 extern "C" int rsm_result_device(rsm_ctx *c, const double **d0, const double **d1, int64_t *n_points,
                                  const double **xyz, const uint8_t **bgr) {
     if (!c) return RSM_E_INVALID;

@@ -191,3 +191,37 @@ def test_pairs_in_flight_equal_sequential_runs():
     finally:
         for c in pool:
             c.close()
+
+
+def test_page_locked_host_buffers_give_the_same_results():
+    """rsm_host_alloc / rsm_host_register: results downloaded into page-locked buffers (and through the pair queue with
+    page-locked outputs) equal the pageable ones; a registered caller-owned buffer works and unregisters cleanly."""
+    import ctypes as C
+    from reconstruction_amd import Context, _lib, host_empty, match_pairs
+    cfgs = [synth.config_small(256, 160, 3, radius=3, offset=2, pair=p) for p in range(3)]
+    with Context(0) as ctx:
+        ctx.upload_pair(cfgs[0])
+        ctx.run_pair()
+        a, b = ctx.download_pair(), ctx.download_pair(pinned=True)
+        for v in range(2):
+            assert np.array_equal(a.disparity[v], b.disparity[v])
+        assert a.n_points == b.n_points and np.array_equal(a.xyz, b.xyz, equal_nan=True) and np.array_equal(a.bgr, b.bgr)
+    pool = [Context(0), Context(0)]
+    try:
+        r0, s0 = match_pairs(pool, cfgs)
+        r1, s1 = match_pairs(pool, cfgs, pinned=True)
+        assert s0 == s1 == [0, 0, 0]
+        for x, y in zip(r0, r1):
+            assert x.n_points == y.n_points and np.array_equal(x.xyz, y.xyz, equal_nan=True)
+            assert all(np.array_equal(x.disparity[v], y.disparity[v]) for v in range(2))
+    finally:
+        for c in pool:
+            c.close()
+    lib = _lib.load()
+    buf = np.zeros(1 << 20, np.uint8)
+    assert lib.rsm_host_register(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes)) == 0
+    assert lib.rsm_host_unregister(C.c_void_p(buf.ctypes.data)) == 0
+    assert lib.rsm_host_register(None, C.c_size_t(16)) != 0
+    h = host_empty((1000, 3), np.float64)
+    h[...] = 1.5
+    assert float(h.sum()) == 4500.0

@@ -3,14 +3,15 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reconstruction_amd import Context, match_pairs, synth
 cfgs = [synth.config_c3(pair=p) for p in range(10)]
-for nctx, disp in ((1, True), (2, True), (1, False), (2, False), (3, False)):
+for nctx, disp, pinned in ((1, True, False), (2, True, False), (2, False, False), (3, False, False), (2, True, True), (3, True, True), (2, False, True), (3, False, True)):
     pool = [Context(0) for _ in range(nctx)]
-    match_pairs(pool, cfgs[:nctx], want_cloud=True, want_disparity=disp)
+    match_pairs(pool, cfgs[:nctx], want_cloud=True, want_disparity=disp, pinned=pinned)
     tm = {}
-    res, st = match_pairs(pool, cfgs, want_cloud=True, want_disparity=disp, timing=tm)
+    res, st = match_pairs(pool, cfgs, want_cloud=True, want_disparity=disp, timing=tm, pinned=pinned)
     dt = tm["call_s"]
     v = sum(r.v_top for r in res)
-    print("C3 10 pairs, %d context(s), host buffers in/out (%s): %.1f ms per pair, %.1f Mdisp/s (PCIe-inclusive), statuses %s"
-          % (nctx, "cloud + both fp64 disparity maps" if disp else "cloud only", dt / 10 * 1e3, v / dt / 1e6, set(st)), flush=True)
+    print("C3 10 pairs, %d context(s), %s host buffers in/out (%s): %.1f ms per pair, %.1f Mdisp/s (PCIe-inclusive), statuses %s"
+          % (nctx, "page-locked OUTPUT," if pinned else "pageable", "cloud + both fp64 disparity maps" if disp else "cloud only", dt / 10 * 1e3, v / dt / 1e6, set(st)), flush=True)
+    del res
     for c in pool:
         c.close()
