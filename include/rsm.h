@@ -222,7 +222,9 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *   "refine_defer_from" / "refine_defer_to" / "refine_defer_min_px"   sweeps whose data-term cache misses are listed and served
  *                          by a second kernel, a lane per miss, instead of inside the sweep (to = 0 = never, default)
  *   "heavy_exclusive" = 0 | 1 | 2   contexts sharing a GPU: no turns / the top level's refine sweeps take turns (default) /
- *                          every large level's; "heavy_min_px", "heavy_from_sweep" bound the sections that take turns */
+ *                          every large level's; "heavy_min_px", "heavy_from_sweep" bound the sections that take turns;
+ *                          "heavy_lanes" = 2 (default): a level's single-sweep part (fabric-bound) and its time-skewed part
+ *                          (issue-bound) take turns separately, so one pair's may run beside the other kind of another pair's */
 int rsm_set_option(rsm_ctx *ctx, const char *name, long long value);
 
 /* ---- measurement ------------------------------------------------------------------------- */

@@ -97,6 +97,7 @@ struct rsm_ctx {
     uint8_t *blk = nullptr;                 // coarse bad-block map of the top-level mask (cloud erosion)
     hipEvent_t ev_cloudprep = nullptr;
     hipEvent_t ev_heavy = nullptr; // end of this context's last bandwidth-bound section (heavy_begin / heavy_end)
+    hipEvent_t ev_heavy2 = nullptr; // ... of its last issue-bound (time-skewed) section: lane 1
     int32_t *row_count = nullptr;
     int64_t *row_offset = nullptr;
     int64_t *d_npoints = nullptr;
@@ -117,6 +118,7 @@ struct rsm_ctx {
     int opt_no_rowgemm = 0;
     int opt_heavy_from_sweep = 1;  // ... from this sweep of the level on
     int opt_heavy_min_px = 400000; // ... from this many margin pixels on (smaller levels are launch-bound themselves)
+    int opt_heavy_lanes = 2;     // 2: the single-sweep part and the time-skewed part of a level's refine take turns separately (lanes 0 / 1)
     int opt_heavy_exclusive = 1; // refine sections of contexts sharing a GPU take turns (heavy_begin): 1 = the top level's, 2 = every large level's, 0 = none
     int opt_refine_defer_from = 4, opt_refine_defer_to = 0;  // sweeps whose cache misses go to k_refine_fixup (to = 0: never -- the default: measured slower)
     double opt_refine_defer_min_px = 1.0e6;                  // ... on levels with at least this many margin pixels per direction
@@ -153,30 +155,35 @@ struct rsm_ctx {
 // the other pair's second-largest level and full-size non-refine stages then run beside the top-level sweeps and fill
 // their launch tails, at the price of 158 us per top-level launch.
 #define RSM_MAX_DEVICES 64
-static std::mutex g_heavy_mu[RSM_MAX_DEVICES];
-static hipEvent_t g_heavy_last[RSM_MAX_DEVICES];
-static rsm_ctx *g_heavy_owner[RSM_MAX_DEVICES];
+static std::mutex g_heavy_mu[RSM_MAX_DEVICES][2];
+static hipEvent_t g_heavy_last[RSM_MAX_DEVICES][2];
+static rsm_ctx *g_heavy_owner[RSM_MAX_DEVICES][2];
 
-static bool heavy_begin(rsm_ctx *c, double pixels, bool top) {
+// lane 0: sections bound by the fabric (one sweep per launch); lane 1 (option heavy_lanes = 2): the time-skewed sections, bound
+// by fp64 issue -- a section of one kind runs well beside a section of the other kind of another pair
+static bool heavy_begin(rsm_ctx *c, double pixels, bool top, int lane = 0) {
     if (!c->opt_heavy_exclusive || pixels < (double)c->opt_heavy_min_px || c->device >= RSM_MAX_DEVICES) return false;
     if (c->opt_heavy_exclusive == 1 && !top) return false; // 1: only the top level's sweeps take turns
-    g_heavy_mu[c->device].lock();
-    if (g_heavy_last[c->device] && g_heavy_owner[c->device] != c) (void)hipStreamWaitEvent(c->stream, g_heavy_last[c->device], 0);
+    g_heavy_mu[c->device][lane].lock();
+    if (g_heavy_last[c->device][lane] && g_heavy_owner[c->device][lane] != c) (void)hipStreamWaitEvent(c->stream, g_heavy_last[c->device][lane], 0);
     return true;
 }
-static void heavy_end(rsm_ctx *c, bool held) {
+static void heavy_end(rsm_ctx *c, bool held, int lane = 0) {
     if (!held) return;
-    (void)hipEventRecord(c->ev_heavy, c->stream);
-    g_heavy_last[c->device] = c->ev_heavy;
-    g_heavy_owner[c->device] = c;
-    g_heavy_mu[c->device].unlock();
+    hipEvent_t ev = lane ? c->ev_heavy2 : c->ev_heavy;
+    (void)hipEventRecord(ev, c->stream);
+    g_heavy_last[c->device][lane] = ev;
+    g_heavy_owner[c->device][lane] = c;
+    g_heavy_mu[c->device][lane].unlock();
 }
 static void heavy_forget(rsm_ctx *c) { // the context goes away: nobody may wait on its event any more
     if (c->device >= RSM_MAX_DEVICES) return;
-    std::lock_guard<std::mutex> g(g_heavy_mu[c->device]);
-    if (g_heavy_owner[c->device] == c) {
-        g_heavy_owner[c->device] = nullptr;
-        g_heavy_last[c->device] = nullptr;
+    for (int lane = 0; lane < 2; lane++) {
+        std::lock_guard<std::mutex> g(g_heavy_mu[c->device][lane]);
+        if (g_heavy_owner[c->device][lane] == c) {
+            g_heavy_owner[c->device][lane] = nullptr;
+            g_heavy_last[c->device][lane] = nullptr;
+        }
     }
 }
 
@@ -240,7 +247,8 @@ extern "C" int rsm_create(rsm_ctx **out, int hip_device) {
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_cloudprep, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_heavy2, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return RSM_E_HIP;
     }
@@ -275,6 +283,7 @@ extern "C" void rsm_destroy(rsm_ctx *c) {
     (void)hipEventDestroy(c->ev_cloudprep);
     heavy_forget(c);
     (void)hipEventDestroy(c->ev_heavy);
+    (void)hipEventDestroy(c->ev_heavy2);
     for (int k = 0; k < RSM_MAX_LEVELS; k++) (void)hipEventDestroy(c->ev_prep[k]);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
@@ -455,6 +464,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
     else if (!strcmp(name, "heavy_from_sweep")) c->opt_heavy_from_sweep = (int)std::max(1LL, std::min(value, 100000LL));
     else if (!strcmp(name, "heavy_min_px")) c->opt_heavy_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
+    else if (!strcmp(name, "heavy_lanes")) c->opt_heavy_lanes = (int)std::max(1LL, std::min(value, 2LL));
     else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = (int)std::max(0LL, std::min(value, 2LL));
     else if (!strcmp(name, "no_rowgemm")) c->opt_no_rowgemm = value != 0 ? 1 : 0;
     else if (!strcmp(name, "refine_defer_from")) c->opt_refine_defer_from = (int)value;
@@ -657,14 +667,21 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         // the section that takes turns with the other contexts of this GPU starts once the sweeps have settled into pure
         // streaming: the first ones are busy computing data terms (VALU) and run well beside another pair's streaming sweeps
         bool held = false;
+        int lane = 0;
         const int turn_from = (c && heavy_px > 0.0) ? std::min(std::max(c->opt_heavy_from_sweep, 1), iters) : iters + 1;
         for (int t = 1; t < iters;) {
-            if (t >= turn_from && !held) held = heavy_begin(c, heavy_px, top);
+            const bool skew_now = skew && t >= c->opt_refine_skew_from && t + skewT <= iters;
+            if (c && c->opt_heavy_lanes == 2 && (int)skew_now != lane && t >= turn_from) { // the section changes kind: hand its lane on
+                heavy_end(c, held, lane);
+                held = false;
+                lane = (int)skew_now;
+            }
+            if (t >= turn_from && !held) held = heavy_begin(c, heavy_px, top, lane);
             if (multi && t >= c->opt_refine_multi_from && t + 1 < iters) {
                 a.flag3 = nmulti++;
                 launch(t, 0, INT_MAX, 2);
                 t += 2;
-            } else if (skew && t >= c->opt_refine_skew_from && t + skewT <= iters) {
+            } else if (skew_now) {
                 a.flag3 = nskew++;
                 launch(t, 0, INT_MAX, -skewT);
                 t += skewT;
@@ -681,7 +698,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
                 t += 1;
             }
         }
-        heavy_end(c, held);
+        heavy_end(c, held, lane);
     } else { // time-skewed bands: sweep u + 1 of band j reads what sweep u wrote, buffers alternate with u
         for (int j = 0; Y0 + j * B - (nsw - 1) < Y1; j++)
             for (int u = 0; u < nsw; u++) {
