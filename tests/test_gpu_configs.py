@@ -192,12 +192,14 @@ def test_pairs_in_flight_equal_sequential_runs():
         for c in pool:
             c.close()
 
+_KEEP = []
+
 
 def test_page_locked_host_buffers_give_the_same_results():
     """rsm_host_alloc / rsm_host_register: results downloaded into page-locked buffers (and through the pair queue with
     page-locked outputs) equal the pageable ones; a registered caller-owned buffer works and unregisters cleanly."""
     import ctypes as C
-    from reconstruction_amd import Context, _lib, host_empty, match_pairs
+    from reconstruction_amd import Context, PairResult, _lib, host_empty, match_pairs
     cfgs = [synth.config_small(256, 160, 3, radius=3, offset=2, pair=p) for p in range(3)]
     with Context(0) as ctx:
         ctx.upload_pair(cfgs[0])
@@ -218,8 +220,25 @@ def test_page_locked_host_buffers_give_the_same_results():
         for c in pool:
             c.close()
     lib = _lib.load()
-    buf = np.zeros(1 << 20, np.uint8)
+    # (page-aligned and kept for the life of the process: a range that was once registered is never handed back to the
+    # allocator, where a later download target could land on it)
+    import mmap
+    mm = mmap.mmap(-1, 1 << 20)
+    _KEEP.append(mm)
+    buf = np.frombuffer(mm, np.uint8)
     assert lib.rsm_host_register(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes)) == 0
+    ctx2 = Context(0)
+    try:
+        ctx2.upload_pair(cfgs[1])
+        ctx2.run_pair()
+        first = ctx2.download_pair()
+        into = PairResult(disparity=[np.frombuffer(mm, np.float64, 256 * 160, 0).reshape(160, 256),
+                                     np.frombuffer(mm, np.float64, 256 * 160, 256 * 160 * 8).reshape(160, 256)],
+                          margin=first.margin, n_points=0, xyz=np.zeros((0, 3)), bgr=np.zeros((0, 3), np.uint8), v_top=first.v_top)
+        ctx2.download_pair(want_cloud=False, into=into)      # straight into the registered range
+        assert all(np.array_equal(into.disparity[v], first.disparity[v]) for v in range(2))
+    finally:
+        ctx2.close()
     assert lib.rsm_host_unregister(C.c_void_p(buf.ctypes.data)) == 0
     assert lib.rsm_host_register(None, C.c_size_t(16)) != 0
     h = host_empty((1000, 3), np.float64)
