@@ -3,7 +3,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reconstruction_amd import Context, match_pairs, synth
 cfgs = [synth.config_c3(pair=p) for p in range(10)]
-for nctx, disp, pinned in ((1, True, False), (2, True, False), (2, False, False), (3, False, False), (2, True, True), (3, True, True), (2, False, True), (3, False, True)):
+import sys
+CASES = ((1, True, False), (2, True, False), (2, False, False), (3, False, False), (2, True, True), (3, True, True), (2, False, True), (3, False, True))
+if len(sys.argv) > 1:  # e.g. 4,0,1 5,0,1 : contexts, disparity maps too, page-locked outputs
+    CASES = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[1:])
+for nctx, disp, pinned in CASES:
     pool = [Context(0) for _ in range(nctx)]
     match_pairs(pool, cfgs[:nctx], want_cloud=True, want_disparity=disp, pinned=pinned)
     tm = {}

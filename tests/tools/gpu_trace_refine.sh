@@ -13,9 +13,9 @@ rows=list(cur.execute("select name, start, end from kernels order by start"))
 top=[(n,s,e) for n,s,e in rows if "k_refine_sweep<1" in n or "k_refine_skew<" in n and ", 1>" in n or "k_refine_first" in n]
 sw=[(n,s,e) for n,s,e in rows if "k_refine_sweep<1" in n]
 sk=[(n,s,e) for n,s,e in rows if "k_refine_skew<" in n and ", 1>" in n]
-per=37
+per=int("$NSW")
 print("single sweeps, last pair:", [round((e-s)/1000) for n,s,e in sw[-per:]])
-print("skew launches, last pair:", [round((e-s)/1000) for n,s,e in sk[-28:]])
+print("skew launches, last pair:", [round((e-s)/1000) for n,s,e in sk[-int("$NSK"):]])
 first=[(e-s)/1000 for n,s,e in rows if "k_refine_first" in n]
 print("k_refine_first:", [round(x) for x in first[-5:]])
 allk={}
