@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--measure-traffic", type=int, default=1,
                     help="1 (default, N = 1): two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one pair in a child process give "
                          "roofline.traffic; 0: quote profiles/pmc_traffic.json while it still describes this kernel source")
+    ap.add_argument("--adapter-pairs", type=int, default=6,
+                    help="pairs matched through the compiled C++ adapter (tests/cpp/adapter_bench.cpp) for value_adapter_pcie_inclusive; 0: skip")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -335,6 +337,14 @@ def main():
                 px = (cfg.width - 2 * r_) * (cfg.height - 2 * r_)
                 out["ncc_kernel"]["%dx%d_%d" % (2 * r_ + 1, 2 * r_ + 1, cands)] = {
                     "ms_per_launch": round(ms, 3), "MDE_per_s": round(px * cands / ms / 1e3, 1)}
+        if world == 1 and args.config in ("c2", "c3", "c5") and args.adapter_pairs > 0:
+            # the drop-in as a maintainer integrates it: the compiled C++ adapter's MatchAll (include/rsm_stereo_adapter.hpp),
+            # host images in, InsertPoint stream out, PCIe included -- never `value`
+            try:
+                out["adapter"] = adapter_bench(cfgs, args.adapter_pairs, F, int(res.v_top))
+                out["value_adapter_pcie_inclusive"] = out["adapter"]["value"]
+            except Exception as e:  # noqa: BLE001
+                out["adapter"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth)
         print(json.dumps(out), flush=True)
@@ -410,6 +420,48 @@ def measure_traffic(kernel, args):
     return {"fetch_size_kib_per_launch": round(f, 1), "write_size_kib_per_launch": round(w, 1), "dispatches": res["FETCH_SIZE"][1],
             "correction": "gfx950: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM), WRITE_SIZE as reported",
             "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0}
+
+
+def adapter_bench(cfgs, n_pairs, inflight, v_top):
+    """Builds tests/cpp/adapter_bench.cpp with g++ against the in-tree librsm_mi355.so and lets the C++ adapter's MatchAll
+    (RsmStereoAdapter, include/rsm_stereo_adapter.hpp: the pair loop of CStereoMatching.cpp:17-33 with pairs in flight,
+    page-locked result buffers, no disparity download) match `n_pairs` pairs -- this run's differently seeded pairs,
+    cycled -- from pageable host images to the InsertPoint stream.  Mdisparities/s = n_pairs * V_top / wall time."""
+    import shutil
+    import subprocess
+    import tempfile
+    from reconstruction_amd import _lib
+    gxx = shutil.which("g++")
+    if not gxx:
+        raise RuntimeError("no g++ on this box")
+    tmp = tempfile.mkdtemp(prefix="rsm_adapter_", dir="/tmp")
+    try:
+        exe = os.path.join(tmp, "adapter_bench")
+        libdir = os.path.dirname(_lib.LIB_PATH)
+        subprocess.run([gxx, "-std=c++11", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_bench.cpp"),
+                        "-o", exe, "-L" + libdir, "-lrsm_mi355", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib",
+                        "-Wl,--allow-shlib-undefined", "-pthread"], check=True, capture_output=True, timeout=120)
+        c0 = cfgs[0]
+        with open(os.path.join(tmp, "in.bin"), "wb") as f:
+            f.write(np.array([len(cfgs), c0.width, c0.height, c0.pyr_levels, c0.radius, c0.offset, c0.origin_width or c0.width, 0, -1], np.int32).tobytes())
+            f.write(np.array([c0.ws], np.float64).tobytes())
+            for c in cfgs:
+                f.write(np.asarray(c.Q, np.float64).tobytes() + np.asarray(c.R_final, np.float64).tobytes() + np.asarray(c.T_final, np.float64).tobytes())
+                for a in (c.image[0], c.image[1], c.mask[0], c.mask[1]):
+                    f.write(np.ascontiguousarray(a, np.uint8).tobytes())
+        env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        r = subprocess.run([exe, os.path.join(tmp, "in.bin"), str(n_pairs), str(inflight)], capture_output=True, text=True, env=env, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError("adapter_bench rc %d: %s" % (r.returncode, r.stderr[-200:]))
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        d["value"] = round(n_pairs * v_top / d["seconds"] / 1e6, 3)
+        d["ms_per_pair"] = round(d["seconds"] / n_pairs * 1e3, 3)
+        d["what"] = ("RsmStereoAdapter::MatchAll compiled from include/rsm_stereo_adapter.hpp: %d pairs, %d in flight, pageable host images "
+                     "in, page-locked fp64 clouds out, InsertPoint (float xyz push_back) per point and filter(pair) replayed in pair order; "
+                     "fp64 disparity maps not downloaded (the reference never reads them after CStereoMatching.cpp:29)" % (n_pairs, inflight))
+        return d
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def kernel_src_sha():

@@ -8,10 +8,19 @@
 //   #include "CStereoMatching.h"
 //   #include "CStereoMatchingMI355.hpp"
 //   ...
-//   static RsmStereoMI355 gpu(0);             // one per process and GPU
+//   void CStereoMatching::MatchAllLayer()         // the whole loop, .cpp:15-34, three pairs in flight on GPU 0
+//   {
+//       static RsmStereoMI355 gpu(0, 3);          // one per process and GPU
+//       // Rectify is private (CStereoMatching.h:49-50): a lambda written inside this member function may call it
+//       RsmCvTraits::rectify() = [](CStereoMatching &s, int CamPair) { s.Rectify(CamPair, s.Q); };   // .cpp:20
+//       std::vector<int> status(m_data->m_CampairNum);
+//       if (gpu.MatchAll(*this, m_data->m_CampairNum, status.data()) != m_data->m_CampairNum) printf("rsm: %s\n", gpu.LastError());
+//   }
+// or, keeping the reference's loop and replacing only its body (.cpp:21-31), one pair at a time:
+//   static RsmStereoMI355 gpu(0);
 //   for (int CamPair = 0; CamPair < m_data->m_CampairNum; CamPair++) {
 //       Rectify(CamPair, Q);                  // unchanged reference code (.cpp:20)
-//       if (!gpu.MatchPair(*this, CamPair)) printf("rsm: %s\n", gpu.LastError());   // replaces .cpp:21-31
+//       if (!gpu.MatchPair(*this, CamPair)) printf("rsm: %s\n", gpu.LastError());
 //   }
 #ifndef CSTEREOMATCHING_MI355_HPP
 #define CSTEREOMATCHING_MI355_HPP
@@ -29,6 +38,18 @@ struct RsmCvTraits {
     static int offset(Stereo &s) { return s.m_offset; }
     static int verbose(Stereo &s) { return s.Verbose; }
     static bool isoutput(Stereo &s) { return s.m_data->isoutput != 0; }
+    // MatchAll's per-pair preparation = CStereoMatching::Rectify(CamPair, Q) (.cpp:20, private): the member function that
+    // owns the loop installs it (see the header comment); it fills cam[pair][v].image / .mask / .P and Q, R_final, T_final
+    typedef void (*RectifyFn)(Stereo &, int);
+    static RectifyFn &rectify() {
+        static RectifyFn fn = 0;
+        return fn;
+    }
+    static bool prepare(Stereo &s, int pair) {
+        if (!rectify()) return false;
+        rectify()(s, pair);
+        return !s.m_data->cam[pair][0].image.empty(); // Rectify returns silently when an image cannot be read (.cpp:147-151)
+    }
     static bool mat(const cv::Mat &m, int type, const unsigned char *&p, int &w, int &h) {
         if (m.empty() || !m.isContinuous() || m.type() != type) return false;
         p = m.data;

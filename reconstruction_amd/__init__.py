@@ -5,5 +5,5 @@ host-side mirror of the reference's CStereoMatching call surface, synthetic inpu
 pair-sharding / RCCL cloud gather for multi-GPU runs.
 """
 from .api import (Context, StereoMatching, ManageData, Camera, PairResult, Boundary, NOMATCH, RsmError,  # noqa: F401
-                  write_ply, stereo_rectify, run_pairs, match_pairs, CloudOptimization, host_empty)
+                  write_ply, stereo_rectify, run_pairs, match_pairs, match_pairs_multi_gpu, CloudOptimization, host_empty)
 from . import synth  # noqa: F401

@@ -233,20 +233,52 @@ class Context:
     def run_pair(self):
         self._chk(self._lib.rsm_run_pair(self._h))
 
+    def alloc_result(self, pinned=False, want_cloud=True, want_disparity=True) -> PairResult:
+        """Result buffers for download_pair(into=...) sized for ANY cloud of the resident pair's size (W*H points: the
+        point count depends on the data), page-locked when `pinned`."""
+        H, W = self._shape
+        new = (lambda shape, dt: host_empty(shape, dt)) if pinned else (lambda shape, dt: np.zeros(shape, dt))
+        d = [new((H, W), np.float64), new((H, W), np.float64)] if want_disparity else [None, None]
+        cap = W * H if want_cloud else 0
+        xyz_buf, bgr_buf = new((cap, 3), np.float64), new((cap, 3), np.uint8)
+        res = PairResult(disparity=d, margin=[None, None], n_points=0, xyz=xyz_buf[:0], bgr=bgr_buf[:0], v_top=0)
+        res._xyz_buf, res._bgr_buf = xyz_buf, bgr_buf
+        return res
+
     def download_pair(self, want_cloud=True, want_disparity=True, pinned=False, into=None) -> PairResult:
-        """pinned: the results land in page-locked arrays (host_empty) instead of pageable ones; into: a PairResult of an
-        earlier download of a result of the same size whose buffers are reused (no allocation)."""
+        """pinned: the results land in page-locked arrays (host_empty) instead of pageable ones; into: a PairResult whose
+        buffers are reused (no allocation) -- one from alloc_result() (capacity W*H points: fits every cloud) or from an
+        earlier download (capacity = that cloud's size; a larger cloud raises RsmError, nothing is truncated).  n_points,
+        v_top, margin and the xyz / bgr views of `into` are refreshed from this download."""
         H, W = self._shape
         if into is not None:
+            xyz_buf = getattr(into, "_xyz_buf", None)
+            bgr_buf = getattr(into, "_bgr_buf", None)
+            if xyz_buf is None:
+                xyz_buf, bgr_buf = into.xyz, into.bgr
             pout = PairOut()
             if want_disparity:
-                pout.disparity[0] = into.disparity[0].ctypes.data
-                pout.disparity[1] = into.disparity[1].ctypes.data
+                for v in range(2):
+                    dv = into.disparity[v]
+                    if dv is None or dv.shape != (H, W) or dv.dtype != np.float64 or not dv.flags.c_contiguous:
+                        raise RsmError(-1, "download_pair(into=): disparity[%d] must be a C-contiguous float64 %dx%d array" % (v, H, W))
+                    pout.disparity[v] = dv.ctypes.data
+            cap = int(xyz_buf.shape[0]) if want_cloud else 0
             if want_cloud:
-                pout.max_points = into.xyz.shape[0]
-                pout.xyz = into.xyz.ctypes.data
-                pout.bgr = into.bgr.ctypes.data
+                if bgr_buf.shape[0] != cap or xyz_buf.dtype != np.float64 or bgr_buf.dtype != np.uint8:
+                    raise RsmError(-1, "download_pair(into=): xyz / bgr buffers disagree")
+                pout.max_points = cap
+                pout.xyz = xyz_buf.ctypes.data if cap else None
+                pout.bgr = bgr_buf.ctypes.data if cap else None
             self._chk(self._lib.rsm_download_pair(self._h, C.byref(pout)))
+            n = int(pout.n_points)
+            if want_cloud and n > cap:
+                raise RsmError(-1, "download_pair(into=): the cloud has %d points, the buffers hold %d (use Context.alloc_result())" % (n, cap))
+            into.n_points, into.v_top = n, int(pout.v_top)
+            into.margin = [pout.margin[0].astuple(), pout.margin[1].astuple()]
+            if want_cloud:
+                into._xyz_buf, into._bgr_buf = xyz_buf, bgr_buf
+                into.xyz, into.bgr = xyz_buf[:n], bgr_buf[:n]
             return into
         new = (lambda shape, dt: host_empty(shape, dt)) if pinned else (lambda shape, dt: np.zeros(shape, dt))
         d = [new((H, W), np.float64), new((H, W), np.float64)] if want_disparity else [None, None]
@@ -478,16 +510,12 @@ def run_pairs(ctxs, repeats=1):
         raise RsmError(st, "; ".join(m for m in msgs if m))
 
 
-def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True, timing=None, pinned=False):
-    """rsm_match_pairs: the pair loop of MatchAllLayer (.cpp:17-33) for a list of pair configs over a pool of
-    contexts (same or different GPUs), pairs in flight together.  Returns (results in pair order, statuses).
-    timing (optional dict) receives "call_s": seconds inside the C call alone (output buffers pre-faulted, the
-    slicing of the results outside).  pinned: the output buffers are page-locked (host_empty)."""
-    lib = _lib.load()
+def _pairs_io(cfgs, want_cloud, want_disparity, pinned):
+    """rsm_pair_in / rsm_pair_out arrays + the host buffers behind them for a list of pair configs."""
     n = len(cfgs)
     full = (lambda shape, v, dt=np.float64: _filled(host_empty(shape, dt), v)) if pinned else (lambda shape, v, dt=np.float64: np.full(shape, v, dt))
-    ins = (PairIn * n)()
-    outs = (PairOut * n)()
+    ins = (PairIn * max(n, 1))()
+    outs = (PairOut * max(n, 1))()
     keep, bufs = [], []
     for p, cfg in enumerate(cfgs):
         pin, k = Context._pair_in(cfg)
@@ -505,13 +533,10 @@ def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True, timing=None, p
             outs[p].xyz = xyz.ctypes.data
             outs[p].bgr = bgr.ctypes.data
         bufs.append((d, xyz, bgr))
-    status = (C.c_int * n)()
-    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
-    import time as _time
-    t0 = _time.perf_counter()
-    lib.rsm_match_pairs(arr, len(ctxs), ins, outs, n, status)
-    if timing is not None:
-        timing["call_s"] = _time.perf_counter() - t0
+    return ins, outs, keep, bufs
+
+
+def _pairs_results(n, outs, bufs, status, want_cloud):
     res = []
     for p in range(n):
         if status[p] != 0:
@@ -522,7 +547,37 @@ def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True, timing=None, p
         res.append(PairResult(disparity=d, margin=[outs[p].margin[0].astuple(), outs[p].margin[1].astuple()], n_points=m,
                               xyz=xyz[:m] if want_cloud else np.zeros((0, 3)),
                               bgr=bgr[:m] if want_cloud else np.zeros((0, 3), np.uint8), v_top=int(outs[p].v_top)))
-    return res, list(status)
+    return res
+
+
+def match_pairs(ctxs, cfgs, want_cloud=True, want_disparity=True, timing=None, pinned=False):
+    """rsm_match_pairs: the pair loop of MatchAllLayer (.cpp:17-33) for a list of pair configs over a pool of
+    contexts (same or different GPUs), pairs in flight together.  Returns (results in pair order, statuses).
+    timing (optional dict) receives "call_s": seconds inside the C call alone (output buffers pre-faulted, the
+    slicing of the results outside).  pinned: the output buffers are page-locked (host_empty)."""
+    lib = _lib.load()
+    n = len(cfgs)
+    ins, outs, keep, bufs = _pairs_io(cfgs, want_cloud, want_disparity, pinned)
+    status = (C.c_int * max(n, 1))()
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    import time as _time
+    t0 = _time.perf_counter()
+    lib.rsm_match_pairs(arr, len(ctxs), ins, outs, n, status)
+    if timing is not None:
+        timing["call_s"] = _time.perf_counter() - t0
+    return _pairs_results(n, outs, bufs, status, want_cloud), list(status)[:n]
+
+
+def match_pairs_multi_gpu(cfgs, n_gpus=0, pairs_in_flight=2, want_cloud=True, want_disparity=True):
+    """rsm_match_pairs_multi_gpu: the same loop sharded over the GPUs of this node from ONE process; the
+    library creates and destroys its own contexts (context i on GPU i % n_gpus, `pairs_in_flight` per GPU).
+    n_gpus = 0: every visible GPU.  Returns (results in pair order -- None for a failed pair --, statuses, return code)."""
+    lib = _lib.load()
+    n = len(cfgs)
+    ins, outs, keep, bufs = _pairs_io(cfgs, want_cloud, want_disparity, False)
+    status = (C.c_int * max(n, 1))()
+    rc = lib.rsm_match_pairs_multi_gpu(ins, n, int(n_gpus), int(pairs_in_flight), outs, status)
+    return _pairs_results(n, outs, bufs, status, want_cloud), list(status)[:n], int(rc)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -34,7 +34,12 @@
 
 #include <string.h>
 
-#define FILTER_MAX_CELLS (1 << 25) // cells a per-cell table is made for (256 MB); beyond that: binary search on the keys
+#define FILTER_MAX_CELLS (1 << 25) // most cells a per-cell table is made for (256 MB); beyond that: per-row table / binary search on the keys
+// ... for an n-point cloud: a table of far more cells than points is mostly empty, and its bytes are pinned in the context's
+// grow-only arena (a 1-point cloud must not cost 256 MB)
+static inline size_t filter_max_cells(int64_t n) {
+    return (size_t)std::min<int64_t>(FILTER_MAX_CELLS, std::max<int64_t>(1 << 16, 8 * n));
+}
 // Grid in KEY order: axis "x" is the fastest digit of the cell key, and it is the WORLD axis with the most cells (p0) --
 // a depth map is a sheet in a deep box, so the rows of cells along its depth hold a handful of points each and the
 // per-row table + short search inside the row (table kind 2) stays cheap when the cells are too many for a table.
@@ -728,15 +733,18 @@ int filter_arena_reserve(FilterArena *a, size_t bytes) {
     a->off = 0;
     a->failed = false;
     if (bytes <= a->cap) return RSM_OK;
+    // grows geometrically: hipFree synchronises the whole device, other contexts' pairs in flight included
+    const size_t want = std::max(bytes, a->cap + a->cap / 2);
     if (a->base) (void)hipFree(a->base);
     a->base = nullptr;
     a->cap = 0;
-    if (hipMalloc((void **)&a->base, bytes) != hipSuccess) return RSM_E_NOMEM;
-    a->cap = bytes;
+    if (hipMalloc((void **)&a->base, want) == hipSuccess) a->cap = want;
+    else if (hipMalloc((void **)&a->base, bytes) == hipSuccess) a->cap = bytes;
+    else return RSM_E_NOMEM;
     return RSM_OK;
 }
 size_t filter_arena_bytes(int64_t n) { // upper bound of one filter call's scratch for an n-point cloud (callers add their own buffers)
-    return (size_t)n * 112 + ((size_t)FILTER_MAX_CELLS + 64) * sizeof(int2) + ((size_t)64 << 20);
+    return (size_t)n * 112 + (filter_max_cells(n) + 64) * sizeof(int2) + std::min<size_t>((size_t)64 << 20, ((size_t)8 << 20) + (size_t)n * 16);
 }
 void *filter_arena_alloc(FilterArena *a, size_t bytes) { return a->get<char>(bytes); }
 
@@ -807,8 +815,9 @@ static int build_grid(FilterArena *A, const float *d_xyz, int64_t n, int64_t nv,
     G.table = nullptr;
     G.table_kind = 0;
     const double nrow = (double)G.g.ny * G.g.nz;
-    if (nv > 0 && (ncell <= (double)FILTER_MAX_CELLS || nrow <= (double)FILTER_MAX_CELLS)) {
-        G.table_kind = ncell <= (double)FILTER_MAX_CELLS ? 1 : 2;
+    const double max_cells = (double)filter_max_cells(n);
+    if (nv > 0 && (ncell <= max_cells || nrow <= max_cells)) {
+        G.table_kind = ncell <= max_cells ? 1 : 2;
         const size_t nc = (size_t)(G.table_kind == 1 ? ncell : nrow);
         G.table = A->get<int2>(nc);
         if (!G.table) return RSM_E_NOMEM;

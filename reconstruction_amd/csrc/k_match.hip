@@ -1304,11 +1304,8 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
         hipLaunchKernelGGL(k_ncc_rowgemm<R>, dim3((grid.x * NCC_TX + RG_PX - 1) / RG_PX, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), 0, st, a, mode);
     if (kind == 3) {
         const size_t lds_s = slide_lds_bytes<R>();
-        static bool attr_set = false; // per instantiation
-        if (!attr_set && lds_s > 65536) {
+        if (lds_s > 65536) // the attribute is per DEVICE: set on every launch, as for k_ncc_wide (contexts may live on several GPUs)
             (void)hipFuncSetAttribute((const void *)k_ncc_slide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            attr_set = true;
-        }
         const int tiles = (grid.x * NCC_TX + (SL_COLS - 2 * R) - 1) / (SL_COLS - 2 * R);
         hipLaunchKernelGGL(k_ncc_slide<R>, dim3((tiles + 3) / 4, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), lds_s, st, a, mode);
     }

@@ -151,8 +151,27 @@ __device__ __forceinline__ int sum4(uint32_t v, int acc) { return (int)__builtin
 // Reads the BGRX copies (one aligned dword per pixel, X = 0): 24 loads, the window bytes stay packed in
 // registers.  The reference's unchecked right-window reads (.cpp:628) are emulated on the flat buffer: the flat
 // byte index test fi in [0, 3WH) of the BGR image is the flat pixel index test in [0, WH) here.
+// (pwp, delta) from the three matching costs xi at iMatch + {0, 1, 2}: .cpp:631-650
+__device__ __forceinline__ void refine_entry(double x0, double x1, double x2, double &pwp, double &delta) {
+    int index = x0 >= x1; // .cpp:631-632
+    if ((index ? x1 : x0) > x2) index = 2;
+    if (index == 0) {
+        pwp = x1 - x0;
+        delta = -0.5;
+    } else if (index == 2) {
+        pwp = x1 - x2;
+        delta = 0.5;
+    } else {
+        pwp = 0.5 * (x0 + x2) - x1;
+        delta = (pwp == 0) ? 0.0 : 0.5 * (x0 - x2) / (x0 + x2 - 2 * x1);
+    }
+}
+
+// xs (optional): the three matching costs themselves -- the entry of an ADJACENT iMatch shares two of them
+// (k_refine_first: refine_cost_one supplies the third).
 __device__ __forceinline__ void refine_data_term_packed(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
-                                                        int W, int H, int x, int y, int key, double &pwp, double &delta) {
+                                                        int W, int H, int x, int y, int key, double &pwp, double &delta,
+                                                        double *xs = nullptr) {
     const long long npx = (long long)W * H;
     uint32_t aP[3][3], bP[3][5];
 #pragma unroll
@@ -221,18 +240,59 @@ __device__ __forceinline__ void refine_data_term_packed(const uint32_t *__restri
 #pragma unroll
             for (int q = 0; q < 4; q++) bP[j][q] = bP[j][q + 1];
     }
-    int index = x0 >= x1; // .cpp:631-632
-    if ((index ? x1 : x0) > x2) index = 2;
-    if (index == 0) {
-        pwp = x1 - x0;
-        delta = -0.5;
-    } else if (index == 2) {
-        pwp = x1 - x2;
-        delta = 0.5;
-    } else {
-        pwp = 0.5 * (x0 + x2) - x1;
-        delta = (pwp == 0) ? 0.0 : 0.5 * (x0 - x2) / (x0 + x2 - 2 * x1);
+    refine_entry(x0, x1, x2, pwp, delta);
+    if (xs) {
+        xs[0] = x0;
+        xs[1] = x1;
+        xs[2] = x2;
     }
+}
+
+// ONE matching cost xi = (1 - ncc) / 2 of pixel (x, y) against the right window whose left edge is column `col` (.cpp:626-629):
+// the same operation sequence per value as refine_data_term_packed (left mean / norm restated, one right window).
+__device__ __forceinline__ double refine_cost_one(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, int W, int H,
+                                                  int x, int y, int col) {
+    const long long npx = (long long)W * H;
+    uint32_t aP[3][3], bP[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t *pa = A + (size_t)(y - 1 + j) * W + (x - 1);
+        const long long fb = (long long)(y - 1 + j) * W + col;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            aP[j][p] = pa[p];
+            const long long fi = fb + p;
+            bP[j][p] = (fi >= 0 && fi < npx) ? B[fi] : 0u;
+        }
+    }
+    int SL = 0, SR = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            SL = sum4(aP[j][p], SL);
+            SR = sum4(bP[j][p], SR);
+        }
+    const double meanL = (double)SL / 27.0, meanR = (double)SR / 27.0;
+    double n1 = 0.0, n2 = 0.0, m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        const double ul = byte_f64(aP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanL;
+        const double ur = byte_f64(bP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanR;
+        if (k & 1) {
+            n2 += ul * ul;
+            m2 += ur * ur;
+            d2 += ul * ur;
+        } else {
+            n1 += ul * ul;
+            m1 += ur * ur;
+            d1 += ul * ur;
+        }
+    }
+    double normL = sqrt(n1 + n2), normR = sqrt(m1 + m2);
+    if (normL == 0) normL = 1;
+    if (normR == 0) normR = 1;
+    return (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
 }
 
 // One quad (4 adjacent lanes) computes refine_data_term_packed for one (x, y, key): every lane restates the left
@@ -285,18 +345,7 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
     const double xi = (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
     const int qb = (int)(threadIdx.x & 63) & ~3; // the quad's first lane
     const double x0 = __shfl(xi, qb + 1), x1 = __shfl(xi, qb + 2), x2 = __shfl(xi, qb + 3);
-    int index = x0 >= x1; // .cpp:631-632
-    if ((index ? x1 : x0) > x2) index = 2;
-    if (index == 0) {
-        pwp = x1 - x0;
-        delta = -0.5;
-    } else if (index == 2) {
-        pwp = x1 - x2;
-        delta = 0.5;
-    } else {
-        pwp = 0.5 * (x0 + x2) - x1;
-        delta = (pwp == 0) ? 0.0 : 0.5 * (x0 - x2) / (x0 + x2 - 2 * x1);
-    }
+    refine_entry(x0, x1, x2, pwp, delta);
 }
 
 // First sweep of a level: every cache entry is empty, so instead of a worklist the kernel walks the whole
@@ -319,13 +368,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return;
     }
     const int key = (int)(dC - 1.5) + x;
-    double pwp, delta;
-    refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, key, pwp, delta);
+    double pwp, delta, xs[3];
+    refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, key, pwp, delta, xs);
     const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
     d.rf_key[cpix] = (int16_t)(key - x);
     d.rf_pwp[cpix] = pwp;
     d.rf_delta[cpix] = delta;
-    d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+    const double val = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+    d.f64_b[pix] = val;
+    // The second cache way, filled ahead of its first use.  The level starts from integers, so int(dC - 1.5) sits in the
+    // middle of its interval and the pixel leaves it on the side its first update points to: measured with the oracle
+    // (tests/tools/analyze_keys.py), the next iMatch a pixel needs is the neighbour in that direction for > 99.9 % of the
+    // pixels -- in the sweep kernels each of them would be a cache miss (C2's top level: 4.8 M in the third sweep alone).
+    // The neighbour's data term shares two of its three matching costs with this one: one more right window.
+    if (a.flag3 & 2) return; // option refine_prefill = 0 (A/B)
+    const int rel0 = key - x, rel1 = (int)(val - 1.5);
+    const int rel2 = rel1 != rel0 ? rel1 : (val > dC ? rel0 + 1 : (val < dC ? rel0 - 1 : rel0));
+    if (rel2 == rel0 + 1 || rel2 == rel0 - 1) {
+        const bool up = rel2 > rel0;
+        const double xe = refine_cost_one(d.img4_own, d.img4_oth, W, H, x, y, up ? key + 3 : key - 1);
+        double p2, q2;
+        refine_entry(up ? xs[1] : xe, up ? xs[2] : xs[0], up ? xe : xs[1], p2, q2);
+        const size_t cpix2 = pix + (size_t)(rel2 & 1) * a.rf_stride;
+        d.rf_key[cpix2] = (int16_t)rel2;
+        d.rf_pwp[cpix2] = p2;
+        d.rf_delta[cpix2] = q2;
+    }
 }
 
 // One Jacobi sweep f64_a -> f64_b: RF_PPT vertically adjacent pixels per thread, every load issued up front.

@@ -126,7 +126,8 @@ struct rsm_ctx {
     int opt_refine_multi_from = 0;  // first sweep of a level that may run in the two-sweeps-per-launch kernel (0: never = default: measured slower, k_refine.hip)
     int opt_refine_multi_min_px = 400000; // ... at levels with at least this many margin pixels
     int opt_refine_band_rows = 0; // > 0: band height in rows, overrides refine_band_mb (tests)
-    int opt_refine_skew_from = 38; // first sweep of a level that may run in the time-skewed kernel (k_refine_skew; 0: never): before that too many pixels still miss the data-term cache for its lane-serial miss service
+    int opt_refine_skew_from = 22; // first sweep of a level that may run in the time-skewed kernel (k_refine_skew; 0: never): before that too many pixels still miss the data-term cache for its lane-serial miss service
+    int opt_refine_prefill = 1;    // k_refine_first also fills the second cache way with the neighbour iMatch its update points to
     int opt_refine_skew_T = 4;     // sweeps per time-skewed launch (2..4)
     int opt_refine_skew_min_px = 1000000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
     int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
@@ -366,7 +367,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->upd_cnt, 2 * RF_UPD_SHARDS);
     // every pixel of the sweep workgroups (256 x RF_PPT pixels each, both directions) that can hash to one shard
     c->miss_cap = (int)((((size_t)(in->width / 256 + 2) * (size_t)(in->height / RF_PPT + 2) * 2) / RF_UPD_SHARDS + 2) * 256 * RF_PPT);
-    DALLOC(c, c->miss_list, (size_t)RF_UPD_SHARDS * c->miss_cap);
+    c->miss_list = nullptr; // 227 MB at C2 for a path that is off by default: allocated by rsm_run_pair when refine_defer_to > 0
     DALLOC(c, c->tie_cnt, 2 * RSM_MAX_LEVELS);
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->blk, CLOUD_BLOCKS(in->width, in->height));
@@ -475,6 +476,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_multi_from")) c->opt_refine_multi_from = (int)std::max(0LL, std::min(value, 100000LL));
     else if (!strcmp(name, "refine_multi_min_px")) c->opt_refine_multi_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_from")) c->opt_refine_skew_from = (int)std::max(0LL, std::min(value, 100000LL));
+    else if (!strcmp(name, "refine_prefill")) c->opt_refine_prefill = value != 0;
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
@@ -635,7 +637,9 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
     bind(0);
     a.row_lo = 0;
     a.row_hi = INT_MAX;
+    a.flag3 = (c && !c->opt_refine_prefill) ? 2 : 0;
     launch_refine_sweep(a, st); // k_refine_first: whole interior
+    a.flag3 = 0;
     launches++;
     curB = true;
     const int nsw = iters - 1;
@@ -724,6 +728,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     c->have_result = false;
     c->ev_used = 0;
     const double P_top_full = (double)c->Wk[N - 1] * c->Hk[N - 1];
+    if (c->opt_refine_defer_to > 0 && !c->miss_list) DALLOC(c, c->miss_list, (size_t)RF_UPD_SHARDS * c->miss_cap); // deferred miss service (option)
 
     // ConstructPyrm, .cpp:1040-1053 (top level = uploaded images).  The main stream needs the masks (margins) first;
     // everything that depends on the images or the top mask only goes to the side stream and is made while the small
@@ -1436,7 +1441,7 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     a.rf_stride = px;
     a.upd_cap = 4096;
     a.miss_cap = (int)((((size_t)(W / 256 + 2) * (size_t)(H / RF_PPT + 2)) / RF_UPD_SHARDS + 2) * 256 * RF_PPT);
-    a.miss_list = t.alloc<RfMiss>((size_t)RF_UPD_SHARDS * a.miss_cap);
+    a.miss_list = c->opt_refine_defer_to > 0 ? t.alloc<RfMiss>((size_t)RF_UPD_SHARDS * a.miss_cap) : nullptr;
     a.upd_list = t.alloc<RfUpd>((size_t)RF_UPD_SHARDS * a.upd_cap);
     a.upd_cnt = t.alloc<int32_t>(2 * RF_UPD_SHARDS);
     if (!t.ok) return finish(c, t);

@@ -154,12 +154,15 @@ class Comm:
 
     def gather(self, local, n_pairs_total, root=0, capacity=None):
         """local: [(pair_id, records uint8 [n,16] CUDA tensor)] in any order.  Root returns [(pair_id, records view)]
-        for all pairs.  capacity = records the root's buffer holds; None sizes it exactly with a counts-only
-        exchange first (one more all-reduce)."""
+        for all pairs.  capacity = records the root's buffer holds (only the root's value matters: it travels to the
+        peers inside rsm_gather_clouds' own all-reduce); None sizes it exactly from the counts.  The counts-only
+        exchange is posted by EVERY rank on EVERY call, whatever its `capacity` argument: ranks that disagreed about
+        it would otherwise post different collective sequences and hang."""
         from . import _lib
         n = len(local)
+        total = sum(self.counts(local, n_pairs_total))
         if capacity is None:
-            capacity = sum(self.counts(local, n_pairs_total))
+            capacity = total
         ids = (C.c_int * max(n, 1))(*[int(p) for p, _ in local])
         ptrs = (C.c_void_p * max(n, 1))(*[int(r.data_ptr()) if r.shape[0] else None for _, r in local])
         cnts = (C.c_int64 * max(n, 1))(*[int(r.shape[0]) for _, r in local])

@@ -1,0 +1,103 @@
+// adapter_bench.cpp -- times include/rsm_stereo_adapter.hpp's MatchAll (the pair loop of CStereoMatching::MatchAllLayer,
+// reconstruction/CStereoMatching.cpp:17-33) on the bench workload, PCIe included: host images in (pageable, as the
+// reference's cv::Mat), InsertPoint stream out.  Mock CStereoMatching / CManageData behind the traits, no OpenCV.
+// Built and run by bench.py (value_adapter_pcie_inclusive) and tests/test_gpu_cpp_adapter.py.
+//   adapter_bench <in.bin> <n_pairs_total> <pairs_in_flight> [want_disparity]
+// in.bin: the format of mock_adapter.cpp; its pairs are cycled until n_pairs_total pairs have been matched.  One
+// untimed MatchAll over pairs_in_flight pairs first (contexts, workspaces, page-locked buffers), then the timed one.
+// stdout: one JSON line.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <vector>
+
+#include "rsm_stereo_adapter.hpp"
+
+struct BPair {
+    double Q[16], R[9], T[3];
+    std::vector<unsigned char> img[2], msk[2];
+};
+struct BStereo {
+    int pyr_levels, lowest_w, lowest_h, origin_w, radius, offset;
+    double ws;
+    int W, H, cur;
+    std::vector<BPair> pairs; // the distinct inputs; pair p of the run uses pairs[p % size]
+    std::vector<float> cloud; // what InsertPoint keeps: float xyz (CCloudOptimization.cpp:61)
+    int64_t points, filters;
+};
+struct BTraits {
+    typedef BStereo Stereo;
+    static const BPair &pr(Stereo &s, int pair) { return s.pairs[(size_t)pair % s.pairs.size()]; }
+    static int pyr_levels(Stereo &s) { return s.pyr_levels; }
+    static int lowest_width(Stereo &s) { return s.lowest_w; }
+    static int lowest_height(Stereo &s) { return s.lowest_h; }
+    static int origin_width(Stereo &s) { return s.origin_w; }
+    static int radius(Stereo &s) { return s.radius; }
+    static double ws(Stereo &s) { return s.ws; }
+    static int offset(Stereo &s) { return s.offset; }
+    static int verbose(Stereo &) { return 0; }
+    static bool isoutput(Stereo &) { return false; }
+    static bool prepare(Stereo &s, int pair) { s.cur = pair; return true; }
+    static bool image(Stereo &s, int pair, int v, const unsigned char *&p, int &w, int &h) { p = pr(s, pair).img[v].data(); w = s.W; h = s.H; return true; }
+    static bool mask(Stereo &s, int pair, int v, const unsigned char *&p, int &w, int &h) { p = pr(s, pair).msk[v].data(); w = s.W; h = s.H; return true; }
+    static double Q(Stereo &s, int i, int j) { return pr(s, s.cur).Q[4 * i + j]; }
+    static double R_final(Stereo &s, int i, int j) { return pr(s, s.cur).R[3 * i + j]; }
+    static double T_final(Stereo &s, int i) { return pr(s, s.cur).T[i]; }
+    static void set_margin(Stereo &, int, int, const rsm_boundary &) {}
+    static void insert_point(Stereo &s, const double xyz[3]) {
+        s.cloud.push_back((float)xyz[0]);
+        s.cloud.push_back((float)xyz[1]);
+        s.cloud.push_back((float)xyz[2]);
+        s.points++;
+    }
+    static void filter(Stereo &s, int) {
+        s.filters++;
+        s.cloud.clear(); // (the reference's filter() consumes cloud_in and clears it, CCloudOptimization.cpp:84-121)
+    }
+};
+
+template <typename T>
+static bool rd(FILE *f, T *p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
+
+int main(int argc, char **argv) {
+    if (argc < 4) return 2;
+    FILE *fi = fopen(argv[1], "rb");
+    if (!fi) return 2;
+    const int n_total = atoi(argv[2]), inflight = atoi(argv[3]);
+    const bool want_disp = argc > 4 && atoi(argv[4]) != 0;
+    int32_t hdr[9];
+    BStereo s;
+    if (!rd(fi, hdr, 9) || !rd(fi, &s.ws, 1)) return 2;
+    s.W = hdr[1]; s.H = hdr[2]; s.pyr_levels = hdr[3]; s.radius = hdr[4]; s.offset = hdr[5]; s.origin_w = hdr[6];
+    s.lowest_w = s.W >> (s.pyr_levels - 1);
+    s.lowest_h = s.H >> (s.pyr_levels - 1);
+    const size_t px = (size_t)s.W * s.H;
+    s.pairs.resize(hdr[0]);
+    for (size_t p = 0; p < s.pairs.size(); p++) {
+        BPair &bp = s.pairs[p];
+        if (!rd(fi, bp.Q, 16) || !rd(fi, bp.R, 9) || !rd(fi, bp.T, 3)) return 2;
+        for (int v = 0; v < 2; v++) { bp.img[v].resize(px * 3); if (!rd(fi, bp.img[v].data(), px * 3)) return 2; }
+        for (int v = 0; v < 2; v++) { bp.msk[v].resize(px); if (!rd(fi, bp.msk[v].data(), px)) return 2; }
+    }
+    fclose(fi);
+    RsmStereoAdapter<BTraits> gpu(0, inflight);
+    if (!gpu.Ok()) { fprintf(stderr, "%s\n", gpu.LastError()); return 3; }
+    gpu.want_disparity = want_disp;
+    s.cloud.reserve(px * 3);
+    s.points = s.filters = 0;
+    { // warm-up: contexts, workspaces and page-locked buffers of every slot
+        BStereo w = s;
+        if (gpu.MatchAll(w, inflight) != inflight) { fprintf(stderr, "warm-up: %s\n", gpu.LastError()); return 4; }
+    }
+    std::vector<int> status((size_t)n_total, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int ok = gpu.MatchAll(s, n_total, status.data());
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (ok != n_total) { fprintf(stderr, "MatchAll: %d of %d pairs, %s\n", ok, n_total, gpu.LastError()); return 5; }
+    printf("{\"pairs\": %d, \"pairs_in_flight\": %d, \"seconds\": %.6f, \"points\": %lld, \"filters\": %lld, \"v_top_last\": %lld, \"want_disparity\": %d}\n",
+           n_total, inflight, dt, (long long)s.points, (long long)s.filters, (long long)gpu.LastVTop(), want_disp ? 1 : 0);
+    return 0;
+}

@@ -2,6 +2,8 @@
 // for real: mock stand-ins of CStereoMatching / CManageData behind a traits type, no OpenCV.  Built with g++ on the
 // GPU box by tests/test_gpu_cpp_adapter.py, linked against librsm_mi355.so.
 //   mock_adapter <in.bin> <out.bin>
+//   mock_adapter <in.bin> <out.bin> [mode]      mode 0: a MatchPair call per pair (default); N >= 1: ONE MatchAll call
+//                                               with N pairs in flight
 // in.bin : int32 n_pairs, W, H, levels, radius, offset, origin_w, isoutput, bad_pair; double ws;
 //          per pair: double Q[16], R[9], T[3]; u8 img0[WH3], img1[WH3], mask0[WH], mask1[WH]
 // out.bin: per pair: int32 ok, status; int32 margin[2][6]; int64 n_points (InsertPoint calls); int32 filter_arg;
@@ -29,6 +31,16 @@ struct MockStereo { // the fields of CStereoMatching + CManageData the adapter t
     rsm_boundary margin[2];
     std::vector<double> inserted;
     std::vector<int> filtered;
+    // what each pair's replay produced, captured when filter(pair) is called (the last call of a pair's replay)
+    struct Got {
+        bool seen;
+        std::vector<double> xyz, disp0;
+        int filter_arg;
+        Got() : seen(false), filter_arg(-1) {}
+    };
+    std::vector<Got> got;
+    const std::vector<double> *adapter_disp0; // the adapter's `disparity[0]`
+    std::vector<int> prepared;                // order of the prepare (Rectify) calls
 };
 struct MockTraits {
     typedef MockStereo Stereo;
@@ -58,8 +70,21 @@ struct MockTraits {
         s.margin[v] = m;
         s.pairs[pair].bound[v] = m;
     }
+    static bool prepare(Stereo &s, int pair) { // the reference's Rectify(CamPair, Q): Q / R_final / T_final become this pair's
+        s.cur = pair;
+        s.prepared.push_back(pair);
+        return true;
+    }
     static void insert_point(Stereo &s, const double xyz[3]) { s.inserted.insert(s.inserted.end(), xyz, xyz + 3); }
-    static void filter(Stereo &s, int pair) { s.filtered.push_back(pair); }
+    static void filter(Stereo &s, int pair) {
+        s.filtered.push_back(pair);
+        MockStereo::Got &g = s.got[pair];
+        g.seen = true;
+        g.filter_arg = pair;
+        g.xyz.swap(s.inserted);
+        s.inserted.clear();
+        if (s.adapter_disp0) g.disp0 = *s.adapter_disp0;
+    }
 };
 
 template <typename T>
@@ -91,18 +116,41 @@ int main(int argc, char **argv) {
         if (p == bad_pair) for (int v = 0; v < 2; v++) memset(mp.msk[v].data(), 0, px); // empty mask: degenerate margin
     }
     fclose(fi);
-    RsmStereoAdapter<MockTraits> gpu(0);
+    const int mode = argc > 3 ? atoi(argv[3]) : 0;
+    RsmStereoAdapter<MockTraits> gpu(0, mode > 0 ? mode : 1);
     if (!gpu.Ok()) { fprintf(stderr, "%s\n", gpu.LastError()); return 3; }
+    gpu.want_disparity = true;
+    s.adapter_disp0 = &gpu.disparity[0];
+    s.got.resize(n_pairs);
+    std::vector<int> status(n_pairs, 0);
+    std::vector<int> okv(n_pairs, 0);
+    if (mode > 0) { // the pair loop of MatchAllLayer (.cpp:17-33) in one call, pairs in flight
+        const int nok = gpu.MatchAll(s, n_pairs, status.data());
+        int cnt = 0;
+        for (int p = 0; p < n_pairs; p++) { okv[p] = status[p] == RSM_OK; cnt += okv[p]; }
+        if (cnt != nok) { fprintf(stderr, "MatchAll returned %d, status says %d\n", nok, cnt); return 4; }
+        for (int p = 0; p < n_pairs; p++)
+            if ((int)s.prepared.size() != n_pairs || s.prepared[p] != p) { fprintf(stderr, "prepare order\n"); return 4; }
+        int last = -1; // filter(CamPair) calls in ascending pair order, one per good pair
+        for (size_t i = 0; i < s.filtered.size(); i++) { if (s.filtered[i] <= last) { fprintf(stderr, "replay order\n"); return 4; } last = s.filtered[i]; }
+    } else {
+        for (int p = 0; p < n_pairs; p++) { // the loop written out, a MatchPair call per pair (Rectify already done)
+            MockTraits::prepare(s, p);
+            okv[p] = gpu.MatchPair(s, p) ? 1 : 0;
+            status[p] = gpu.LastStatus();
+            if (!okv[p]) fprintf(stderr, "pair %d: %s\n", p, gpu.LastError());
+        }
+    }
     FILE *fo = fopen(argv[2], "wb");
     if (!fo) return 2;
-    for (int p = 0; p < n_pairs; p++) { // the pair loop of MatchAllLayer, .cpp:17-33 (Rectify already done)
-        s.cur = p;
-        s.inserted.clear();
-        s.filtered.clear();
-        const bool ok = gpu.MatchPair(s, p);
-        const int32_t okst[2] = {ok ? 1 : 0, gpu.LastStatus()};
+    for (int p = 0; p < n_pairs; p++) {
+        const int32_t okst[2] = {okv[p], status[p]};
         wr(fo, okst, 2);
-        if (!ok) { fprintf(stderr, "pair %d: %s\n", p, gpu.LastError()); continue; }
+        if (!okv[p]) {
+            if (mode > 0) fprintf(stderr, "pair %d: status %d\n", p, status[p]);
+            if (s.got[p].seen) return 5; // a failed pair must not reach InsertPoint / filter
+            continue;
+        }
         int32_t mg[12];
         for (int v = 0; v < 2; v++) {
             const rsm_boundary &b = s.pairs[p].bound[v];
@@ -110,12 +158,14 @@ int main(int argc, char **argv) {
             memcpy(mg + 6 * v, t, sizeof t);
         }
         wr(fo, mg, 12);
-        const int64_t n = (int64_t)s.inserted.size() / 3;
+        const MockStereo::Got &g = s.got[p];
+        const int64_t n = (int64_t)g.xyz.size() / 3;
         wr(fo, &n, 1);
-        const int32_t farg = s.filtered.size() == 1 ? s.filtered[0] : -1;
+        const int32_t farg = g.seen ? g.filter_arg : -1;
         wr(fo, &farg, 1);
-        wr(fo, s.inserted.data(), s.inserted.size());
-        wr(fo, gpu.disparity[0].data(), px);
+        wr(fo, g.xyz.data(), g.xyz.size());
+        if (g.disp0.size() != px) return 6;
+        wr(fo, g.disp0.data(), px);
     }
     fclose(fo);
     return 0;

@@ -80,7 +80,14 @@ def test_cpp_adapter_compiles_against_the_reference_headers(tmp_path, pcl):
     src.write_text('#define __declspec(x)\n#define _Longlong long long\n#include "SharedInclude.h"\n'
                    + ('' if pcl else '#undef IS_PCL\n') +
                    '#include "CStereoMatching.h"\n#include "CStereoMatchingMI355.hpp"\n'
-                   'bool f(CStereoMatching &sm) { RsmStereoMI355 g(0); return g.MatchPair(sm, 0) && g.LastStatus() == 0; }\n')
+                   'bool f(CStereoMatching &sm) { RsmStereoMI355 g(0); return g.MatchPair(sm, 0) && g.LastStatus() == 0; }\n'
+                   # the whole loop as INTEGRATION.md 2 writes it: a member function, so the lambda may call the private Rectify
+                   'void CStereoMatching::MatchAllLayer() {\n'
+                   '    static RsmStereoMI355 gpu(0, 3);\n'
+                   '    RsmCvTraits::rectify() = [](CStereoMatching &s, int CamPair) { s.Rectify(CamPair, s.Q); };\n'
+                   '    std::vector<int> status(m_data->m_CampairNum);\n'
+                   '    if (gpu.MatchAll(*this, m_data->m_CampairNum, status.data()) != m_data->m_CampairNum) printf("rsm: %s\\n", gpu.LastError());\n'
+                   '}\n')
     r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-I/root/reference/include",
                         "-I/root/reference/reconstruction", "-I" + os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
@@ -94,5 +101,5 @@ def test_mock_adapter_program_builds_and_links(tmp_path):
     r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "tests", "cpp", "mock_adapter.cpp"), "-o", str(tmp_path / "mock_adapter"),
                         "-L" + os.path.dirname(_lib.LIB_PATH), "-lrsm_mi355", "-Wl,-rpath-link,/opt/rocm/lib",
-                        "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+                        "-Wl,--allow-shlib-undefined", "-pthread"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -1,7 +1,8 @@
 """The C++ glue of include/rsm_stereo_adapter.hpp, executed: tests/cpp/mock_adapter.cpp (mock CStereoMatching /
 CManageData behind the accessor traits, no OpenCV) is built with g++ here on the GPU box, linked against
 librsm_mi355.so, fed three pairs -- the middle one degenerate -- and its InsertPoint stream, bounds, disparity and
-cloud%d.ply (isoutput) are compared with the ctypes path."""
+cloud%d.ply (isoutput) are compared with the ctypes path: once as a MatchPair call per pair, once as ONE MatchAll call (the
+pair loop of CStereoMatching.cpp:17-33 with two / three pairs in flight, results replayed in pair order)."""
 import os
 import struct
 import subprocess
@@ -19,16 +20,17 @@ def build(tmp_path):
     exe = str(tmp_path / "mock_adapter")
     cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mock_adapter.cpp"),
            "-o", exe, "-L" + os.path.dirname(_lib.LIB_PATH), "-lrsm_mi355", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH),
-           "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+           "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-pthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return exe
 
 
-def test_mock_pipeline_through_the_cpp_adapter(ctx, tmp_path):
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_mock_pipeline_through_the_cpp_adapter(ctx, tmp_path, mode):
     exe = build(tmp_path)
     kw = dict(width=192, height=128, levels=3, radius=2, offset=2, mask_l0_width=30, border_l0=4)
-    cfgs = [synth.config_small(pair=p, **kw) for p in (1, 2, 4)]
+    cfgs = [synth.config_small(pair=p, **kw) for p in ((1, 2, 4) if mode == 0 else (1, 2, 4, 5, 3))]
     bad = 1
     W, H = kw["width"], kw["height"]
     with open(tmp_path / "in.bin", "wb") as f:
@@ -39,8 +41,8 @@ def test_mock_pipeline_through_the_cpp_adapter(ctx, tmp_path):
             for a in (c.image[0], c.image[1], c.mask[0], c.mask[1]):
                 f.write(np.ascontiguousarray(a, np.uint8).tobytes())
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, cwd=tmp_path, env=env,
-                       timeout=300)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(mode)], capture_output=True, text=True, cwd=tmp_path,
+                       env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     buf = open(tmp_path / "out.bin", "rb").read()
     off = 0
@@ -48,7 +50,7 @@ def test_mock_pipeline_through_the_cpp_adapter(ctx, tmp_path):
         ok, status = struct.unpack_from("<2i", buf, off); off += 8
         if p == bad:
             assert (ok, status) == (0, -2)      # RSM_E_DEGENERATE_MARGIN: reported, and the NEXT pair still runs
-            assert "level" in r.stderr
+            assert ("level" in r.stderr) if mode == 0 else ("pair 1: status -2" in r.stderr)
             continue
         assert (ok, status) == (1, 0)
         mg = struct.unpack_from("<12i", buf, off); off += 48

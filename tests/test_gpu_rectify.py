@@ -172,7 +172,8 @@ def test_cli_isoutput_and_filter(ctx, tmp_path, monkeypatch):
     rec = np.frombuffer(body, dtype=[("xyz", "<f4", 3), ("bgr", "u1", 3), ("n", "<f4", 4)])
     assert len(rec) == n_f and rec["bgr"].any()
     nn = np.linalg.norm(rec["n"][:, :3], axis=1)        # NaN where fewer than 3 points lie within the search radius
-    assert np.isfinite(nn).all() is not None and (not np.isfinite(nn).any() or np.abs(nn[np.isfinite(nn)] - 1).max() < 1e-3)
+    fin = np.isfinite(nn)
+    assert fin.mean() > 0.9 and np.abs(nn[fin] - 1).max() < 1e-3   # unit normals wherever one exists: nearly everywhere on a plane
     # an unreadable first mask is reported like the reference's "read image ... error", not an assertion
     os.remove(root + "mask/0001_Cam0.png")
     assert main([root + "config.yml"]) == 1
