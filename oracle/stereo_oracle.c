@@ -55,8 +55,9 @@ static double wall_now(void) {
  * (tests/test_oracle_known_answers.py), and equal to the GPU's evaluation bit for bit (tests/test_gpu_golden.py runs
  * rsm_stage_exp_neg over the whole argument range incl. the subnormal results).
  * orc_set_exp_mode(1) switches the oracle to the host libm for comparison. */
-static int g_exp_mode = 0;
-void orc_set_exp_mode(int libm) { g_exp_mode = libm != 0; }
+static int g_exp_mode = 0; /* 0: the specified exp; 1: the host libm's exp; 2: the host libm's long-double expl rounded to double
+                            * (a second, independent libm-grade exp: the control of tests/test_oracle_exp_control.py) */
+void orc_set_exp_mode(int mode) { g_exp_mode = (mode == 1 || mode == 2) ? mode : 0; }
 
 /* The polynomial part with the hardware instruction where the CPU has it (same values as fma() by definition). */
 #if defined(__x86_64__) && defined(__GNUC__)
@@ -89,6 +90,7 @@ static int g_have_fma = -1;
 void orc_set_exp_soft_fma(int soft) { g_have_fma = soft ? 0 : -1; } /* tests: force the C library's fma() */
 
 double orc_exp_neg(double t) {
+    if (g_exp_mode == 2) return (double)expl(-(long double)t);
     if (g_exp_mode || !(t >= 0.0)) return exp(-t);        /* (t is a square: never negative or NaN on this path) */
     if (t > 745.13321910194110842) return 0.0;            /* underflow threshold of exp */
     int k;

@@ -40,6 +40,8 @@ def main(argv=None) -> int:
     ap.add_argument("--ws", type=float, default=0.03, help="smoothness weight (CReconstruction.cpp:17: 0.03)")
     ap.add_argument("--filter", action="store_true",
                     help="per-pair StatisticalOutlierRemoval (k=100, 1 sigma) as CCloudOptimization::filter (CReconstruction.cpp:18)")
+    ap.add_argument("--mls-radius", type=float, default=2.5,
+                    help="search radius of the per-pair normals, in scene units (m_mls_radius; CReconstruction.cpp:18 passes 2.5)")
     args = ap.parse_args(argv)
 
     from .config import load_config
@@ -54,7 +56,7 @@ def main(argv=None) -> int:
     if args.filter:
         from . import CloudOptimization
         sink = CloudOptimization(sm._ctx)
-        sink.Init(100, 1, 50, 2, 2.5, data, False)                # CReconstruction.cpp:18
+        sink.Init(100, 1, 50, 2, args.mls_radius, data, False)    # CReconstruction.cpp:18
     else:
         sink = CloudSink()
     sm.Init(data, sink, args.radius, args.ws)

@@ -744,7 +744,7 @@ int filter_arena_reserve(FilterArena *a, size_t bytes) {
     return RSM_OK;
 }
 size_t filter_arena_bytes(int64_t n) { // upper bound of one filter call's scratch for an n-point cloud (callers add their own buffers)
-    return (size_t)n * 112 + (filter_max_cells(n) + 64) * sizeof(int2) + std::min<size_t>((size_t)64 << 20, ((size_t)8 << 20) + (size_t)n * 16);
+    return (size_t)n * 112 + (filter_max_cells(n) + 64) * sizeof(int2) + std::min<size_t>((size_t)64 << 20, ((size_t)32 << 20) + (size_t)n * 16) /* sort / scan temporaries, the exhaustive search's 16 MB of histograms */;
 }
 void *filter_arena_alloc(FilterArena *a, size_t bytes) { return a->get<char>(bytes); }
 

@@ -25,7 +25,8 @@ struct BStereo {
     double ws;
     int W, H, cur;
     std::vector<BPair> pairs; // the distinct inputs; pair p of the run uses pairs[p % size]
-    std::vector<float> cloud; // what InsertPoint keeps: float xyz (CCloudOptimization.cpp:61)
+    std::vector<float> cloud; // what InsertPoint keeps: float xyz (CCloudOptimization.cpp:61); sized once, filled through `fill`
+    size_t fill;
     int64_t points, filters;
 };
 struct BTraits {
@@ -47,15 +48,17 @@ struct BTraits {
     static double R_final(Stereo &s, int i, int j) { return pr(s, s.cur).R[3 * i + j]; }
     static double T_final(Stereo &s, int i) { return pr(s, s.cur).T[i]; }
     static void set_margin(Stereo &, int, int, const rsm_boundary &) {}
-    static void insert_point(Stereo &s, const double xyz[3]) {
-        s.cloud.push_back((float)xyz[0]);
-        s.cloud.push_back((float)xyz[1]);
-        s.cloud.push_back((float)xyz[2]);
+    static void insert_point(Stereo &s, const double xyz[3]) { // the cast and append of CCloudOptimization::InsertPoint
+        float *d = &s.cloud[s.fill];
+        d[0] = (float)xyz[0];
+        d[1] = (float)xyz[1];
+        d[2] = (float)xyz[2];
+        s.fill += 3;
         s.points++;
     }
     static void filter(Stereo &s, int) {
         s.filters++;
-        s.cloud.clear(); // (the reference's filter() consumes cloud_in and clears it, CCloudOptimization.cpp:84-121)
+        s.fill = 0; // (the reference's filter() consumes cloud_in and clears it, CCloudOptimization.cpp:84-121)
     }
 };
 
@@ -86,7 +89,8 @@ int main(int argc, char **argv) {
     RsmStereoAdapter<BTraits> gpu(0, inflight);
     if (!gpu.Ok()) { fprintf(stderr, "%s\n", gpu.LastError()); return 3; }
     gpu.want_disparity = want_disp;
-    s.cloud.reserve(px * 3);
+    s.cloud.assign(px * 3, 0.0f); // a cloud can hold a point per pixel
+    s.fill = 0;
     s.points = s.filters = 0;
     { // warm-up: contexts, workspaces and page-locked buffers of every slot
         BStereo w = s;

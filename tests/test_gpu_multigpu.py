@@ -130,3 +130,106 @@ def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT, timeout=300)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_match_pairs_multi_gpu_from_one_process(ctx):
+    """rsm_match_pairs_multi_gpu: the pair loop sharded over the node's GPUs from ONE process, the library
+    owning its contexts.  n_gpus = 0 (every visible GPU) and 1, two pairs in flight per GPU, a degenerate pair in the
+    middle (the reference's exit(0), CStereoMatching.cpp:827-830): every other pair equals rsm_match_pair bit for bit."""
+    from reconstruction_amd import match_pairs_multi_gpu
+    cfgs = [synth.config_small(**kw) for kw in PAIRS] + [synth.config_small(**PAIRS[0])]
+    bad = synth.config_small(**PAIRS[1])
+    bad.mask = [np.zeros_like(bad.mask[0]), np.zeros_like(bad.mask[1])]
+    cfgs.insert(2, bad)
+    want = [None if i == 2 else ctx.match_pair(c) for i, c in enumerate(cfgs)]
+    for n_gpus in (0, 1):
+        res, status, rc = match_pairs_multi_gpu(cfgs, n_gpus=n_gpus, pairs_in_flight=2)
+        assert status == [0, 0, -2, 0, 0] and rc == -2      # RSM_E_DEGENERATE_MARGIN reported, the others still ran
+        assert res[2] is None
+        for r, w in zip(res, want):
+            if w is None:
+                continue
+            assert r.margin == w.margin and r.n_points == w.n_points > 0 and r.v_top == w.v_top
+            assert all(np.array_equal(r.disparity[v], w.disparity[v]) for v in range(2))
+            assert np.array_equal(r.xyz, w.xyz, equal_nan=True) and np.array_equal(r.bgr, w.bgr)
+    # no pairs, and bad arguments
+    assert match_pairs_multi_gpu([], n_gpus=1)[2] == 0
+    from reconstruction_amd import _lib
+    assert _lib.load().rsm_match_pairs_multi_gpu(None, 1, 1, 1, None, None) != 0
+    assert _lib.load().rsm_match_pairs_multi_gpu(None, 0, -1, 1, None, None) != 0
+
+
+def _rccl_worker(rank, world, uid, owned, q):
+    """one process per GPU: match the owned pairs on device `rank`, pack them, fan them in to rank 0 over RCCL"""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    from reconstruction_amd import Context
+    from reconstruction_amd.dist import Comm, unpack_records
+    comm = Comm(uid, rank, world, rank)
+    try:
+        local = []
+        with Context(rank) as ctx:
+            for pid, kw in owned:
+                if kw is None:                 # an owned pair whose cloud is empty
+                    local.append((pid, torch.empty((0, 16), dtype=torch.uint8, device="cuda:%d" % rank)))
+                    continue
+                res = ctx.match_pair(synth.config_small(**kw))
+                rec = torch.empty((res.n_points, 16), dtype=torch.uint8, device="cuda:%d" % rank)
+                assert ctx.pack_cloud16(rec.data_ptr(), res.n_points) == res.n_points
+                local.append((pid, rec))
+            out = comm.gather(local, n_pairs_total=5, root=0)
+            if rank == 0:
+                q.put([(pid,) + unpack_records(r.cpu()) for pid, r in out])
+            else:
+                assert out is None
+    finally:
+        comm.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_real_rccl_fan_in_between_two_gpus(ctx):
+    """The C ABI's own transport for real: two processes, one GPU each, rsm_comm_create + rsm_gather_clouds (ncclSend /
+    ncclRecv group over xGMI).  Pair ids listed out of order, a pair nobody owns, an owned pair with an empty cloud:
+    rank 0 receives every cloud in pair order, equal to the single-process clouds."""
+    from reconstruction_amd.dist import Comm
+    owned = {0: [(3, PAIRS[0]), (0, PAIRS[2])], 1: [(4, None), (2, PAIRS[1])]}   # pair 1 belongs to nobody
+    want = {pid: ctx.match_pair(synth.config_small(**kw)) for r in owned for pid, kw in owned[r] if kw is not None}
+    uid = Comm.unique_id()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rccl_worker, args=(r, 2, uid, owned[r], q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [pid for pid, _, _ in res] == [0, 1, 2, 3, 4]
+    for pid, xyz, bgr in res:
+        if pid in want:
+            assert len(xyz) == want[pid].n_points > 0
+            assert np.array_equal(xyz, want[pid].xyz.astype(np.float32), equal_nan=True) and np.array_equal(bgr, want[pid].bgr)
+        else:
+            assert len(xyz) == 0
+
+
+def test_bench_rig_config_shards_ten_pairs_strong_scaling():
+    """bench.py --config c4s (BASELINE configs[3] at the shipped scale): the rig's ten pairs, pair % N -> rank, every step all
+    ten pairs + the gather of the ten clouds; strong scaling, so N = 1 and N = 2 (gloo stand-in) report the same V_top total."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = {}
+    for n, extra in ((1, {}), (2, {"RSM_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"})):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--config", "c4s",
+                            "--no-cpu-baseline", "--measure-traffic", "0"], capture_output=True, text=True, env=dict(env, **extra), cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        out[n] = json.loads(lines[0])
+    d1, d2 = out[1], out[2]
+    assert d1["scaling"] == d2["scaling"] == "strong" and d1["config"]["pairs"] == 10
+    assert d1["config"]["pairs_per_rank"] == [10] and d2["config"]["pairs_per_rank"] == [5, 5] and d2["n_gpus"] == 2
+    # value = sum of V_top over the ten pairs / step time: the same numerator at both N
+    v1 = d1["value"] * d1["ms_per_step"]
+    v2 = d2["value"] * d2["ms_per_step"]
+    assert abs(v1 - v2) <= 1e-3 * v1 and d1["value"] > 0
