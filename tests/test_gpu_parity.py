@@ -466,7 +466,7 @@ def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows):
             for v in range(2):
                 assert np.array_equal(res.disparity[v], fin["disparity"][v])
     finally:
-        ctx.set_option("refine_skew_from", 38)  # the defaults
+        ctx.set_option("refine_skew_from", 22)  # the defaults
         ctx.set_option("refine_skew_T", 4)
         ctx.set_option("refine_skew_min_px", 1000000)
         ctx.set_option("refine_skew_rows", 0)
