@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int
 //               whose parent row is NOMATCH search the entire other margin, .cpp:260-283: a handful of
 //               rows carrying as many evaluations as the rest of the level.)
 #define NCC_G 5
-#define NCC_WIDE 160
+#define NCC_WIDE 160 // the largest interval the band kernel takes (its LDS staging is sized for it); StageArgs::ncc_wide may lower the threshold
 #define RG_SLOTS 512 // rows per direction k_ncc_rowgemm can take (more: the surplus rows fall back to k_ncc_wide)
 #define RG_MIN 48 // wide pixels of a (direction, row) from which the row is matched by k_ncc_rowgemm instead of k_ncc_wide
 
@@ -339,7 +339,10 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
         Rr = min(Rr, W - 1 - R);
         if (L > Rr) active = false;
     }
-    const bool wide = active && (Rr - L + 1 > NCC_WIDE);
+    // a row that holds RG_MIN or more pixels with an interval longer than ncc_mid goes to a row kernel (k_ncc_rowstat counted them):
+    // there every such pixel leaves this kernel, elsewhere only those beyond its own limit
+    const int wide_from = (a.opt_no_rowgemm != 1 && a.wrow[NCC_WROW_MID(a.H) + blockIdx.z * a.H + y] >= RG_MIN) ? a.ncc_mid : NCC_WIDE;
+    const bool wide = active && (Rr - L + 1 > wide_from);
     // append of the wide pixels to the worklist of k_ncc_wide / the row kernels, ONE pair of atomics per workgroup
     // (per wave, the single list counter -- ~88 same-address atomics per microsecond -- was 2.2 ms of a 12.5 MP frame
     // of wide pixels)
@@ -766,20 +769,59 @@ typedef int rg_v4i __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) RgQuad {
     uint32_t a, b, c, d;
 };
-// the rows of a direction with at least RG_MIN wide pixels, in order: wrow[2H + dir (H + 1)] = count, then the rows
-__global__ __launch_bounds__(64) void k_rg_rows(StageArgs a) {
+// Per (direction, row), BEFORE the matchers run: how many pixels search an interval longer than ncc_mid, and the widest interval.
+// A row with RG_MIN or more of them is matched by a row kernel (every such pixel of it: the row kernels run at 260-330 G
+// pixel-candidate pairs per second from ~65 candidates on, the 5-candidate band kernel at ~190), and which one follows from the
+// widest interval (k_rg_rows).  One wave per row, 64 pixels per round.
+__global__ __launch_bounds__(256) void k_ncc_rowstat(StageArgs a, int mode) {
+    const DirArgs &d = a.d[blockIdx.z];
+    const int y = d.own.YL + (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (y > d.own.YR) return;
+    const int W = a.W, R = a.r;
+    int cnt = 0, wmax = 0;
+    for (int xb = d.own.XL; xb <= d.own.XR; xb += 64) { // uniform
+        const int x = xb + lane;
+        int width = 0;
+        if (x <= d.own.XR) {
+            const size_t pix = (size_t)y * W + x;
+            if (d.mask_own[pix] == 255) {
+                int L = mode == 0 ? d.oth.XL : (int)d.BL[pix], Rr = mode == 0 ? d.oth.XR : (int)d.BR[pix];
+                L = max(L, R);
+                Rr = min(Rr, W - 1 - R);
+                width = max(Rr - L + 1, 0);
+            }
+        }
+        cnt += __popcll(__ballot(width > a.ncc_mid));
+        wmax = max(wmax, width);
+    }
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) {
+        a.wrow[NCC_WROW_MID(a.H) + blockIdx.z * a.H + y] = cnt;
+        a.wrow[NCC_WROW_MAX(a.H) + blockIdx.z * a.H + y] = wmax;
+    }
+}
+// the rows of a direction with at least RG_MIN wide pixels, in order, as two lists ([0] = count, then the rows): list 0 for
+// k_ncc_rowgemm (rows whose widest interval exceeds ncc_slide_max: the int8 GEMM wins from ~500 candidates on), list 1 for
+// k_ncc_slide.  `force`: 2 = every row to the GEMM, 3 = every row to the sliding sums (A/B, tests).
+__global__ __launch_bounds__(64) void k_rg_rows(StageArgs a, int force) {
     const DirArgs &d = a.d[blockIdx.x];
-    int32_t *rowlist = a.wrow + 2 * a.H + blockIdx.x * (a.H + 1);
+    int32_t *list0 = a.wrow + NCC_WROW_LIST(a.H, 0) + blockIdx.x * (a.H + 1), *list1 = a.wrow + NCC_WROW_LIST(a.H, 1) + blockIdx.x * (a.H + 1);
     const int lane = threadIdx.x;
-    int seen = 0;
+    int seen0 = 0, seen1 = 0;
     for (int yb = d.own.YL; yb <= d.own.YR; yb += 64) { // uniform
         const int yy = yb + lane;
         const bool q = yy <= d.own.YR && a.wrow[blockIdx.x * a.H + yy] >= RG_MIN;
-        const unsigned long long mm = __ballot(q);
-        if (q) rowlist[1 + seen + __popcll(mm & ((1ull << lane) - 1ull))] = yy;
-        seen += __popcll(mm);
+        const bool slide = force == 3 || (force != 2 && q && a.wrow[NCC_WROW_MAX(a.H) + blockIdx.x * a.H + yy] <= a.ncc_slide_max);
+        const unsigned long long m0 = __ballot(q && !slide), m1 = __ballot(q && slide);
+        if (q && !slide) list0[1 + seen0 + __popcll(m0 & ((1ull << lane) - 1ull))] = yy;
+        if (q && slide) list1[1 + seen1 + __popcll(m1 & ((1ull << lane) - 1ull))] = yy;
+        seen0 += __popcll(m0);
+        seen1 += __popcll(m1);
     }
-    if (lane == 0) rowlist[0] = seen;
+    if (lane == 0) {
+        list0[0] = seen0;
+        list1[0] = seen1;
+    }
 }
 template <int R>
 __global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
@@ -797,7 +839,7 @@ __global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lg = lane >> 4;
     // blockIdx.y = slot: this workgroup takes the slot-th row of the direction with at least RG_MIN wide pixels (the few
     // wide pixels of other rows stay with k_ncc_wide), from the list k_rg_rows made.
-    const int32_t *rowlist = a.wrow + 2 * a.H + blockIdx.z * (a.H + 1); // [0] = number of rows, then the rows
+    const int32_t *rowlist = a.wrow + NCC_WROW_LIST(a.H, 0) + blockIdx.z * (a.H + 1); // [0] = number of rows, then the rows
     const int nrows = rowlist[0];
     for (int slot = blockIdx.y; slot < nrows; slot += gridDim.y) { // uniform
         __syncthreads(); // the previous row is done with the shared arrays
@@ -824,7 +866,7 @@ __global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
                 Rr = min(Rr, W - 1 - R);
                 if (L > Rr) active = false;
             }
-            const bool wide = active && (Rr - L + 1 > NCC_WIDE); // exactly k_ncc_dot4's test
+            const bool wide = active && (Rr - L + 1 > a.ncc_mid); // exactly k_ncc_dot4's test in a listed row
             const double Sa = wide ? (double)d.S1_own[pix] : 0.0;
             const double va = wide ? (double)n * (double)d.S2_own[pix] - Sa * Sa : 0.0;
             sPSa[tid] = Sa;
@@ -1011,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
     int *mF = mC + 4 * SL_COLS;                     // [4][SL_COLS]: bit 0 exact, bit 1 tie
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W;
-    const int32_t *rowlist = a.wrow + 2 * a.H + blockIdx.z * (a.H + 1); // [0] = number of rows, then the rows (k_rg_rows)
+    const int32_t *rowlist = a.wrow + NCC_WROW_LIST(a.H, 1) + blockIdx.z * (a.H + 1); // [0] = number of rows, then the rows (k_rg_rows)
     const int nrows = rowlist[0];
     __shared__ int s_planes[4];
     for (int q = lane; q < 2 * NV; q += 64) sV[q] = 0;
@@ -1033,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
                 int L = mode == 0 ? d.oth.XL : (int)d.BL[pix], Rr = mode == 0 ? d.oth.XR : (int)d.BR[pix];
                 L = max(L, R);
                 Rr = min(Rr, W - 1 - R);
-                if (Rr - L + 1 > NCC_WIDE) {
+                if (Rr - L + 1 > a.ncc_mid) {
                     dlo = min(dlo, L - x);
                     dhi = max(dhi, Rr - x);
                 }
@@ -1077,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
                 Rr = min(Rr, W - 1 - R);
                 if (L > Rr) active = false;
             }
-            const bool wide = active && (Rr - L + 1 > NCC_WIDE); // exactly k_ncc_dot4's test
+            const bool wide = active && (Rr - L + 1 > a.ncc_mid); // exactly k_ncc_dot4's test in a listed row
             const double s1 = wide ? (double)d.S1_own[pix] : 0.0;
             const double va = wide ? (double)n * (double)d.S2_own[pix] - s1 * s1 : 0.0;
             Sa[e] = s1;
@@ -1279,7 +1321,9 @@ static size_t slide_lds_bytes() {
 }
 
 template <int R>
-static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st) {
+static void launch_dot4(const StageArgs &a_in, int mode, dim3 grid, hipStream_t st) {
+    StageArgs a = a_in;
+    if (a.ncc_mid <= 0) a.ncc_mid = R >= 5 ? 64 : (R >= 3 ? 96 : NCC_WIDE); // 11x11 / 65 candidates: 261 against 177 G pairs/s; 5x5 / 65: 372 against 444
     constexpr int WS = 2 * R + 1, SA = NCC_TX + 2 * R, SB = NCC_CH + 2 * R + NCC_G + 3;
     const size_t lds = 16 + (size_t)WS * (SA + SB) * 4 + (size_t)(NCC_CH + NCC_G) * 9 + 16;
     if (mode == 2) { // the worklist was filled by launch_set_boundary
@@ -1287,27 +1331,32 @@ static void launch_dot4(const StageArgs &a, int mode, dim3 grid, hipStream_t st)
         if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
         return;
     }
+    // per row: pixels with long intervals and the widest interval (decides, before the matchers run, which rows the row kernels take)
+    if (a.opt_no_rowgemm != 1) hipLaunchKernelGGL(k_ncc_rowstat, dim3((grid.y + 3) / 4, 1, grid.z), dim3(256), 0, st, a, mode);
     // *a.ncc_cnt (wide-pixel count) is zero on entry: the caller hands every launch a fresh counter
     hipLaunchKernelGGL(k_ncc_dot4<R>, grid, dim3(NCC_TX), lds, st, a, mode);
     const size_t ldsw = (size_t)WS * (NCC_TX * NCC_G + 2 * R + NCC_G) * 4;
     if (ldsw > 65536) // radii 6 and 7 stage more than the default 64 KB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void *)k_ncc_wide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
     hipLaunchKernelGGL(k_ncc_wide<R>, dim3(8192), dim3(NCC_TX), ldsw, st, a, mode);
-    // rows of wide pixels (opt_no_rowgemm: 1 = no row kernel, 3 = sliding window sums, 0 / 2 = the int8 row GEMM on the
-    // matrix cores).  Measured on a 12.5 MP frame of wide pixels (profiles/r03_ncc_micro.log) the two formulations end
-    // within ~10 % of each other -- 15 x 15 / 257 candidates: 9.3 ms sliding, 10.5 ms row GEMM; 15 x 15 / 1025: 33.2 / 29.2 ms;
-    // whole pairs: C5 initial match 2.05 / 1.95 ms, C2 1.83 / 1.43 ms -- both are bound by the fp64 score epilogue
-    // (~25 VALU operations per pixel-candidate pair) rather than by how Sab is formed; the row GEMM is the default.
-    int kind = a.opt_no_rowgemm == 0 ? 2 : a.opt_no_rowgemm;
-    if (kind != 1) hipLaunchKernelGGL(k_rg_rows, dim3(a.ndir), dim3(64), 0, st, a);
-    if (kind == 2) // grid.y = row SLOTS: rows with many wide pixels are few (all of them only at a wide lowest level)
-        hipLaunchKernelGGL(k_ncc_rowgemm<R>, dim3((grid.x * NCC_TX + RG_PX - 1) / RG_PX, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), 0, st, a, mode);
-    if (kind == 3) {
-        const size_t lds_s = slide_lds_bytes<R>();
-        if (lds_s > 65536) // the attribute is per DEVICE: set on every launch, as for k_ncc_wide (contexts may live on several GPUs)
-            (void)hipFuncSetAttribute((const void *)k_ncc_slide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-        const int tiles = (grid.x * NCC_TX + (SL_COLS - 2 * R) - 1) / (SL_COLS - 2 * R);
-        hipLaunchKernelGGL(k_ncc_slide<R>, dim3((tiles + 3) / 4, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), lds_s, st, a, mode);
+    // Rows of wide pixels: two formulations of the same scores (profiles/r04_ncc_micro.log, 12.5 MP frame, every pixel wide):
+    // sliding window sums 11x11 / 129 candidates 4.9 ms (330 G pairs/s), 15x15 / 257 9.4 ms, 15x15 / 1025 33.7 ms; int8 row
+    // GEMM on the matrix cores 6.2 / 10.1 / 28.8 ms -- the GEMM wins from ~500 candidates on (C2's rows below an empty parent row
+    // search 2048), the sliding sums below.  k_rg_rows sorts the rows by their widest interval (opt_no_rowgemm: 0 = that choice,
+    // 1 = no row kernel, 2 = every row to the GEMM, 3 = every row to the sliding sums).
+    const int kind = a.opt_no_rowgemm;
+    if (kind != 1) {
+        hipLaunchKernelGGL(k_rg_rows, dim3(a.ndir), dim3(64), 0, st, a, kind);
+        // grid.y = row SLOTS: rows with many wide pixels are few (all of them only at a wide lowest level)
+        if (kind != 3)
+            hipLaunchKernelGGL(k_ncc_rowgemm<R>, dim3((grid.x * NCC_TX + RG_PX - 1) / RG_PX, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), 0, st, a, mode);
+        if (kind != 2) {
+            const size_t lds_s = slide_lds_bytes<R>();
+            if (lds_s > 65536) // the attribute is per DEVICE: set on every launch, as for k_ncc_wide (contexts may live on several GPUs)
+                (void)hipFuncSetAttribute((const void *)k_ncc_slide<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            const int tiles = (grid.x * NCC_TX + (SL_COLS - 2 * R) - 1) / (SL_COLS - 2 * R);
+            hipLaunchKernelGGL(k_ncc_slide<R>, dim3((tiles + 3) / 4, min((int)grid.y, RG_SLOTS), grid.z), dim3(256), lds_s, st, a, mode);
+        }
     }
     if (!a.opt_no_exact) hipLaunchKernelGGL(k_ncc_exact, dim3(128), dim3(256), 0, st, a, mode);
 }

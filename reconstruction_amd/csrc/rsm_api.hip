@@ -116,6 +116,9 @@ struct rsm_ctx {
     int opt_ncc_bytes = 0;
     int opt_no_exact = 0;
     int opt_no_rowgemm = 0;
+    int opt_ncc_mid = 0;         // rows that hold many (RG_MIN) pixels with intervals longer than this go to a row kernel; 0 = by window size
+                                 // (measured crossover against the band kernel: 11x11 from ~40 candidates on, 5x5 beyond 160)
+    int opt_ncc_slide_max = 512; // rows whose widest interval has at most this many candidates take the sliding-sums kernel, the others the int8 row GEMM
     int opt_heavy_from_sweep = 1;  // ... from this sweep of the level on
     int opt_heavy_min_px = 400000; // ... from this many margin pixels on (smaller levels are launch-bound themselves)
     int opt_heavy_lanes = 2;     // 2: the single-sweep part and the time-skewed part of a level's refine take turns separately (lanes 0 / 1)
@@ -361,7 +364,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->rf_cnt, 32 + 2 * (size_t)in->height); // level k uses rf_cnt + k: [0] wide-pixel count, [16 + dir * H + y] Rematch pixels of a row
     DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
     DALLOC(c, c->tie_list, 2 * px + 64);
-    DALLOC(c, c->wrow, 4 * (size_t)in->height + 16); // [2H] wide pixels per row, then per direction the list of GEMM rows
+    DALLOC(c, c->wrow, NCC_WROW_INTS((size_t)in->height)); // per (direction, row) counters and the row kernels' row lists (rsm_dev.h)
     c->upd_cap = (int)std::min<size_t>(65536, std::max<size_t>(1024, px / 8));
     DALLOC(c, c->upd_list, (size_t)RF_UPD_SHARDS * c->upd_cap);
     DALLOC(c, c->upd_cnt, 2 * RF_UPD_SHARDS);
@@ -472,6 +475,8 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_defer_to")) c->opt_refine_defer_to = (int)value;
     else if (!strcmp(name, "refine_defer_min_px")) c->opt_refine_defer_min_px = (double)value;
     else if (!strcmp(name, "wide_rows")) c->opt_no_rowgemm = (value >= 0 && value <= 3) ? (int)value : 0;
+    else if (!strcmp(name, "ncc_mid")) c->opt_ncc_mid = value <= 0 ? 0 : (int)std::max(8LL, std::min(value, 160LL));
+    else if (!strcmp(name, "ncc_slide_max")) c->opt_ncc_slide_max = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
     else if (!strcmp(name, "refine_multi_from")) c->opt_refine_multi_from = (int)std::max(0LL, std::min(value, 100000LL));
     else if (!strcmp(name, "refine_multi_min_px")) c->opt_refine_multi_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
@@ -527,6 +532,8 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.tie_cnt = c->tie_cnt + 2 * k;
     a.wrow = c->wrow;
     a.opt_no_rowgemm = c->opt_no_rowgemm;
+    a.ncc_mid = c->opt_ncc_mid;
+    a.ncc_slide_max = c->opt_ncc_slide_max;
     a.upd_list = c->upd_list;
     a.upd_cnt = c->upd_cnt;
     a.upd_cap = c->upd_cap;
@@ -1211,8 +1218,8 @@ bool setup_match(rsm_ctx *c, Tmp &t, const uint8_t *img_own, const uint8_t *img_
     b.tl = t.alloc<uint32_t>(px + 64);
     b.tc = t.alloc<int32_t>(2);
     if (b.tc) (void)hipMemsetAsync(b.tc, 0, 2 * sizeof(int), c->stream);
-    b.wr = t.alloc<int32_t>(4 * (size_t)H + 16);
-    if (b.wr) (void)hipMemsetAsync(b.wr, 0, sizeof(int32_t) * (4 * (size_t)H + 16), c->stream);
+    b.wr = t.alloc<int32_t>(NCC_WROW_INTS((size_t)H));
+    if (b.wr) (void)hipMemsetAsync(b.wr, 0, sizeof(int32_t) * NCC_WROW_INTS((size_t)H), c->stream);
     b.i4o = t.alloc<uint32_t>(px);
     b.i4t = t.alloc<uint32_t>(px);
     b.S1o = t.alloc<int32_t>(px);
@@ -1232,6 +1239,8 @@ StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, cons
     a.opt_ncc_bytes = c->opt_ncc_bytes;
     a.opt_no_exact = c->opt_no_exact;
     a.opt_no_rowgemm = c->opt_no_rowgemm;
+    a.ncc_mid = c->opt_ncc_mid;
+    a.ncc_slide_max = c->opt_ncc_slide_max;
     a.row_lo = 0;
     a.row_hi = INT_MAX;
     a.ndir = 1;

@@ -50,6 +50,14 @@ struct RfMiss {
 };
 #define RF_UPD_SHARDS 32 // append counters (one counter serialises at ~88 appends per microsecond)
 
+// ints of StageArgs::wrow for a level of H rows: [0, 2H) wide pixels per (direction, row) appended by k_ncc_dot4; then two row lists of
+// 2 (H + 1) ints (k_ncc_rowgemm's, k_ncc_slide's); then [2H] pixels with an interval longer than ncc_mid and [2H] the widest interval, per
+// (direction, row), from k_ncc_rowstat
+#define NCC_WROW_INTS(H) (10 * (H) + 32)
+#define NCC_WROW_LIST(H, which) (2 * (H) + (which) * (2 * (H) + 2))
+#define NCC_WROW_MID(H) (6 * (H) + 4)
+#define NCC_WROW_MAX(H) (8 * (H) + 4)
+
 struct StageArgs {
     DirArgs d[2];
     int ndir;    // 1 or 2 (gridDim.z)
@@ -77,6 +85,8 @@ struct StageArgs {
     int32_t *tie_cnt;   // NCC: [0] entries of tie_list after an initial-match launch, [1] after a Rematch launch (zero on entry)
     int32_t *wrow;     // NCC: [dir * H + y] wide pixels of a row after k_ncc_dot4 (zero on entry); rows with many go to k_ncc_rowgemm
     int opt_no_rowgemm; // A/B: every wide pixel through k_ncc_wide
+    int ncc_mid;        // NCC: in a row with many pixels of long intervals, every interval longer than this joins the row kernels (<= NCC_WIDE = 160, the band kernel's limit)
+    int ncc_slide_max;  // NCC: rows whose widest interval is at most this take k_ncc_slide, the others k_ncc_rowgemm
     int32_t *ncc_cnt;  // NCC: [0] number of wide pixels in rf_list (zero before an initial-match launch), [16 + dir * H + y] Rematch pixels of a row
 };
 
