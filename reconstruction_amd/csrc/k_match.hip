@@ -286,6 +286,10 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int
 #define NCC_WIDE 160 // the largest interval the band kernel takes (its LDS staging is sized for it); StageArgs::ncc_wide may lower the threshold
 #define RG_SLOTS 512 // rows per direction k_ncc_rowgemm can take (more: the surplus rows fall back to k_ncc_wide)
 #define RG_MIN 48 // wide pixels of a (direction, row) from which the row is matched by k_ncc_rowgemm instead of k_ncc_wide
+#define RG_SLIDE_MIN 1024 // wide pixels of a row from which k_ncc_slide takes it (when its widest interval allows): C2's rows below an empty parent row at
+                          // the lower levels (128...1024 pixels x as many candidates) run faster in the GEMM (initial match 1.43 against 1.83 ms)
+#define RG_MID_MIN 512 // pixels of a row with an interval beyond the band kernel's crossover (ncc_mid) from which ALL of them join the row
+                       // kernel: a short row (C2's lowest level: 128 pixels x 128 candidates) is latency-bound there (initial match 1.40 -> 1.88 ms)
 
 // offers the candidate group c0..c0+G-1 (their G accumulated Sab) to the running best, ascending columns
 template <int R>
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_dot4(StageArgs a, int mode) {
     }
     // a row that holds RG_MIN or more pixels with an interval longer than ncc_mid goes to a row kernel (k_ncc_rowstat counted them):
     // there every such pixel leaves this kernel, elsewhere only those beyond its own limit
-    const int wide_from = (a.opt_no_rowgemm != 1 && a.wrow[NCC_WROW_MID(a.H) + blockIdx.z * a.H + y] >= RG_MIN) ? a.ncc_mid : NCC_WIDE;
+    const int wide_from = (a.opt_no_rowgemm != 1 && a.wrow[NCC_WROW_MID(a.H) + blockIdx.z * a.H + y] >= RG_MID_MIN) ? a.ncc_mid : NCC_WIDE;
     const bool wide = active && (Rr - L + 1 > wide_from);
     // append of the wide pixels to the worklist of k_ncc_wide / the row kernels, ONE pair of atomics per workgroup
     // (per wave, the single list counter -- ~88 same-address atomics per microsecond -- was 2.2 ms of a 12.5 MP frame
@@ -811,7 +815,9 @@ __global__ __launch_bounds__(64) void k_rg_rows(StageArgs a, int force) {
     for (int yb = d.own.YL; yb <= d.own.YR; yb += 64) { // uniform
         const int yy = yb + lane;
         const bool q = yy <= d.own.YR && a.wrow[blockIdx.x * a.H + yy] >= RG_MIN;
-        const bool slide = force == 3 || (force != 2 && q && a.wrow[NCC_WROW_MAX(a.H) + blockIdx.x * a.H + yy] <= a.ncc_slide_max);
+        // the sliding sums pay on long rows (a workgroup = four 128-column tiles) of moderate intervals; short rows are latency-bound there
+        const bool slide = force == 3 || (force != 2 && q && a.wrow[NCC_WROW_MAX(a.H) + blockIdx.x * a.H + yy] <= a.ncc_slide_max &&
+                                          a.wrow[blockIdx.x * a.H + yy] >= RG_SLIDE_MIN);
         const unsigned long long m0 = __ballot(q && !slide), m1 = __ballot(q && slide);
         if (q && !slide) list0[1 + seen0 + __popcll(m0 & ((1ull << lane) - 1ull))] = yy;
         if (q && slide) list1[1 + seen1 + __popcll(m1 & ((1ull << lane) - 1ull))] = yy;
@@ -844,6 +850,7 @@ __global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
     for (int slot = blockIdx.y; slot < nrows; slot += gridDim.y) { // uniform
         __syncthreads(); // the previous row is done with the shared arrays
         const int y = rowlist[1 + slot];
+        const int wide_from = a.wrow[NCC_WROW_MID(a.H) + blockIdx.z * a.H + y] >= RG_MID_MIN ? a.ncc_mid : NCC_WIDE; // as k_ncc_dot4 chose for this row
         if (tid == 0) {
             s_lohi[0] = 0x7fffffff;
             s_lohi[1] = -1;
@@ -866,7 +873,7 @@ __global__ __launch_bounds__(256) void k_ncc_rowgemm(StageArgs a, int mode) {
                 Rr = min(Rr, W - 1 - R);
                 if (L > Rr) active = false;
             }
-            const bool wide = active && (Rr - L + 1 > a.ncc_mid); // exactly k_ncc_dot4's test in a listed row
+            const bool wide = active && (Rr - L + 1 > wide_from); // exactly k_ncc_dot4's test
             const double Sa = wide ? (double)d.S1_own[pix] : 0.0;
             const double va = wide ? (double)n * (double)d.S2_own[pix] - Sa * Sa : 0.0;
             sPSa[tid] = Sa;
@@ -1059,6 +1066,7 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
     for (int q = lane; q < 2 * NV; q += 64) sV[q] = 0;
     for (int slot = blockIdx.y; slot < nrows; slot += gridDim.y) { // uniform
         const int y = rowlist[1 + slot];
+        const int wide_from = a.wrow[NCC_WROW_MID(a.H) + blockIdx.z * a.H + y] >= RG_MID_MIN ? a.ncc_mid : NCC_WIDE; // as k_ncc_dot4 chose for this row
         // A workgroup owns FOUR consecutive tiles.  How its 4 waves share them depends on the disparity range the tiles
         // span (device data: a pre-pass measures it): up to ~2 chunks of planes per tile every wave takes a tile of its own
         // and walks all its planes (setup and merge amortised over 4 times the work: 257 candidates are 65 planes per
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
                 int L = mode == 0 ? d.oth.XL : (int)d.BL[pix], Rr = mode == 0 ? d.oth.XR : (int)d.BR[pix];
                 L = max(L, R);
                 Rr = min(Rr, W - 1 - R);
-                if (Rr - L + 1 > a.ncc_mid) {
+                if (Rr - L + 1 > wide_from) {
                     dlo = min(dlo, L - x);
                     dhi = max(dhi, Rr - x);
                 }
@@ -1119,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_ncc_slide(StageArgs a, int mode) {
                 Rr = min(Rr, W - 1 - R);
                 if (L > Rr) active = false;
             }
-            const bool wide = active && (Rr - L + 1 > a.ncc_mid); // exactly k_ncc_dot4's test in a listed row
+            const bool wide = active && (Rr - L + 1 > wide_from); // exactly k_ncc_dot4's test
             const double s1 = wide ? (double)d.S1_own[pix] : 0.0;
             const double va = wide ? (double)n * (double)d.S2_own[pix] - s1 * s1 : 0.0;
             Sa[e] = s1;
