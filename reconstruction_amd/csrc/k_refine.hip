@@ -125,14 +125,46 @@ __device__ __forceinline__ double refine_update(int mode, double dC, double dE, 
     return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
 }
 
+// exp_neg2 without the underflow selects: the same bits for t1, t2 <= 745.13 (callers guarantee it with a wave-uniform test).
+__device__ __forceinline__ void exp_neg2_small(double t1, double t2, double &w1, double &w2) {
+    const double ln2HI = 0x1.62e42feep-1, ln2LO = 0x1.a39ef35793c76p-33, invln2 = 0x1.71547652b82fep+0;
+    double r1 = -t1, r2 = -t2;
+    const int k1 = (int)__builtin_fma(invln2, r1, -0.5), k2 = (int)__builtin_fma(invln2, r2, -0.5);
+    const double tk1 = (double)k1, tk2 = (double)k2;
+    r1 = __builtin_fma(-tk1, ln2HI, r1);
+    r2 = __builtin_fma(-tk2, ln2HI, r2);
+    r1 = __builtin_fma(-tk1, ln2LO, r1);
+    r2 = __builtin_fma(-tk2, ln2LO, r2);
+    double p1 = 0x1.6124613a86d09p-33, p2 = 0x1.6124613a86d09p-33;
+#define RF_H(c)                      \
+    p1 = __builtin_fma(p1, r1, (c)); \
+    p2 = __builtin_fma(p2, r2, (c));
+    RF_H(0x1.1eed8eff8d898p-29) RF_H(0x1.ae64567f544e4p-26) RF_H(0x1.27e4fb7789f5cp-22) RF_H(0x1.71de3a556c734p-19)
+    RF_H(0x1.a01a01a01a01ap-16) RF_H(0x1.a01a01a01a01ap-13) RF_H(0x1.6c16c16c16c17p-10) RF_H(0x1.1111111111111p-7)
+    RF_H(0x1.5555555555555p-5) RF_H(0x1.5555555555555p-3) RF_H(0x1.0000000000000p-1) RF_H(1.0) RF_H(1.0)
+#undef RF_H
+    w1 = __builtin_ldexp(p1, k1);
+    w2 = __builtin_ldexp(p2, k2);
+}
+
 // refine_update for mode 3 without a divergent branch (k_refine_skew's straight-line path, entered by all lanes): the same
-// operations on the same operands; where wx + wy == 0 the quotient is computed (0 / 0) and replaced.
-__device__ __forceinline__ double refine_update3(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws) {
-    const double pdp = (pwp == 0) ? 0.0 : dC + delta;
+// operations on the same operands.  The three special cases of the general form -- a weight beyond exp's underflow threshold
+// (|ex| or |ey| > 27), both weights zero (.cpp:667-668), pwp == 0 (.cpp:642-643) -- are tested ONCE for the whole row (`lv`: the
+// lanes whose result is kept) and handled by the general sequence when any kept lane needs it; otherwise their compares and
+// selects (10 of ~135 vector instructions) are not executed at all.
+__device__ __forceinline__ double refine_update3(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws, bool lv) {
     const double ex = fabs(dE - dC) - fabs(dW - dC);
     const double ey = fabs(dS - dC) - fabs(dN - dC);
+    const double tx = ex * ex, ty = ey * ey;
+    if (!__ballot(lv && (fmax(tx, ty) > 700.0 || pwp == 0))) { // wave-uniform; the usual case
+        double wx, wy;
+        exp_neg2_small(tx, ty, wx, wy); // .cpp:665-666; both weights >= exp(-700) > 0
+        const double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));
+        return ((dC + delta) * pwp + ws * ds) / (pwp + ws); // .cpp:671
+    }
+    const double pdp = (pwp == 0) ? 0.0 : dC + delta;
     double wx, wy;
-    exp_neg2(ex * ex, ey * ey, wx, wy); // .cpp:665-666
+    exp_neg2(tx, ty, wx, wy); // .cpp:665-666
     const double sw = wx + wy;
     double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
     if (__ballot(sw == 0)) // both weights underflowed somewhere in the row (|ex|, |ey| > 27): .cpp:667-668, wave-uniform and rare
@@ -916,7 +948,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 const double2 pd = way ? e1 : e0;
                 if (!RF_EXP(2)) {
                     if (!__ballot(lv && !(ew && ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
-                        const double u = refine_update3(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
+                        const double u = refine_update3(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, lv);
                         val = lv ? u : dC;
                     } else if (lv) {
                         const int mode = (int)ew + (int)ns * 2; // .cpp:620
