@@ -289,7 +289,7 @@ def main():
                 dom = k
         top = prof_acc[dom]
         spl = int(round(top["bytes"] / max(1, top["launches"]) / light_b)) if light_b > 0 else 1  # sweeps per launch
-        kname = {"refine_skew_top": "k_refine_skew<%d,1> (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level)" % (spl, spl),
+        kname = {"refine_skew_top": "k_refine_skew<%d,1, (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level; the third template argument is the variant: option refine_skew_variant)" % (spl, spl),
                  "refine_multi_top": "k_refine_multi<1> (DisparityRefine, two Jacobi sweeps per launch, top level)",
                  "refine_light_top": "k_refine_sweep<1,0> (DisparityRefine Jacobi sweep, top level)"}[dom]
         multi = dom != "refine_light_top"

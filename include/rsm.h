@@ -216,8 +216,11 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *   "refine_band_mb" / "refine_band_rows"   time-skewed band schedule of the refine sweeps (0 = whole-frame, default)
  *   "refine_skew_from" / "refine_skew_T" / "refine_skew_min_px" / "refine_skew_waves" / "refine_skew_rows"   time-skewed refine
  *                          sweeps (k_refine_skew): T (2..4, default 4) sweeps per launch from that sweep of a level on (default
- *                          38; 0 = never) at levels with at least min_px margin pixels per direction (default 1 M: the two
+ *                          22; 0 = never) at levels with at least min_px margin pixels per direction (default 1 M: the two
  *                          largest levels of a 12 MP pair), aiming at `waves` workgroups (default 1280) or `rows` rows per chunk
+ *   "refine_skew_variant"  0 (default) the shipped time-skewed kernel; bit 0 / bit 1 = two bit-identical restatements measured
+ *                          slower (a row's staging shared by two waves / lane-mask predicates + unscaled divisions), kept for A/B
+ *   "refine_prefill"       1 (default): the first sweep of a level also fills the second cache way (0: A/B)
  *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)
  *   "refine_defer_from" / "refine_defer_to" / "refine_defer_min_px"   sweeps whose data-term cache misses are listed and served
  *                          by a second kernel, a lane per miss, instead of inside the sweep (to = 0 = never, default)
@@ -267,6 +270,10 @@ int rsm_stage_refine(rsm_ctx *ctx, const int16_t *disp_in, const uint8_t *img_ow
                      const rsm_boundary *own, double *disp_out);
 /* the specified exp(-t) of DisparityRefine's weights (CStereoMatching.cpp:665-666 call exp) on n values */
 int rsm_stage_exp_neg(rsm_ctx *ctx, const double *t, int64_t n, double *out);
+/* DisparityRefine's two divisions (CStereoMatching.cpp:669,671) as the time-skewed kernel evaluates them on its common path --
+ * the hardware's fp64 division sequence without its operand-scaling and fix-up steps -- beside the compiler's a / b, on n operand
+ * pairs: the parity tests hold the two equal bit for bit over the operand range the kernel's guard admits */
+int rsm_stage_div_unscaled(rsm_ctx *ctx, const double *a, const double *b, int64_t n, double *q_fast, double *q_ieee);
 int rsm_stage_cloud(rsm_ctx *ctx, const double *disp, const uint8_t *mask_org, const uint8_t *img_own,
                     int W, int H, const double *Q, double scale, const double *R_final,
                     const double *T_final, const rsm_boundary *own, double *xyz, uint8_t *bgr,

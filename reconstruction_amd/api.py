@@ -485,6 +485,16 @@ class Context:
         self._chk(self._lib.rsm_stage_exp_neg(self._h, _p(t), C.c_int64(t.size), _p(out)))
         return out
 
+    def div_unscaled(self, a, b):
+        """(q_fast, q_ieee): the time-skewed refine kernel's division without operand scaling beside the device's a / b."""
+        a = np.ascontiguousarray(a, np.float64).ravel()
+        b = np.ascontiguousarray(b, np.float64).ravel()
+        assert a.shape == b.shape
+        qf = np.zeros(a.shape, np.float64)
+        qi = np.zeros(a.shape, np.float64)
+        self._chk(self._lib.rsm_stage_div_unscaled(self._h, _p(a), _p(b), C.c_int64(a.size), _p(qf), _p(qi)))
+        return qf, qi
+
     def disparity_to_cloud(self, disp, mask_org, img_own, Q, scale, R, T, own):
         d = np.ascontiguousarray(disp, np.float64); mask_org = _u8(mask_org); img_own = _u8(img_own)
         H, W = d.shape

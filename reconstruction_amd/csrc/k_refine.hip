@@ -147,6 +147,70 @@ __device__ __forceinline__ void exp_neg2_small(double t1, double t2, double &w1,
     w2 = __builtin_ldexp(p2, k2);
 }
 
+// fp64 division a / b as the hardware sequence the compiler emits for it (v_div_scale x2, v_rcp, two Newton steps, quotient,
+// residual, v_div_fmas, v_div_fixup) WITHOUT the operand scaling and the fix-up: 8 instead of 11 instructions, identical bits
+// whenever v_div_scale leaves both operands unscaled and v_div_fixup passes the quotient through -- a and b finite and non-zero,
+// b normal, |exponent(a) - exponent(b)| < 768, biased exponent(a) > 53, a / b normal (ISA: V_DIV_SCALE_F64).  The caller's guard:
+// 2^-300 < |a| < 2^300 and 2^-300 < b < 2^300 (tests/test_gpu_golden.py holds it to the IEEE quotient on 4 M operand pairs).
+__device__ __forceinline__ double div_unscaled(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, y, q);
+}
+
+// test entry (rsm_stage_div_unscaled): the trimmed division beside the compiler's on arrays
+__global__ void k_div_unscaled(const double *a, const double *b, double *q_fast, double *q_ieee, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        q_fast[i] = div_unscaled(a[i], b[i]);
+        q_ieee[i] = a[i] / b[i];
+    }
+}
+void launch_div_unscaled(const double *a, const double *b, double *q_fast, double *q_ieee, long long n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_div_unscaled, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, q_fast, q_ieee, n);
+}
+
+// Lane masks straight from the compare (one v_cmp into a scalar pair), combined with scalar logic; rf_sel turns a mask back into
+// a select / branch condition at no cost.  A ballot of a COMBINED bool costs two vector instructions (v_cndmask 0 / 1 + v_cmp).
+#define RF_FNE(x, y) __builtin_amdgcn_fcmp((x), (y), 14) // unordered or not equal: C's !=
+#define RF_FGT(x, y) __builtin_amdgcn_fcmp((x), (y), 2)  // ordered and greater: C's >
+#define RF_IEQ(x, y) __builtin_amdgcn_sicmp((x), (y), 32)
+#define rf_sel(m) __builtin_amdgcn_inverse_ballot_w64(m)
+
+// refine_update3 with the predicates as lane masks and both divisions unscaled (k_refine_skew, round 4): m_lv = the lanes whose
+// result is kept.  The row takes the general sequence when any kept lane is outside the unscaled division's guard -- a weight
+// below e^-200 (the reference's exp underflow, .cpp:667-668, is inside that case), a numerator that is zero or tiny (a zero sum of
+// neighbours; pwp == 0 with ws * ds == 0: (dC + delta) * 0 = +-0 otherwise adds like .cpp:642-643's pdp = 0) -- and whenever ws is
+// outside [2^-200, 2^200] (wsok: pwp is in [0, 1], so pwp + ws is in range with it).
+__device__ __forceinline__ double refine_update3m(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws,
+                                                  unsigned long long m_lv, bool wsok) {
+    const double ex = fabs(dE - dC) - fabs(dW - dC);
+    const double ey = fabs(dS - dC) - fabs(dN - dC);
+    const double tx = ex * ex, ty = ey * ey;
+    if (wsok) { // kernel-uniform
+        double wx, wy;
+        exp_neg2_small(tx, ty, wx, wy); // .cpp:665-666; the same bits as exp_neg for t <= 745 (guard below: <= 200)
+        const double a1 = wx * (dE + dW) + wy * (dN + dS);
+        const double ds = div_unscaled(a1, 2 * (wx + wy)); // the denominator is in [2^-287, 4]
+        const double a2 = (dC + delta) * pwp + ws * ds;
+        const double u = div_unscaled(a2, pwp + ws);        // .cpp:671
+        const unsigned long long m_bad = RF_FGT(fmax(tx, ty), 200.0) | ~(RF_FGT(fabs(a1), 0x1p-300) & RF_FGT(fabs(a2), 0x1p-300));
+        if (!(m_lv & m_bad)) return u; // wave-uniform; the usual case
+    }
+    const double pdp = (pwp == 0) ? 0.0 : dC + delta;
+    double wx, wy;
+    exp_neg2(tx, ty, wx, wy); // .cpp:665-666
+    const double sw = wx + wy;
+    double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
+    ds = (sw == 0) ? (dE + dW + dS + dN) / 4 : ds; // .cpp:667-668
+    return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
+}
+
 // refine_update for mode 3 without a divergent branch (k_refine_skew's straight-line path, entered by all lanes): the same
 // operations on the same operands.  The three special cases of the general form -- a weight beyond exp's underflow threshold
 // (|ex| or |ey| > 27), both weights zero (.cpp:667-668), pwp == 0 (.cpp:642-643) -- are tested ONCE for the whole row (`lv`: the
@@ -824,7 +888,13 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
 // scatters afterwards (another strip may be staging the same pixel's entries at that moment: an in-place write could
 // be read torn).  At most one record per (pixel, way) and launch, so k_refine_apply never sees two writers of a slot.
 // Values are those of T single sweeps, bit for bit (tests/test_gpu_parity.py).
-template <int T, int TOP>
+// V (option refine_skew_variant, T = 4; 0 = the shipped kernel) holds two round-4 restatements that compute the same bits with
+// less work per wave and are SLOWER, kept as measured evidence of what bounds this kernel (not VALU issue slots,
+// not the staging wave's extra work -- the waves' own dependent chains and the launch's tail):
+//   V & 1: the staging of a row shared by two waves (below);
+//   V & 2: the row's predicates as lane masks and the mode-3 update with unscaled divisions (refine_update3m): 8 % fewer
+//          vector instructions per launch (95.8 M against 104.1 M), 12 % more scalar ones, 0.328 ms per launch against 0.310.
+template <int T, int TOP, int V>
 __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_refine_skew(StageArgs a) {
     constexpr int NE = 2 * T + 1;  // rows of cache entries resident: row r is staged in step r - 1 and last used in step r + 2T - 1
     constexpr int UW = 64 - 2 * T; // columns a strip owns
@@ -853,6 +923,8 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int cy_lo = max(YL + 1, ya - (T - t)), cy_hi = min(YR - 1, yb - 1 + (T - t));
     const int cx_lo = max(XL + 1, xa - (T - t)), cx_hi = min(XR - 1, xb - 1 + (T - t));
     const bool colok = x >= cx_lo && x <= cx_hi;
+    const unsigned long long m_col = __builtin_amdgcn_ballot_w64(colok), m_own = __builtin_amdgcn_ballot_w64(xown);
+    const bool wsok = a.ws >= 0x1p-200 && a.ws <= 0x1p200; // refine_update3m's division guard
     // A row is loaded two steps before it is needed (its loads are issued in step row - 2, it goes to LDS at the end of
     // step row - 1 and is first read in step row): one step of update math does not cover the memory latency under
     // load.  Waves 0 and 1 take the even and the odd rows, so a wave's staging registers are busy for two steps and the
@@ -861,19 +933,29 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     uint32_t nk0 = 0, nk1 = 0; // packed only when they go to LDS: nothing may consume a loaded value in the step that issues the load
     const uint16_t *__restrict__ keys = (const uint16_t *)d.rf_key;
     const unsigned xcu0 = (unsigned)xc; // row pointers are wave-uniform, the column a 32-bit lane offset: no 64-bit address arithmetic per lane
+    // V & 1 (T = 4): the staging of a row is shared by two waves -- waves 0 / 1 take the state and the keys of the even / odd rows,
+    // waves 2 / 3 both ways' (pwp, delta) -- so that every wave stages every other step (3 or 4 loads, 2 or 3 LDS writes) instead
+    // of two waves carrying all seven loads and five writes while the other two wait at the barrier.
+    constexpr bool BAL = (V & 1) && T == 4;
+    const bool st_lo = !BAL || wid < 2, st_hi = !BAL || wid >= 2; // what this wave stages: state + keys / the entries
     auto load_row = [&](int row) {
         const size_t p = (size_t)row * W;
         unsigned xcu = xcu0;
         asm volatile("" : "+v"(xcu)); // keeps (array + column) from being hoisted into seven 64-bit lane addresses
-        nd = (in + p)[xcu];
-        nk0 = (keys + p)[xcu];
-        nk1 = (keys + p + way1)[xcu];
-        np0 = (d.rf_pwp + p)[xcu];
-        nq0 = (d.rf_delta + p)[xcu];
-        np1 = (d.rf_pwp + p + way1)[xcu];
-        nq1 = (d.rf_delta + p + way1)[xcu];
+        if (st_lo) {
+            nd = (in + p)[xcu];
+            nk0 = (keys + p)[xcu];
+            nk1 = (keys + p + way1)[xcu];
+        }
+        if (st_hi) {
+            np0 = (d.rf_pwp + p)[xcu];
+            nq0 = (d.rf_delta + p)[xcu];
+            np1 = (d.rf_pwp + p + way1)[xcu];
+            nq1 = (d.rf_delta + p + way1)[xcu];
+        }
     };
-    if (wid == (y0 & 1)) load_row(y0);
+    const int spar = BAL ? (wid & 1) : wid; // this wave stages the rows of this parity (!BAL: waves 0 and 1 only)
+    if (spar == (y0 & 1)) load_row(y0);
     // This wave's row in step s is r = s - 2t + 1; e = (r - y0) % NE is kept as a counter.
     int r = y0 - 2 * t, e = ((r - y0) % NE + NE) % NE;
 // Timing experiments (results invalid; -DRF_SKEW_EXP=bits: 1 no staging loads, 2 no update math, 4 no barrier, 8 misses
@@ -903,7 +985,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         nsteps++;
 #endif
-        if (wid == (s & 1) && s + 2 <= y1 && !RF_EXP(1)) load_row(s + 2);
+        if (spar == (s & 1) && s + 2 <= y1 && !RF_EXP(1)) load_row(s + 2);
         RF_TICK(0) // staging loads issued
         if (r >= y0 && r <= y1) { // wave-uniform
             // one LDS round trip: the five state values, the keys and BOTH ways' entries (the way depends on dC)
@@ -923,7 +1005,43 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             operands();
             double val = dC;
             RF_TICK(1) // LDS operands arrived
-            if (r >= cy_lo && r <= cy_hi) { // wave-uniform: rows sweep t can compute here
+            if ((V & 2) && r >= cy_lo && r <= cy_hi) { // wave-uniform: rows sweep t can compute here; predicates as lane masks
+                const double NM = (double)NOMATCH;
+                const unsigned long long m_lv = m_col & RF_FNE(dC, NM); // .cpp:613
+                const unsigned long long m_ew = RF_FNE(dE, NM) & RF_FNE(dW, NM), m_ns = RF_FNE(dS, NM) & RF_FNE(dN, NM); // .cpp:620
+                const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
+                const int way = rel & 1;
+                const int crel = (int)(int16_t)(kk >> (way << 4));
+                const unsigned long long m_miss = RF_EXP(8) ? 0ull : m_lv & (m_ew | m_ns) & ~RF_IEQ(crel, rel);
+                // (keeps both entry reads in the first LDS batch: they are dead on the miss path, which reloads them, and
+                // would otherwise sink below it and add a second LDS round trip to every row)
+                asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
+                if (m_miss) { // wave-uniform, rare
+                    skew_miss(a, d, W, H, x, xa - T, r, rel, way, lane, rf_sel(m_miss), xown && r >= ya && r < yb, cnt, shard, s_ent[e], s_key[e], s_emit[e], kk, s_ml[wid]);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    operands(); // from LDS again (the entries now with the new ones): nothing lives in registers across the data-term routine
+                    asm volatile("" : "+v"(dC), "+v"(dN), "+v"(dS), "+v"(dE), "+v"(dW), "+v"(kk));
+                    asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
+                    val = dC;
+                }
+                const double2 pd = way ? e1 : e0;
+                if (!RF_EXP(2)) {
+                    if (!(m_lv & ~(m_ew & m_ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
+                        const double u = refine_update3m(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv, wsok);
+                        val = rf_sel(m_lv) ? u : dC;
+                    } else if (rf_sel(m_lv)) {
+                        const int mode = (int)rf_sel(m_ew) + (int)rf_sel(m_ns) * 2; // .cpp:620
+                        if (mode != 0) val = refine_update(mode, dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
+                    }
+                }
+                if (t == T && rf_sel(m_lv & m_own)) { // sweep T's computable rows are the owned rows (xc == x there)
+                    unsigned xo = xcu0;
+                    asm volatile("" : "+v"(xo)); // no hoisted (and then spilled) 64-bit lane address
+                    (out + (size_t)r * W)[xo] = val;
+                }
+            }
+            if (!(V & 2) && r >= cy_lo && r <= cy_hi) { // round 3's form of the same
                 const bool lv = colok && dC != (double)NOMATCH; // .cpp:613
                 const bool ew = dE != (double)NOMATCH && dW != (double)NOMATCH, ns = dS != (double)NOMATCH && dN != (double)NOMATCH;
                 const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
@@ -964,13 +1082,17 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             if (t < T) s_d[t][r & 3][lane + 1] = val;
         }
         RF_TICK(2) // update math + result write
-        if (wid == ((s + 1) & 1) && s + 1 <= y1) {
+        if (spar == ((s + 1) & 1) && s + 1 <= y1) {
             const int es = (s + 1 - y0) % NE;
-            s_d[0][(s + 1) & 3][lane + 1] = nd;
-            s_key[es][lane] = nk0 | (nk1 << 16);
-            s_emit[es][lane] = 0;
-            s_ent[es][0][lane] = make_double2(np0, nq0);
-            s_ent[es][1][lane] = make_double2(np1, nq1);
+            if (st_lo) {
+                s_d[0][(s + 1) & 3][lane + 1] = nd;
+                s_key[es][lane] = nk0 | (nk1 << 16);
+                s_emit[es][lane] = 0;
+            }
+            if (st_hi) {
+                s_ent[es][0][lane] = make_double2(np0, nq0);
+                s_ent[es][1][lane] = make_double2(np1, nq1);
+            }
         }
         r++;
         e = (e + 1 == NE) ? 0 : e + 1;
@@ -997,16 +1119,22 @@ void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev
     const int uw = 64 - 2 * T;
     const dim3 grid((cols + uw - 1) / uw, (rows + a.skew_rows - 1) / a.skew_rows, a.ndir);
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (T == 2) {
-        if (a.flag) hipLaunchKernelGGL((k_refine_skew<2, 1>), grid, dim3(128), 0, st, a);
-        else hipLaunchKernelGGL((k_refine_skew<2, 0>), grid, dim3(128), 0, st, a);
-    } else if (T == 3) {
-        if (a.flag) hipLaunchKernelGGL((k_refine_skew<3, 1>), grid, dim3(192), 0, st, a);
-        else hipLaunchKernelGGL((k_refine_skew<3, 0>), grid, dim3(192), 0, st, a);
-    } else {
-        if (a.flag) hipLaunchKernelGGL((k_refine_skew<4, 1>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_refine_skew<4, 0>), grid, dim3(256), 0, st, a);
-    }
+#define RF_LAUNCH_V(TT, VV)                                                                                   \
+    do {                                                                                                      \
+        if (a.flag) hipLaunchKernelGGL((k_refine_skew<TT, 1, VV>), grid, dim3(64 * TT), 0, st, a);          \
+        else hipLaunchKernelGGL((k_refine_skew<TT, 0, VV>), grid, dim3(64 * TT), 0, st, a);                 \
+    } while (0)
+    if (T == 2) RF_LAUNCH_V(2, 0);
+    else if (T == 3) RF_LAUNCH_V(3, 0);
+    else // the measured variants exist for T = 4 only (option refine_skew_variant; 0 = the shipped kernel)
+        switch (a.skew_variant & 3) {
+        case 1: RF_LAUNCH_V(4, 1); break;
+        case 2: RF_LAUNCH_V(4, 2); break;
+        case 3: RF_LAUNCH_V(4, 3); break;
+        default: RF_LAUNCH_V(4, 0); break;
+        }
+#undef RF_LAUNCH_V
+#undef RF_LAUNCH
     if (ev1) (void)hipEventRecord(ev1, st);
     hipLaunchKernelGGL(k_refine_apply, dim3(8, RF_UPD_SHARDS), dim3(256), 0, st, a);
 }

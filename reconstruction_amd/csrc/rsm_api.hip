@@ -96,6 +96,8 @@ struct rsm_ctx {
     int *d_cj1 = nullptr, *d_cj2 = nullptr; // ... and DisparityToCloud's (uploaded with the pair)
     uint8_t *blk = nullptr;                 // coarse bad-block map of the top-level mask (cloud erosion)
     hipEvent_t ev_cloudprep = nullptr;
+    int ordinal = 0;               // n-th context created on its device
+    int opt_cu_share = 0;          // > 1: the context's streams are confined to one of that many equal shares of the compute units
     hipEvent_t ev_heavy = nullptr; // end of this context's last bandwidth-bound section (heavy_begin / heavy_end)
     hipEvent_t ev_heavy2 = nullptr; // ... of its last issue-bound (time-skewed) section: lane 1
     int32_t *row_count = nullptr;
@@ -135,6 +137,7 @@ struct rsm_ctx {
     int opt_refine_skew_min_px = 1000000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
     int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
+    int opt_refine_skew_variant = 0;     // T = 4: measured restatements of the time-skewed kernel (bit 0: staging shared by two waves, bit 1: lane-mask predicates + unscaled divisions); 0 = shipped
 
     // profiling
     bool profile = false;
@@ -245,6 +248,10 @@ extern "C" int rsm_create(rsm_ctx **out, int hip_device) {
     if (hip_device < 0 || hip_device >= ndev) return RSM_E_INVALID;
     rsm_ctx *c = new rsm_ctx();
     c->device = hip_device;
+    {
+        static std::atomic<int> g_ordinal[RSM_MAX_DEVICES];
+        c->ordinal = hip_device < RSM_MAX_DEVICES ? g_ordinal[hip_device].fetch_add(1) : 0; // which share of the CUs option cu_share gives it
+    }
     // (stream priorities were measured and dropped: a high-priority main stream next to low-priority sweep streams ran
     //  two pairs in flight at 164 Mdisp/s instead of 210)
     if (hipSetDevice(hip_device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -485,8 +492,41 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
+    else if (!strcmp(name, "refine_skew_variant")) c->opt_refine_skew_variant = (int)std::max(0LL, std::min(value, 3LL));
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
-    else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
+    else if (!strcmp(name, "cu_share")) {
+        // Contexts that share a GPU each on their own share of the compute units (the `ordinal % n`-th of n equal ranges of the
+        // CU mask, hipExtStreamCreateWithCUMask) instead of all of them on the whole chip; 0 / 1 = the whole chip.
+        const int n = (int)std::max(0LL, std::min(value, 64LL));
+        if (hipSetDevice(c->device) != hipSuccess) return set_err(c, RSM_E_HIP, "hipSetDevice");
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return set_err(c, RSM_E_HIP, "hipGetDeviceProperties");
+        const int ncu = prop.multiProcessorCount;
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->stream2);
+        hipStream_t s1 = nullptr, s2 = nullptr;
+        hipError_t e1, e2;
+        if (n > 1) {
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            const int idx = c->ordinal % n, lo = (int)((long long)idx * ncu / n), hi = (int)((long long)(idx + 1) * ncu / n);
+            for (int i = lo; i < hi; i++) mask[(size_t)i / 32] |= 1u << (i & 31);
+            e1 = hipExtStreamCreateWithCUMask(&s1, (uint32_t)mask.size(), mask.data());
+            e2 = hipExtStreamCreateWithCUMask(&s2, (uint32_t)mask.size(), mask.data());
+        } else {
+            e1 = hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+            e2 = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        }
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            if (s1) (void)hipStreamDestroy(s1);
+            if (s2) (void)hipStreamDestroy(s2);
+            return set_err(c, RSM_E_HIP, "cu_share: stream creation failed");
+        }
+        (void)hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->stream2);
+        c->stream = s1;
+        c->stream2 = s2;
+        c->opt_cu_share = n;
+    } else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
     else if (!strcmp(name, "refine_band_rows")) c->opt_refine_band_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
     return RSM_OK;
@@ -669,6 +709,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
                 strips += (std::max(1, a.d[v].own.XR - a.d[v].own.XL - 1) + (64 - 2 * skewT) - 1) / (64 - 2 * skewT);
             }
             const int chunks = std::max(1, c->opt_refine_skew_waves / std::max(1, strips));
+            a.skew_variant = c->opt_refine_skew_variant;
             a.skew_rows = c->opt_refine_skew_rows > 0 ? c->opt_refine_skew_rows : std::max(4 * skewT, (rows + chunks - 1) / chunks);
         }
         int nskew = 0;
@@ -1428,6 +1469,21 @@ extern "C" int rsm_stage_exp_neg(rsm_ctx *c, const double *t_in, int64_t n, doub
     if (!t.ok) return finish(c, t);
     launch_exp_neg(dt, dout, (long long)n, c->stream);
     t.down(out, dout, (size_t)n);
+    return finish(c, t);
+}
+
+// k_refine_skew's unscaled division beside the compiler's (k_refine.hip: div_unscaled) on arrays of operands
+extern "C" int rsm_stage_div_unscaled(rsm_ctx *c, const double *a_in, const double *b_in, int64_t n, double *q_fast, double *q_ieee) {
+    if (!c || !a_in || !b_in || !q_fast || !q_ieee || n < 0) return RSM_E_INVALID;
+    if (n == 0) return RSM_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return set_err(c, RSM_E_HIP, "hipSetDevice");
+    Tmp t(c);
+    const double *da = t.up(a_in, (size_t)n), *db = t.up(b_in, (size_t)n);
+    double *df = t.alloc<double>((size_t)n), *di = t.alloc<double>((size_t)n);
+    if (!t.ok) return finish(c, t);
+    launch_div_unscaled(da, db, df, di, (long long)n, c->stream);
+    t.down(q_fast, df, (size_t)n);
+    t.down(q_ieee, di, (size_t)n);
     return finish(c, t);
 }
 

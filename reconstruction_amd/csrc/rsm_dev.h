@@ -78,6 +78,7 @@ struct StageArgs {
     RfMiss *miss_list; // RF_UPD_SHARDS regions of miss_cap records (counters: upd_cnt); nullptr = never defer
     int miss_cap;      // >= 1024 x the workgroups a shard can receive: a deferring sweep never overflows
     int skew_rows;     // refine (k_refine_skew): rows per chunk
+    int skew_variant;  // refine (k_refine_skew, T = 4): 0 = the shipped kernel, bits 0 / 1 = the measured restatements (k_refine.hip)
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int opt_no_exact;               // skip k_ncc_exact (timing A/B only: ties then follow the integer form)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
@@ -118,6 +119,8 @@ void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, h
 void launch_set_boundary(const StageArgs &a, hipStream_t st, bool emit_list = false);
 void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out (pre-filled NOMATCH)
 void launch_exp_neg(const double *t, double *out, long long n, hipStream_t st); // the specified exp(-t) (tests)
+// k_refine_skew's division without operand scaling beside the compiler's a / b (tests)
+void launch_div_unscaled(const double *a, const double *b, double *q_fast, double *q_ieee, long long n, hipStream_t st);
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);

@@ -94,3 +94,39 @@ def test_hip_specified_exp_equals_the_oracle_bit_for_bit(ctx):
     g, w = ctx.exp_neg(t), orc.exp_neg_array(t)
     bad = g.view(np.int64) != w.view(np.int64)
     assert not bad.any(), (int(bad.sum()), t[bad][:5], g[bad][:5], w[bad][:5])
+
+
+def test_hip_unscaled_division_is_the_ieee_division_inside_its_guard(ctx):
+    """k_refine_skew's common path divides WITHOUT the hardware sequence's operand scaling and fix-up steps (v_div_scale,
+    v_div_fixup), under a guard: 2^-300 < |a| (numerators), denominators in [2^-300, 2^300].  Inside that range the two
+    must be the same bits -- held against the device's own a / b AND against numpy's (IEEE round-to-nearest) division on
+    4 M operand pairs: random mantissas over the admitted exponent range, the operand shapes of .cpp:669,671 (weights in
+    (e^-200, 1], disparities, ws), exact quotients, and ratios one ulp either side of a rounding boundary."""
+    rng = np.random.default_rng(20240917)
+    n = 1 << 20
+
+    def rnd(lo_exp, hi_exp, size, signed=True):
+        m = rng.random(size) + 1.0
+        e = rng.integers(lo_exp, hi_exp + 1, size)
+        v = np.ldexp(m, e)
+        return v * rng.choice([-1.0, 1.0], size) if signed else v
+
+    cases = []
+    cases.append((rnd(-299, 299, n), rnd(-299, 299, n, signed=False)))          # the whole admitted range
+    wx, wy = np.exp(-rng.random(n) * 200.0), np.exp(-rng.random(n) * 200.0)     # .cpp:669: ds
+    dsum1, dsum2 = rng.normal(0, 300, n), rng.normal(0, 300, n)
+    cases.append((wx * dsum1 + wy * dsum2, 2 * (wx + wy)))
+    pwp, ws = rng.random(n), np.ldexp(1.0, rng.integers(-20, 4, n))              # .cpp:671
+    cases.append((rng.normal(0, 200, n) * pwp + ws * rng.normal(0, 200, n), pwp + ws))
+    q = rnd(-40, 40, n)                                                          # exact and nearly exact quotients
+    b = rnd(-100, 100, n, signed=False)
+    a = q * b
+    cases.append((np.nextafter(a, rng.choice([-np.inf, np.inf], n)), b))
+    for a, b in cases:
+        ok = (np.abs(a) > 2.0 ** -300) & (np.abs(a) < 2.0 ** 300) & (b > 2.0 ** -300) & (b < 2.0 ** 300)
+        a, b = a[ok], b[ok]
+        qf, qi = ctx.div_unscaled(a, b)
+        want = a / b
+        assert np.array_equal(qi.view(np.int64), want.view(np.int64))            # the device's a / b is IEEE
+        bad = qf.view(np.int64) != want.view(np.int64)
+        assert not bad.any(), (int(bad.sum()), a[bad][:4], b[bad][:4], qf[bad][:4], want[bad][:4])

@@ -440,13 +440,16 @@ def test_refine_two_sweeps_per_launch_is_bit_identical(ctx, first):
         ctx.set_option("refine_multi_min_px", 400000)
 
 
-@pytest.mark.parametrize("T,first,rows", [(2, 1, 0), (3, 1, 7), (4, 1, 16), (3, 5, 0), (4, 9, 33), (2, 30, 12), (3, 2, 1000)])
-def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows):
+@pytest.mark.parametrize("T,first,rows,variant", [(2, 1, 0, 0), (3, 1, 7, 0), (4, 1, 16, 0), (3, 5, 0, 0), (4, 9, 33, 0), (2, 30, 12, 0), (3, 2, 1000, 0),
+                                                 (4, 1, 16, 1), (4, 9, 33, 2), (4, 1, 0, 3), (4, 22, 0, 2)])
+def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows, variant):
     """k_refine_skew (T Jacobi sweeps per launch: a wave streams down a 64-column strip with sweep t on row y - t, the
     state rings and both cache ways in its LDS slice, cache updates deferred to the update list) from sweep `first` on
     -- from the first cached sweep, where nearly every pixel misses, to the settled regime -- gives the single-sweep
     result, i.e. the oracle's, bit for bit; chunk heights from 4T rows to the whole level, sweep counts that leave 0..T-1
-    single sweeps at the end."""
+    single sweeps at the end.  variant != 0: round 4's restatements of the T = 4 kernel (a row's staging shared by two waves;
+    lane-mask predicates and divisions without the hardware sequence's scaling steps) -- the same bits."""
+    ctx.set_option("refine_skew_variant", variant)
     ctx.set_option("refine_skew_from", first)
     ctx.set_option("refine_skew_T", T)
     ctx.set_option("refine_skew_min_px", 0)
@@ -466,7 +469,8 @@ def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows):
             for v in range(2):
                 assert np.array_equal(res.disparity[v], fin["disparity"][v])
     finally:
-        ctx.set_option("refine_skew_from", 22)  # the defaults
+        ctx.set_option("refine_skew_variant", 0)  # the defaults
+        ctx.set_option("refine_skew_from", 22)
         ctx.set_option("refine_skew_T", 4)
         ctx.set_option("refine_skew_min_px", 1000000)
         ctx.set_option("refine_skew_rows", 0)
