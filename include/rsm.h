@@ -218,8 +218,10 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          sweeps (k_refine_skew): T (2..4, default 4) sweeps per launch from that sweep of a level on (default
  *                          22; 0 = never) at levels with at least min_px margin pixels per direction (default 1 M: the two
  *                          largest levels of a 12 MP pair), aiming at `waves` workgroups (default 1280) or `rows` rows per chunk
- *   "refine_skew_variant"  0 (default) the shipped time-skewed kernel; bit 0 / bit 1 = two bit-identical restatements measured
- *                          slower (a row's staging shared by two waves / lane-mask predicates + unscaled divisions), kept for A/B
+ *   "refine_skew_variant"  the T = 4 time-skewed kernel: 4 (default) rows of a strip without a live pixel (outside an elliptic
+ *                          mask, a hole) skip the update math (0: they do not; C3 +5 %, C2 unchanged); bit 0 / bit 1 = two
+ *                          bit-identical restatements measured slower (a row's staging shared by two waves / lane-mask
+ *                          predicates + unscaled divisions), kept for A/B
  *   "refine_prefill"       1 (default): the first sweep of a level also fills the second cache way (0: A/B)
  *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)
  *   "refine_defer_from" / "refine_defer_to" / "refine_defer_min_px"   sweeps whose data-term cache misses are listed and served

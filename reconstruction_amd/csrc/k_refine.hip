@@ -888,9 +888,11 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
 // scatters afterwards (another strip may be staging the same pixel's entries at that moment: an in-place write could
 // be read torn).  At most one record per (pixel, way) and launch, so k_refine_apply never sees two writers of a slot.
 // Values are those of T single sweeps, bit for bit (tests/test_gpu_parity.py).
-// V (option refine_skew_variant, T = 4; 0 = the shipped kernel) holds two round-4 restatements that compute the same bits with
-// less work per wave and are SLOWER, kept as measured evidence of what bounds this kernel (not VALU issue slots,
-// not the staging wave's extra work -- the waves' own dependent chains and the launch's tail):
+// V (option refine_skew_variant, T = 4).  V & 4 (the default, 4): a row without a live pixel in the strip copies through without
+// the update math (C3's elliptic masks leave 27 % of the margin's box empty: 272 -> 286 Mdisp/s; C2 unchanged).  The other two
+// bits hold round-4 restatements that compute the same bits with less work per wave and are SLOWER, kept as measured evidence
+// of what bounds this kernel (not VALU issue slots, not the staging wave's extra work -- the waves' own dependent
+// chains and the launch's tail):
 //   V & 1: the staging of a row shared by two waves (below);
 //   V & 2: the row's predicates as lane masks and the mode-3 update with unscaled divisions (refine_update3m): 8 % fewer
 //          vector instructions per launch (95.8 M against 104.1 M), 12 % more scalar ones, 0.328 ms per launch against 0.310.
@@ -1041,7 +1043,9 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     (out + (size_t)r * W)[xo] = val;
                 }
             }
-            if (!(V & 2) && r >= cy_lo && r <= cy_hi) { // round 3's form of the same
+            // V & 4: a row without a live pixel in this strip (outside an elliptic mask, a hole) copies through without the update
+            // math -- one more compare per row, chosen by the launcher where the masked pixels leave much of the margin's box empty
+            if (!(V & 2) && r >= cy_lo && r <= cy_hi && (!(V & 4) || (m_col & RF_FNE(dC, (double)NOMATCH)))) { // round 3's form of the same
                 const bool lv = colok && dC != (double)NOMATCH; // .cpp:613
                 const bool ew = dE != (double)NOMATCH && dW != (double)NOMATCH, ns = dS != (double)NOMATCH && dN != (double)NOMATCH;
                 const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
@@ -1126,11 +1130,12 @@ void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev
     } while (0)
     if (T == 2) RF_LAUNCH_V(2, 0);
     else if (T == 3) RF_LAUNCH_V(3, 0);
-    else // the measured variants exist for T = 4 only (option refine_skew_variant; 0 = the shipped kernel)
-        switch (a.skew_variant & 3) {
+    else // the variants exist for T = 4 only (option refine_skew_variant; 4 = the shipped kernel)
+        switch (a.skew_variant & 7) {
         case 1: RF_LAUNCH_V(4, 1); break;
         case 2: RF_LAUNCH_V(4, 2); break;
         case 3: RF_LAUNCH_V(4, 3); break;
+        case 4: RF_LAUNCH_V(4, 4); break;
         default: RF_LAUNCH_V(4, 0); break;
         }
 #undef RF_LAUNCH_V

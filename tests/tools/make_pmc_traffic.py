@@ -13,7 +13,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03b
 rows = list(csv.DictReader(open(src)))
 
 
-def get(c, k="void k_refine_skew<4, 1>"):
+def get(c, k="void k_refine_skew<4, 1"):  # (prefix: the third template argument is the variant)
     r = [r for r in rows if r["kernel"].startswith(k) and r["counter"] == c][0]
     return float(r["mean"]), int(r["dispatches"])
 
