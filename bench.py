@@ -370,9 +370,14 @@ def main():
         if valu and valu.get("active_frac") is not None and traffic and valu.get("launch_ms_in_this_pass"):
             hbm_util = traffic / (valu["launch_ms_in_this_pass"] * 1e-3) / 1e9 / 6300.0
             out["roofline"]["bound"] = "hbm" if hbm_util >= valu["active_frac"] else "valu"
-            out["roofline"]["bound_note"] = ("VALU busy %.0f %% of the launch (fp64 issue), measured HBM traffic at %.0f %% of the achievable 6.3 TB/s: "
-                                             "the kernel is bound by %s" % (100 * valu["active_frac"], 100 * hbm_util,
-                                                                           "fp64 VALU issue, not by the memory system" if hbm_util < valu["active_frac"] else "the memory system"))
+            parked = (valu.get("wave_cycles_split") or {}).get("parked_waitcnt_or_barrier")
+            out["roofline"]["bound_note"] = ("VALU busy %.0f %% of the launch (fp64), measured HBM traffic at %.0f %% of the achievable 6.3 TB/s, a wave parked "
+                                             "(s_waitcnt / barrier) %s of its cycles: %s" % (
+                                                 100 * valu["active_frac"], 100 * hbm_util, ("%.0f %%" % (100 * parked)) if parked is not None else "?",
+                                                 "the fp64 VALU is the busiest unit and neither it nor the memory system is saturated -- the waves' dependent fp64 chains "
+                                                 "(5 waves per SIMD) and the launch's low-occupancy tail bound the kernel: a bit-identical restatement with 8 % fewer vector "
+                                                 "instructions ran 5 % slower (option refine_skew_variant = 2, DESIGN.md 4)"
+                                                 if hbm_util < valu["active_frac"] else "the memory system is the busiest unit"))
         if rig:
             # BASELINE configs[3]: the SAME ten pairs at every N (strong scaling): pair p on rank p % N; a step
             # = all ten pairs matched once + (N > 1) the RCCL fan-in of the ten clouds to rank 0; 10 pairs on 8 GPUs cap at 5x

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/pmc_traffic.json from the PMC summary of tests/tools/gpu_profile_r03b.sh (run on the GPU box), keyed by the hash
+"""profiles/pmc_traffic.json from the PMC summary of tests/tools/gpu_profile_r04.sh (run on the GPU box), keyed by the hash
 of the dominant kernel's source so that bench.py stops quoting it once the kernel changes.  Only a fallback: bench.py
 measures FETCH_SIZE / WRITE_SIZE of the dominant kernel itself (roofline.traffic_source = "measured")."""
 import csv
@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03b_pmc_main_kernels.csv")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04b_pmc_main_kernels.csv")
 rows = list(csv.DictReader(open(src)))
 
 
@@ -24,9 +24,9 @@ hit, miss = get("TCC_HIT_sum")[0], get("TCC_MISS_sum")[0]
 h = hashlib.sha256()
 for fn in ("k_refine.hip", "rsm_dev.h"):
     h.update(open(os.path.join(ROOT, "reconstruction_amd", "csrc", fn), "rb").read())
-out = {"kernel": "k_refine_skew<4,1>", "workload": "C2_4096x3072_r5_d128", "kernel_src_sha256": h.hexdigest(),
+out = {"kernel": "k_refine_skew<4,1,", "workload": "C2_4096x3072_r5_d128", "kernel_src_sha256": h.hexdigest(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python bench.py "
-                 "--no-cpu-baseline --measure-traffic 0 --steps 1 --warmup 0 --inflight 1; tests/tools/gpu_profile_r03b.sh, "
+                 "--no-cpu-baseline --measure-traffic 0 --steps 1 --warmup 0 --inflight 1; tests/tools/gpu_profile_r04.sh, "
                  "summarised by tests/tools/rocpd_pmc.py -> " + os.path.relpath(src, ROOT) + ".  Only the fallback: bench.py "
                  "measures the same two counters itself (roofline.traffic_source = measured)",
        "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "dispatches": nd,
