@@ -465,6 +465,7 @@ def pmc_pass(counters, kernel, args):
                "--pmc-child", "--inflight", "1", "--config", args.config, "--no-cpu-baseline"]
         for o in args.opt:
             cmd += ["--opt", o]
+        cmd += ["--opt", "refine_split=0"]  # the profiled launches are the timed region's: both directions in one launch
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
             env.pop(k, None)

@@ -223,6 +223,10 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          bit-identical restatements measured slower (a row's staging shared by two waves / lane-mask
  *                          predicates + unscaled divisions), kept for A/B
  *   "refine_prefill"       1 (default): the first sweep of a level also fills the second cache way (0: A/B)
+ *   "refine_split"         1 (default): a pair that has the GPU to itself (no other context of the device inside rsm_run_pair,
+ *                          no per-launch timing) runs the two directions of its time-skewed sections as separate launch chains
+ *                          on its two streams (one's low-occupancy tail beside the other's head: one C2 pair 24.1 -> 23.0 ms);
+ *                          never used with pairs in flight (measured slower there)
  *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)
  *   "refine_defer_from" / "refine_defer_to" / "refine_defer_min_px"   sweeps whose data-term cache misses are listed and served
  *                          by a second kernel, a lane per miss, instead of inside the sweep (to = 0 = never, default)

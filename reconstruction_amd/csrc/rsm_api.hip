@@ -100,6 +100,10 @@ struct rsm_ctx {
     int opt_cu_share = 0;          // > 1: the context's streams are confined to one of that many equal shares of the compute units
     hipEvent_t ev_heavy = nullptr; // end of this context's last bandwidth-bound section (heavy_begin / heavy_end)
     hipEvent_t ev_heavy2 = nullptr; // ... of its last issue-bound (time-skewed) section: lane 1
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr; // the two directions of a time-skewed section on two streams (refine_sweeps)
+    RfUpd *upd_list2 = nullptr;     // the second direction's update list / counters while the two run as separate launch chains
+    int32_t *upd_cnt2 = nullptr;
+    int opt_refine_split = 1;       // a pair that has the GPU to itself runs the two directions of its time-skewed sections on two streams
     int32_t *row_count = nullptr;
     int64_t *row_offset = nullptr;
     int64_t *d_npoints = nullptr;
@@ -162,6 +166,16 @@ struct rsm_ctx {
 // the other pair's second-largest level and full-size non-refine stages then run beside the top-level sweeps and fill
 // their launch tails, at the price of 158 us per top-level launch.
 #define RSM_MAX_DEVICES 64
+static std::atomic<int> g_running[RSM_MAX_DEVICES]; // contexts inside rsm_run_pair, per device
+struct RunningGuard {
+    int dev;
+    explicit RunningGuard(int d) : dev(d) {
+        if (dev < RSM_MAX_DEVICES) g_running[dev].fetch_add(1);
+    }
+    ~RunningGuard() {
+        if (dev < RSM_MAX_DEVICES) g_running[dev].fetch_sub(1);
+    }
+};
 static std::mutex g_heavy_mu[RSM_MAX_DEVICES][2];
 static hipEvent_t g_heavy_last[RSM_MAX_DEVICES][2];
 static rsm_ctx *g_heavy_owner[RSM_MAX_DEVICES][2];
@@ -259,7 +273,9 @@ extern "C" int rsm_create(rsm_ctx **out, int hip_device) {
         hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_cloudprep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_heavy2, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_heavy2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return RSM_E_HIP;
     }
@@ -295,6 +311,8 @@ extern "C" void rsm_destroy(rsm_ctx *c) {
     heavy_forget(c);
     (void)hipEventDestroy(c->ev_heavy);
     (void)hipEventDestroy(c->ev_heavy2);
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
     for (int k = 0; k < RSM_MAX_LEVELS; k++) (void)hipEventDestroy(c->ev_prep[k]);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
@@ -374,6 +392,8 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->wrow, NCC_WROW_INTS((size_t)in->height)); // per (direction, row) counters and the row kernels' row lists (rsm_dev.h)
     c->upd_cap = (int)std::min<size_t>(65536, std::max<size_t>(1024, px / 8));
     DALLOC(c, c->upd_list, (size_t)RF_UPD_SHARDS * c->upd_cap);
+    DALLOC(c, c->upd_list2, (size_t)RF_UPD_SHARDS * c->upd_cap);
+    DALLOC(c, c->upd_cnt2, 2 * RF_UPD_SHARDS);
     DALLOC(c, c->upd_cnt, 2 * RF_UPD_SHARDS);
     // every pixel of the sweep workgroups (256 x RF_PPT pixels each, both directions) that can hash to one shard
     c->miss_cap = (int)((((size_t)(in->width / 256 + 2) * (size_t)(in->height / RF_PPT + 2) * 2) / RF_UPD_SHARDS + 2) * 256 * RF_PPT);
@@ -489,6 +509,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_multi_min_px")) c->opt_refine_multi_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_from")) c->opt_refine_skew_from = (int)std::max(0LL, std::min(value, 100000LL));
     else if (!strcmp(name, "refine_prefill")) c->opt_refine_prefill = value != 0;
+    else if (!strcmp(name, "refine_split")) c->opt_refine_split = value != 0;
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
@@ -649,6 +670,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         return bytes;
     };
     int nlaunch = 0;
+    bool split_now = false; // inside a time-skewed section whose two directions run on two streams (below)
     auto launch = [&](int t, int lo, int hi, int multi) { // sweeps t .. t + (multi ? multi : 1) - 1 over the rows [lo, hi); multi = 2: k_refine_multi, < 0: k_refine_skew with T = -multi
         const int skewT = multi < 0 ? -multi : 0;
         if (skewT) multi = skewT;
@@ -665,7 +687,15 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
             c->prof_launches[stg] += 1;
             c->prof_bytes[stg] += (multi ? (double)multi : 1.0) * window_bytes(lo, hi);
         }
-        if (skewT) launch_refine_skew(a, skewT, st, e0, e1);
+        if (skewT && split_now) { // the two directions as two launch chains: one's tail runs beside the other's head
+            StageArgs a0 = a, a1 = a;
+            a0.ndir = a1.ndir = 1;
+            a1.d[0] = a.d[1];
+            a1.upd_list = c->upd_list2;
+            a1.upd_cnt = c->upd_cnt2;
+            launch_refine_skew(a0, skewT, st, nullptr, nullptr);
+            launch_refine_skew(a1, skewT, c->stream2, nullptr, nullptr);
+        } else if (skewT) launch_refine_skew(a, skewT, st, e0, e1);
         else if (multi) launch_refine_multi(a, st, e0, e1);
         else launch_refine_sweep(a, st, e0, e1);
         launches += multi ? multi : 1;
@@ -721,8 +751,26 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         bool held = false;
         int lane = 0;
         const int turn_from = (c && heavy_px > 0.0) ? std::min(std::max(c->opt_heavy_from_sweep, 1), iters) : iters + 1;
+        // A pair that has the GPU to itself (no other context inside rsm_run_pair on this device, no per-launch timing) runs the
+        // two directions of a time-skewed section as separate launch chains on its two streams: every skewed launch ends in a
+        // tail of one or two waves per SIMD, and the other direction's launch fills it.  With pairs in flight the
+        // other pairs' kernels do that already, and the split costs throughput (measured): not used there.
+        const bool may_split = skew && a.ndir == 2 && c->opt_refine_split && !c->profile && c->stream2 != st && c->upd_list2 &&
+                               c->device < RSM_MAX_DEVICES && g_running[c->device].load() == 1;
+        auto join = [&]() {
+            if (!split_now) return;
+            (void)hipEventRecord(c->ev_join, c->stream2);
+            (void)hipStreamWaitEvent(st, c->ev_join, 0);
+            split_now = false;
+        };
         for (int t = 1; t < iters;) {
             const bool skew_now = skew && t >= c->opt_refine_skew_from && t + skewT <= iters;
+            if (skew_now && may_split && !split_now) { // fork: the second stream continues from here
+                (void)hipMemsetAsync(c->upd_cnt2, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
+                (void)hipEventRecord(c->ev_fork, st);
+                (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+                split_now = true;
+            } else if (!skew_now) join();
             if (c && c->opt_heavy_lanes == 2 && (int)skew_now != lane && t >= turn_from) { // the section changes kind: hand its lane on
                 heavy_end(c, held, lane);
                 held = false;
@@ -750,6 +798,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
                 t += 1;
             }
         }
+        join();
         heavy_end(c, held, lane);
     } else { // time-skewed bands: sweep u + 1 of band j reads what sweep u wrote, buffers alternate with u
         for (int j = 0; Y0 + j * B - (nsw - 1) < Y1; j++)
@@ -771,6 +820,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     if (!c) return RSM_E_INVALID;
     if (!c->have_pair) return set_err(c, RSM_E_STATE, "rsm_run_pair before rsm_upload_pair");
     HIPCHK(c, hipSetDevice(c->device));
+    RunningGuard running(c->device);
     hipStream_t st = c->stream;
     const int N = c->N, r = c->in.radius;
     c->have_result = false;
