@@ -391,6 +391,77 @@ __device__ __forceinline__ double refine_cost_one(const uint32_t *__restrict__ A
     return (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
 }
 
+// k_refine_first's form of the data term: every pixel of the level computes one, the kernel is bound by its vector
+// instructions (85 % VALU-busy), and it has 128 registers to spend -- so the 27 left-window differences (u - meanL) and the left
+// norm are computed ONCE and kept for the three shifts and for the extra matching cost of the second cache way, where the
+// 50-register routine of the sweep kernels' miss path recomputes them per shift.  Each value comes out of the same operation
+// sequence (same conversions, same two-accumulator sums in the same order) as in refine_data_term_packed / refine_cost_one.
+struct RfLeft {
+    double ul[27]; // byte - meanL in the reference's vector order (byte column outer, row inner)
+    double normL;
+};
+__device__ __forceinline__ void refine_left(const uint32_t *__restrict__ A, int W, int x, int y, RfLeft &L) {
+    uint32_t aP[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t *pa = A + (size_t)(y - 1 + j) * W + (x - 1);
+#pragma unroll
+        for (int p = 0; p < 3; p++) aP[j][p] = pa[p];
+    }
+    int SL = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) SL = sum4(aP[j][p], SL);
+    const double meanL = (double)SL / 27.0;
+    double n1 = 0.0, n2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        const double u = byte_f64(aP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanL;
+        L.ul[k] = u;
+        if (k & 1) n2 += u * u;
+        else n1 += u * u;
+    }
+    double normL = sqrt(n1 + n2);
+    if (normL == 0) normL = 1;
+    L.normL = normL;
+}
+// the matching cost xi = (1 - ncc) / 2 against the right window whose left edge is column `col` (.cpp:626-629)
+__device__ __forceinline__ double refine_cost_left(const RfLeft &L, const uint32_t *__restrict__ B, int W, int H, int y, int col) {
+    const long long npx = (long long)W * H;
+    uint32_t bP[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const long long fb = (long long)(y - 1 + j) * W + col;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const long long fi = fb + p;
+            bP[j][p] = (fi >= 0 && fi < npx) ? B[fi] : 0u;
+        }
+    }
+    int SR = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) SR = sum4(bP[j][p], SR);
+    const double meanR = (double)SR / 27.0;
+    double m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        const double ur = byte_f64(bP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanR;
+        if (k & 1) {
+            m2 += ur * ur;
+            d2 += L.ul[k] * ur;
+        } else {
+            m1 += ur * ur;
+            d1 += L.ul[k] * ur;
+        }
+    }
+    double normR = sqrt(m1 + m2);
+    if (normR == 0) normR = 1;
+    return (1 - (d1 + d2) / (L.normL * normR)) / 2; // .cpp:629
+}
+
 // One quad (4 adjacent lanes) computes refine_data_term_packed for one (x, y, key): every lane restates the left
 // window's mean and norm, lane q >= 1 the right window of shift c = q - 1 (lane 0 shadows c = 0), lane 0
 // combines.  Each value is produced by the same operation sequence as in refine_data_term_packed.
@@ -464,8 +535,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return;
     }
     const int key = (int)(dC - 1.5) + x;
-    double pwp, delta, xs[3];
-    refine_data_term_packed(d.img4_own, d.img4_oth, W, H, x, y, key, pwp, delta, xs);
+    double pwp, delta, xs[3] = {0.0, 0.0, 0.0};
+    RfLeft L;
+    refine_left(d.img4_own, W, x, y, L);
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) { // (rolled: one copy of the 27-element loop; the left differences stay in registers)
+        xs[0] = xs[1];
+        xs[1] = xs[2];
+        xs[2] = refine_cost_left(L, d.img4_oth, W, H, y, key + c);
+    }
+    refine_entry(xs[0], xs[1], xs[2], pwp, delta);
     const size_t cpix = pix + (size_t)((key - x) & 1) * a.rf_stride;
     d.rf_key[cpix] = (int16_t)(key - x);
     d.rf_pwp[cpix] = pwp;
@@ -482,7 +561,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int rel2 = rel1 != rel0 ? rel1 : (val > dC ? rel0 + 1 : (val < dC ? rel0 - 1 : rel0));
     if (rel2 == rel0 + 1 || rel2 == rel0 - 1) {
         const bool up = rel2 > rel0;
-        const double xe = refine_cost_one(d.img4_own, d.img4_oth, W, H, x, y, up ? key + 3 : key - 1);
+        const double xe = refine_cost_left(L, d.img4_oth, W, H, y, up ? key + 3 : key - 1);
         double p2, q2;
         refine_entry(up ? xs[1] : xe, up ? xs[2] : xs[0], up ? xe : xs[1], p2, q2);
         const size_t cpix2 = pix + (size_t)(rel2 & 1) * a.rf_stride;
