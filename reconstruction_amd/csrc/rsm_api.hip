@@ -509,7 +509,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_multi_min_px")) c->opt_refine_multi_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_from")) c->opt_refine_skew_from = (int)std::max(0LL, std::min(value, 100000LL));
     else if (!strcmp(name, "refine_prefill")) c->opt_refine_prefill = value != 0;
-    else if (!strcmp(name, "refine_split")) c->opt_refine_split = value != 0;
+    else if (!strcmp(name, "refine_split")) c->opt_refine_split = (int)std::max(0LL, std::min(value, 2LL)); // 2: also with pairs in flight (A/B)
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
@@ -693,7 +693,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
             a1.d[0] = a.d[1];
             a1.upd_list = c->upd_list2;
             a1.upd_cnt = c->upd_cnt2;
-            launch_refine_skew(a0, skewT, st, nullptr, nullptr);
+            launch_refine_skew(a0, skewT, st, e0, e1); // (e0 / e1: only under refine_split = 2, an A/B mode)
             launch_refine_skew(a1, skewT, c->stream2, nullptr, nullptr);
         } else if (skewT) launch_refine_skew(a, skewT, st, e0, e1);
         else if (multi) launch_refine_multi(a, st, e0, e1);
@@ -755,8 +755,8 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         // two directions of a time-skewed section as separate launch chains on its two streams: every skewed launch ends in a
         // tail of one or two waves per SIMD, and the other direction's launch fills it.  With pairs in flight the
         // other pairs' kernels do that already, and the split costs throughput (measured): not used there.
-        const bool may_split = skew && a.ndir == 2 && c->opt_refine_split && !c->profile && c->stream2 != st && c->upd_list2 &&
-                               c->device < RSM_MAX_DEVICES && g_running[c->device].load() == 1;
+        const bool may_split = skew && a.ndir == 2 && c->opt_refine_split && (!c->profile || c->opt_refine_split == 2) && c->stream2 != st && c->upd_list2 &&
+                               c->device < RSM_MAX_DEVICES && (c->opt_refine_split == 2 || g_running[c->device].load() == 1);
         auto join = [&]() {
             if (!split_now) return;
             (void)hipEventRecord(c->ev_join, c->stream2);
