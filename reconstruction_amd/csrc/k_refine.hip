@@ -263,8 +263,7 @@ __device__ __forceinline__ void refine_entry(double x0, double x1, double x2, do
     }
 }
 
-// xs (optional): the three matching costs themselves -- the entry of an ADJACENT iMatch shares two of them
-// (k_refine_first: refine_cost_one supplies the third).
+// xs (optional): the three matching costs themselves.
 __device__ __forceinline__ void refine_data_term_packed(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
                                                         int W, int H, int x, int y, int key, double &pwp, double &delta,
                                                         double *xs = nullptr) {
@@ -344,58 +343,11 @@ __device__ __forceinline__ void refine_data_term_packed(const uint32_t *__restri
     }
 }
 
-// ONE matching cost xi = (1 - ncc) / 2 of pixel (x, y) against the right window whose left edge is column `col` (.cpp:626-629):
-// the same operation sequence per value as refine_data_term_packed (left mean / norm restated, one right window).
-__device__ __forceinline__ double refine_cost_one(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, int W, int H,
-                                                  int x, int y, int col) {
-    const long long npx = (long long)W * H;
-    uint32_t aP[3][3], bP[3][3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const uint32_t *pa = A + (size_t)(y - 1 + j) * W + (x - 1);
-        const long long fb = (long long)(y - 1 + j) * W + col;
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            aP[j][p] = pa[p];
-            const long long fi = fb + p;
-            bP[j][p] = (fi >= 0 && fi < npx) ? B[fi] : 0u;
-        }
-    }
-    int SL = 0, SR = 0;
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            SL = sum4(aP[j][p], SL);
-            SR = sum4(bP[j][p], SR);
-        }
-    const double meanL = (double)SL / 27.0, meanR = (double)SR / 27.0;
-    double n1 = 0.0, n2 = 0.0, m1 = 0.0, m2 = 0.0, d1 = 0.0, d2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 27; k++) {
-        const double ul = byte_f64(aP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanL;
-        const double ur = byte_f64(bP[k % 3][(k / 3) / 3], (k / 3) % 3) - meanR;
-        if (k & 1) {
-            n2 += ul * ul;
-            m2 += ur * ur;
-            d2 += ul * ur;
-        } else {
-            n1 += ul * ul;
-            m1 += ur * ur;
-            d1 += ul * ur;
-        }
-    }
-    double normL = sqrt(n1 + n2), normR = sqrt(m1 + m2);
-    if (normL == 0) normL = 1;
-    if (normR == 0) normR = 1;
-    return (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
-}
-
 // k_refine_first's form of the data term: every pixel of the level computes one, the kernel is bound by its vector
 // instructions (85 % VALU-busy), and it has 128 registers to spend -- so the 27 left-window differences (u - meanL) and the left
 // norm are computed ONCE and kept for the three shifts and for the extra matching cost of the second cache way, where the
 // 50-register routine of the sweep kernels' miss path recomputes them per shift.  Each value comes out of the same operation
-// sequence (same conversions, same two-accumulator sums in the same order) as in refine_data_term_packed / refine_cost_one.
+// sequence (same conversions, same two-accumulator sums in the same order) as in refine_data_term_packed.
 struct RfLeft {
     double ul[27]; // byte - meanL in the reference's vector order (byte column outer, row inner)
     double normL;
