@@ -192,6 +192,46 @@ def test_pairs_in_flight_equal_sequential_runs():
         for c in pool:
             c.close()
 
+def test_stream_and_partition_options_do_not_change_results():
+    """Round 4's scheduling options: the two directions of the time-skewed refine sections as separate launch chains on the
+    context's two streams -- a pair alone (the default), forced on with other pairs in flight (refine_split = 2), off -- and
+    contexts confined to disjoint shares of the compute units (cu_share): the same bits as one plain context."""
+    from reconstruction_amd import Context, run_pairs
+    cfgs = [synth.config_small(320, 192, 3, radius=2, pair=1, holes=True),
+            synth.config_small(256, 160, 3, radius=3, pair=5, occlude=True, mask_l0_width=48, border_l0=5)]
+    want = []
+    with Context(0) as one:
+        one.set_option("refine_split", 0)
+        one.set_option("refine_skew_min_px", 0)      # the time-skewed kernel on every level of these small pairs
+        one.set_option("refine_skew_from", 5)
+        want = [one.match_pair(c) for c in cfgs]
+        one.set_option("refine_split", 1)            # alone: split
+        for c, w in zip(cfgs, want):
+            a = one.match_pair(c)
+            for v in range(2):
+                assert np.array_equal(a.disparity[v], w.disparity[v])
+            assert np.array_equal(a.xyz, w.xyz, equal_nan=True)
+    for opts in ({"refine_split": 2}, {"cu_share": 2}, {"cu_share": 2, "refine_split": 2}):
+        pool = [Context(0), Context(0)]
+        try:
+            for c, cfg in zip(pool, cfgs):
+                c.set_option("refine_skew_min_px", 0)
+                c.set_option("refine_skew_from", 5)
+                for k, val in opts.items():
+                    c.set_option(k, val)
+                c.upload_pair(cfg)
+            for _ in range(2):
+                run_pairs(pool)
+            for c, w in zip(pool, want):
+                a = c.download_pair()
+                for v in range(2):
+                    assert np.array_equal(a.disparity[v], w.disparity[v]), opts
+                assert np.array_equal(a.xyz, w.xyz, equal_nan=True), opts
+        finally:
+            for c in pool:
+                c.close()
+
+
 _KEEP = []
 
 
