@@ -211,6 +211,28 @@ __device__ __forceinline__ double refine_update3m(double dC, double dE, double d
     return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
 }
 
+// refine_update3 with its one wave-uniform test taken from lane masks (no ballot of a combined bool) and nothing else changed:
+// the general divisions, the test early in the chain (k_refine_skew variant 8).
+__device__ __forceinline__ double refine_update3e(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws,
+                                                  unsigned long long m_lv) {
+    const double ex = fabs(dE - dC) - fabs(dW - dC);
+    const double ey = fabs(dS - dC) - fabs(dN - dC);
+    const double tx = ex * ex, ty = ey * ey;
+    if (!(m_lv & (RF_FGT(fmax(tx, ty), 700.0) | ~RF_FNE(pwp, 0.0)))) { // wave-uniform; the usual case
+        double wx, wy;
+        exp_neg2_small(tx, ty, wx, wy); // .cpp:665-666; both weights >= exp(-700) > 0
+        const double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));
+        return ((dC + delta) * pwp + ws * ds) / (pwp + ws); // .cpp:671
+    }
+    const double pdp = (pwp == 0) ? 0.0 : dC + delta;
+    double wx, wy;
+    exp_neg2(tx, ty, wx, wy); // .cpp:665-666
+    const double sw = wx + wy;
+    double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
+    ds = (sw == 0) ? (dE + dW + dS + dN) / 4 : ds; // .cpp:667-668
+    return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
+}
+
 // refine_update for mode 3 without a divergent branch (k_refine_skew's straight-line path, entered by all lanes): the same
 // operations on the same operands.  The three special cases of the general form -- a weight beyond exp's underflow threshold
 // (|ex| or |ey| > 27), both weights zero (.cpp:667-668), pwp == 0 (.cpp:642-643) -- are tested ONCE for the whole row (`lv`: the
@@ -919,11 +941,15 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
 // scatters afterwards (another strip may be staging the same pixel's entries at that moment: an in-place write could
 // be read torn).  At most one record per (pixel, way) and launch, so k_refine_apply never sees two writers of a slot.
 // Values are those of T single sweeps, bit for bit (tests/test_gpu_parity.py).
-// V (option refine_skew_variant, T = 4).  V & 4 (the default, 4): a row without a live pixel in the strip copies through without
-// the update math (C3's elliptic masks leave 27 % of the margin's box empty: 272 -> 286 Mdisp/s; C2 unchanged).  The other two
-// bits hold round-4 restatements that compute the same bits with less work per wave and are SLOWER, kept as measured evidence
-// of what bounds this kernel (not VALU issue slots, not the staging wave's extra work -- the waves' own dependent
-// chains and the launch's tail):
+// V (option refine_skew_variant, T = 4; the default is 12 = 4 + 8).
+//   V & 4: a row without a live pixel in the strip copies through without the update math (C3's elliptic masks leave 27 % of the
+//          margin's box empty: 272 -> 286 Mdisp/s; C2 unchanged).
+//   V & 8: the row's wave-level predicates (miss, "every live pixel has four neighbours", the update's rare cases) as lane masks
+//          straight from the compares -- a ballot of a COMBINED bool costs a v_cndmask + v_cmp pair, three times per row; all
+//          tests stay EARLY in the row's chain: 99.2 M vector wave-instructions per launch against 104.9 M, 0.313 ms against
+//          0.322, +2 % on C2 and C3.
+// The other two bits hold round-4 restatements that compute the same bits with less work per wave and are SLOWER, kept as
+// measured evidence of what bounds this kernel:
 //   V & 1: the staging of a row shared by two waves (below);
 //   V & 2: the row's predicates as lane masks and the mode-3 update with unscaled divisions (refine_update3m): 8 % fewer
 //          vector instructions per launch (95.8 M against 104.1 M), 12 % more scalar ones, 0.328 ms per launch against 0.310.
@@ -1036,9 +1062,11 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 kk = s_key[e][lane];
             };
             operands();
+            if (V & 4) // (one LDS round trip: none of the reads may sink below the live-row test, which needs dC only)
+                asm volatile("" : "+v"(dN), "+v"(dS), "+v"(dE), "+v"(dW), "+v"(kk), "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
             double val = dC;
             RF_TICK(1) // LDS operands arrived
-            if ((V & 2) && r >= cy_lo && r <= cy_hi) { // wave-uniform: rows sweep t can compute here; predicates as lane masks
+            if ((V & 10) && r >= cy_lo && r <= cy_hi && (!(V & 4) || (m_col & RF_FNE(dC, (double)NOMATCH)))) { // wave-uniform: rows sweep t can compute here; predicates as lane masks
                 const double NM = (double)NOMATCH;
                 const unsigned long long m_lv = m_col & RF_FNE(dC, NM); // .cpp:613
                 const unsigned long long m_ew = RF_FNE(dE, NM) & RF_FNE(dW, NM), m_ns = RF_FNE(dS, NM) & RF_FNE(dN, NM); // .cpp:620
@@ -1061,7 +1089,8 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 const double2 pd = way ? e1 : e0;
                 if (!RF_EXP(2)) {
                     if (!(m_lv & ~(m_ew & m_ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
-                        const double u = refine_update3m(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv, wsok);
+                        const double u = (V & 8) ? refine_update3e(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv)
+                                                 : refine_update3m(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv, wsok);
                         val = rf_sel(m_lv) ? u : dC;
                     } else if (rf_sel(m_lv)) {
                         const int mode = (int)rf_sel(m_ew) + (int)rf_sel(m_ns) * 2; // .cpp:620
@@ -1076,7 +1105,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             }
             // V & 4: a row without a live pixel in this strip (outside an elliptic mask, a hole) copies through without the update
             // math -- one more compare per row, chosen by the launcher where the masked pixels leave much of the margin's box empty
-            if (!(V & 2) && r >= cy_lo && r <= cy_hi && (!(V & 4) || (m_col & RF_FNE(dC, (double)NOMATCH)))) { // round 3's form of the same
+            if (!(V & 10) && r >= cy_lo && r <= cy_hi && (!(V & 4) || (m_col & RF_FNE(dC, (double)NOMATCH)))) { // round 3's form of the same
                 const bool lv = colok && dC != (double)NOMATCH; // .cpp:613
                 const bool ew = dE != (double)NOMATCH && dW != (double)NOMATCH, ns = dS != (double)NOMATCH && dN != (double)NOMATCH;
                 const int rel = (int)(dC - 1.5); // .cpp:625 (iMatch - x)
@@ -1161,12 +1190,13 @@ void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev
     } while (0)
     if (T == 2) RF_LAUNCH_V(2, 0);
     else if (T == 3) RF_LAUNCH_V(3, 0);
-    else // the variants exist for T = 4 only (option refine_skew_variant; 4 = the shipped kernel)
-        switch (a.skew_variant & 7) {
+    else // the variants exist for T = 4 only (option refine_skew_variant; 12 = the shipped kernel)
+        switch (a.skew_variant & 15) {
         case 1: RF_LAUNCH_V(4, 1); break;
         case 2: RF_LAUNCH_V(4, 2); break;
         case 3: RF_LAUNCH_V(4, 3); break;
         case 4: RF_LAUNCH_V(4, 4); break;
+        case 12: RF_LAUNCH_V(4, 12); break;
         default: RF_LAUNCH_V(4, 0); break;
         }
 #undef RF_LAUNCH_V
