@@ -218,11 +218,12 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          sweeps (k_refine_skew): T (2..4, default 4) sweeps per launch from that sweep of a level on (default
  *                          22; 0 = never) at levels with at least min_px margin pixels per direction (default 1 M: the two
  *                          largest levels of a 12 MP pair), aiming at `waves` workgroups (default 1280) or `rows` rows per chunk
- *   "refine_skew_variant"  the T = 4 time-skewed kernel, a bit set (default 12 = 4 + 8): 4 rows of a strip without a live
+ *   "refine_skew_variant"  the T = 4 time-skewed kernel, a bit set (default 28 = 4 + 8 + 16): 4 rows of a strip without a live
  *                          pixel (outside an elliptic mask, a hole) skip the update math (C3 +5 %, C2 unchanged); 8 the row's
  *                          wave-level predicates as lane masks straight from the compares (5.6 % fewer vector instructions,
- *                          +2 %); 1 / 2 = two bit-identical restatements measured SLOWER (a row's staging shared by two waves /
- *                          lane masks + unscaled divisions behind a late guard), kept for A/B; 0 = round 3's kernel
+ *                          +2 %); 16 only the cache way the state selects is read from LDS (+1.5 %); 1 / 2 = two bit-identical
+ *                          restatements measured SLOWER (a row's staging shared by two waves / lane masks + unscaled divisions
+ *                          behind a late guard), kept for A/B; 0 = round 3's kernel
  *   "refine_prefill"       1 (default): the first sweep of a level also fills the second cache way (0: A/B)
  *   "refine_split"         1 (default): a pair that has the GPU to itself (no other context of the device inside rsm_run_pair,
  *                          no per-launch timing) runs the two directions of its time-skewed sections as separate launch chains

@@ -941,13 +941,18 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
 // scatters afterwards (another strip may be staging the same pixel's entries at that moment: an in-place write could
 // be read torn).  At most one record per (pixel, way) and launch, so k_refine_apply never sees two writers of a slot.
 // Values are those of T single sweeps, bit for bit (tests/test_gpu_parity.py).
-// V (option refine_skew_variant, T = 4; the default is 12 = 4 + 8).
+// V (option refine_skew_variant, T = 4; the default is 28 = 4 + 8 + 16).
 //   V & 4: a row without a live pixel in the strip copies through without the update math (C3's elliptic masks leave 27 % of the
 //          margin's box empty: 272 -> 286 Mdisp/s; C2 unchanged).
 //   V & 8: the row's wave-level predicates (miss, "every live pixel has four neighbours", the update's rare cases) as lane masks
 //          straight from the compares -- a ballot of a COMBINED bool costs a v_cndmask + v_cmp pair, three times per row; all
 //          tests stay EARLY in the row's chain: 99.2 M vector wave-instructions per launch against 104.9 M, 0.313 ms against
 //          0.322, +2 % on C2 and C3.
+//   V & 16: only the cache way the state selects is read from LDS, in a second round trip once dC is there, instead of both
+//          ways and four selects: 93.2 M vector wave-instructions against 97.4 M, a quarter less LDS read traffic, +1.5 % on C2
+//          and C3 (four same-box repetitions each).
+// (Round 4 also took the vector address arithmetic out of the staging: scalar row pointer + 32-bit lane byte offset is the
+// load's own addressing mode -- 99.2 M -> 97.4 M.)
 // The other two bits hold round-4 restatements that compute the same bits with less work per wave and are SLOWER, kept as
 // measured evidence of what bounds this kernel:
 //   V & 1: the staging of a row shared by two waves (below);
@@ -991,26 +996,29 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     double nd = 0, np0 = 0, nq0 = 0, np1 = 0, nq1 = 0;
     uint32_t nk0 = 0, nk1 = 0; // packed only when they go to LDS: nothing may consume a loaded value in the step that issues the load
     const uint16_t *__restrict__ keys = (const uint16_t *)d.rf_key;
-    const unsigned xcu0 = (unsigned)xc; // row pointers are wave-uniform, the column a 32-bit lane offset: no 64-bit address arithmetic per lane
     // V & 1 (T = 4): the staging of a row is shared by two waves -- waves 0 / 1 take the state and the keys of the even / odd rows,
     // waves 2 / 3 both ways' (pwp, delta) -- so that every wave stages every other step (3 or 4 loads, 2 or 3 LDS writes) instead
     // of two waves carrying all seven loads and five writes while the other two wait at the barrier.
     constexpr bool BAL = (V & 1) && T == 4;
     const bool st_lo = !BAL || wid < 2, st_hi = !BAL || wid >= 2; // what this wave stages: state + keys / the entries
+    unsigned xb8 = (unsigned)xc * 8u, xb2 = (unsigned)xc * 2u; // the column as 32-bit BYTE offsets (not const: see load_row)
     auto load_row = [&](int row) {
         const size_t p = (size_t)row * W;
-        unsigned xcu = xcu0;
-        asm volatile("" : "+v"(xcu)); // keeps (array + column) from being hoisted into seven 64-bit lane addresses
+        // scalar row pointer + 32-bit lane byte offset = the load's own addressing mode: no vector address arithmetic at all
+        // (the empty asm keeps the compiler from widening the offsets into 64-bit lane addresses that live across the loop)
+        asm volatile("" : "+v"(xb8), "+v"(xb2));
+        auto ld8 = [&](const double *q) { return *(const double *)((const char *)q + xb8); };
+        auto ld2 = [&](const uint16_t *q) { return (uint32_t) * (const uint16_t *)((const char *)q + xb2); };
         if (st_lo) {
-            nd = (in + p)[xcu];
-            nk0 = (keys + p)[xcu];
-            nk1 = (keys + p + way1)[xcu];
+            nd = ld8(in + p);
+            nk0 = ld2(keys + p);
+            nk1 = ld2(keys + p + way1);
         }
         if (st_hi) {
-            np0 = (d.rf_pwp + p)[xcu];
-            nq0 = (d.rf_delta + p)[xcu];
-            np1 = (d.rf_pwp + p + way1)[xcu];
-            nq1 = (d.rf_delta + p + way1)[xcu];
+            np0 = ld8(d.rf_pwp + p);
+            nq0 = ld8(d.rf_delta + p);
+            np1 = ld8(d.rf_pwp + p + way1);
+            nq1 = ld8(d.rf_delta + p + way1);
         }
     };
     const int spar = BAL ? (wid & 1) : wid; // this wave stages the rows of this parity (!BAL: waves 0 and 1 only)
@@ -1050,20 +1058,24 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             // one LDS round trip: the five state values, the keys and BOTH ways' entries (the way depends on dC)
             double dC, dN, dS, dE, dW;
             uint32_t kk;
-            double2 e0, e1;
+            double2 e0 = make_double2(0.0, 0.0), e1 = e0;
             auto operands = [&]() {
                 dC = s_d[t - 1][r & 3][lane + 1];
                 dN = s_d[t - 1][(r - 1) & 3][lane + 1];
                 dS = s_d[t - 1][(r + 1) & 3][lane + 1];
                 dE = s_d[t - 1][r & 3][lane + 2];
                 dW = s_d[t - 1][r & 3][lane];
-                e0 = s_ent[e][0][lane];
-                e1 = s_ent[e][1][lane];
+                if (!(V & 16)) { // V & 16: only the way the state selects is read, in a second LDS round trip (below)
+                    e0 = s_ent[e][0][lane];
+                    e1 = s_ent[e][1][lane];
+                }
                 kk = s_key[e][lane];
             };
             operands();
-            if (V & 4) // (one LDS round trip: none of the reads may sink below the live-row test, which needs dC only)
-                asm volatile("" : "+v"(dN), "+v"(dS), "+v"(dE), "+v"(dW), "+v"(kk), "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
+            if (V & 4) { // (one LDS round trip: none of the reads may sink below the live-row test, which needs dC only)
+                asm volatile("" : "+v"(dN), "+v"(dS), "+v"(dE), "+v"(dW), "+v"(kk));
+                if (!(V & 16)) asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
+            }
             double val = dC;
             RF_TICK(1) // LDS operands arrived
             if ((V & 10) && r >= cy_lo && r <= cy_hi && (!(V & 4) || (m_col & RF_FNE(dC, (double)NOMATCH)))) { // wave-uniform: rows sweep t can compute here; predicates as lane masks
@@ -1076,17 +1088,17 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 const unsigned long long m_miss = RF_EXP(8) ? 0ull : m_lv & (m_ew | m_ns) & ~RF_IEQ(crel, rel);
                 // (keeps both entry reads in the first LDS batch: they are dead on the miss path, which reloads them, and
                 // would otherwise sink below it and add a second LDS round trip to every row)
-                asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
+                if (!(V & 16)) asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
                 if (m_miss) { // wave-uniform, rare
                     skew_miss(a, d, W, H, x, xa - T, r, rel, way, lane, rf_sel(m_miss), xown && r >= ya && r < yb, cnt, shard, s_ent[e], s_key[e], s_emit[e], kk, s_ml[wid]);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     operands(); // from LDS again (the entries now with the new ones): nothing lives in registers across the data-term routine
                     asm volatile("" : "+v"(dC), "+v"(dN), "+v"(dS), "+v"(dE), "+v"(dW), "+v"(kk));
-                    asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
+                    if (!(V & 16)) asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
                     val = dC;
                 }
-                const double2 pd = way ? e1 : e0;
+                const double2 pd = (V & 16) ? s_ent[e][way][lane] : (way ? e1 : e0);
                 if (!RF_EXP(2)) {
                     if (!(m_lv & ~(m_ew & m_ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
                         const double u = (V & 8) ? refine_update3e(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv)
@@ -1098,9 +1110,8 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     }
                 }
                 if (t == T && rf_sel(m_lv & m_own)) { // sweep T's computable rows are the owned rows (xc == x there)
-                    unsigned xo = xcu0;
-                    asm volatile("" : "+v"(xo)); // no hoisted (and then spilled) 64-bit lane address
-                    (out + (size_t)r * W)[xo] = val;
+                    asm volatile("" : "+v"(xb8)); // scalar row pointer + 32-bit lane byte offset (no hoisted 64-bit lane address)
+                    *(double *)((char *)(out + (size_t)r * W) + xb8) = val;
                 }
             }
             // V & 4: a row without a live pixel in this strip (outside an elliptic mask, a hole) copies through without the update
@@ -1138,9 +1149,8 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     }
                 }
                 if (t == T && lv && xown) { // sweep T's computable rows are the owned rows (xc == x there)
-                    unsigned xo = xcu0;
-                    asm volatile("" : "+v"(xo)); // no hoisted (and then spilled) 64-bit lane address
-                    (out + (size_t)r * W)[xo] = val;
+                    asm volatile("" : "+v"(xb8)); // scalar row pointer + 32-bit lane byte offset (no hoisted 64-bit lane address)
+                    *(double *)((char *)(out + (size_t)r * W) + xb8) = val;
                 }
             }
             if (t < T) s_d[t][r & 3][lane + 1] = val;
@@ -1190,13 +1200,14 @@ void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev
     } while (0)
     if (T == 2) RF_LAUNCH_V(2, 0);
     else if (T == 3) RF_LAUNCH_V(3, 0);
-    else // the variants exist for T = 4 only (option refine_skew_variant; 12 = the shipped kernel)
-        switch (a.skew_variant & 15) {
+    else // the variants exist for T = 4 only (option refine_skew_variant; 28 = the shipped kernel)
+        switch (a.skew_variant & 31) {
         case 1: RF_LAUNCH_V(4, 1); break;
         case 2: RF_LAUNCH_V(4, 2); break;
         case 3: RF_LAUNCH_V(4, 3); break;
         case 4: RF_LAUNCH_V(4, 4); break;
         case 12: RF_LAUNCH_V(4, 12); break;
+        case 28: RF_LAUNCH_V(4, 28); break;
         default: RF_LAUNCH_V(4, 0); break;
         }
 #undef RF_LAUNCH_V

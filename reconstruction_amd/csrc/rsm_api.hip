@@ -141,7 +141,7 @@ struct rsm_ctx {
     int opt_refine_skew_min_px = 1000000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
     int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
-    int opt_refine_skew_variant = 12;    // T = 4 kernel (k_refine.hip): bit 2 rows without a live pixel skip the update math, bit 3 the row's predicates as lane masks (both default); bits 0 / 1 = two bit-identical restatements measured slower (a row's staging shared by two waves / lane masks + unscaled divisions behind a late guard)
+    int opt_refine_skew_variant = 28;    // T = 4 kernel (k_refine.hip), a bit set: 4 rows without a live pixel skip the update math, 8 the row's predicates as lane masks, 16 only the selected cache way is read (all three default); bits 0 / 1 = two bit-identical restatements measured slower
 
     // profiling
     bool profile = false;
@@ -513,7 +513,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
-    else if (!strcmp(name, "refine_skew_variant")) c->opt_refine_skew_variant = (int)std::max(0LL, std::min(value, 15LL));
+    else if (!strcmp(name, "refine_skew_variant")) c->opt_refine_skew_variant = (int)std::max(0LL, std::min(value, 31LL));
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "cu_share")) {
         // Contexts that share a GPU each on their own share of the compute units (the `ordinal % n`-th of n equal ranges of the

@@ -78,7 +78,7 @@ struct StageArgs {
     RfMiss *miss_list; // RF_UPD_SHARDS regions of miss_cap records (counters: upd_cnt); nullptr = never defer
     int miss_cap;      // >= 1024 x the workgroups a shard can receive: a deferring sweep never overflows
     int skew_rows;     // refine (k_refine_skew): rows per chunk
-    int skew_variant;  // refine (k_refine_skew, T = 4): bit set, 12 = the shipped kernel (k_refine.hip)
+    int skew_variant;  // refine (k_refine_skew, T = 4): bit set, 28 = the shipped kernel (k_refine.hip)
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int opt_no_exact;               // skip k_ncc_exact (timing A/B only: ties then follow the integer form)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
