@@ -375,8 +375,9 @@ def main():
                                              "(s_waitcnt / barrier) %s of its cycles: %s" % (
                                                  100 * valu["active_frac"], 100 * hbm_util, ("%.0f %%" % (100 * parked)) if parked is not None else "?",
                                                  "the fp64 VALU is the busiest unit and neither it nor the memory system is saturated -- the waves' dependent fp64 chains "
-                                                 "(5 waves per SIMD) and the launch's low-occupancy tail bound the kernel: a bit-identical restatement with 8 % fewer vector "
-                                                 "instructions ran 5 % slower (option refine_skew_variant = 2, DESIGN.md 4)"
+                                                 "(5 waves per SIMD), its issue rate while all workgroups are resident and the launch's low-occupancy tail bound the kernel: "
+                                                 "vector instructions removed early in a row's chain pay (option refine_skew_variant bits 8 / 16), the same removed behind "
+                                                 "a late guard (bit 2) or traded for a shorter chain cost time (DESIGN.md 4)"
                                                  if hbm_util < valu["active_frac"] else "the memory system is the busiest unit"))
         if rig:
             # BASELINE configs[3]: the SAME ten pairs at every N (strong scaling): pair p on rank p % N; a step
