@@ -212,6 +212,9 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *   "ncc_bytes" = 1        the generic byte-wise NCC kernel instead of the dot4 one
  *   "wide_rows" = 0 | 1 | 2 | 3   rows of wide pixels: default (= 2) / the one-workgroup-per-pixel kernel / the int8 row GEMM
  *                          on the matrix cores / sliding window sums;  "no_rowgemm" = 1 is wide_rows = 1
+ *   "ncc_mid" / "ncc_slide_max"   which rows of long-interval pixels leave the band kernel (intervals longer than ncc_mid
+ *                          candidates; 0 = by window size from the measured crossover) and which of them take the sliding sums
+ *                          (widest interval <= ncc_slide_max, default 512) rather than the int8 row GEMM
  *   "no_exact" = 1         (timing A/B only) skip the reference-order re-evaluation of near-tie pixels
  *   "refine_band_mb" / "refine_band_rows"   time-skewed band schedule of the refine sweeps (0 = whole-frame, default)
  *   "refine_skew_from" / "refine_skew_T" / "refine_skew_min_px" / "refine_skew_waves" / "refine_skew_rows"   time-skewed refine
@@ -224,6 +227,9 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          +2 %); 16 only the cache way the state selects is read from LDS (+1.5 %); 1 / 2 = two bit-identical
  *                          restatements measured SLOWER (a row's staging shared by two waves / lane masks + unscaled divisions
  *                          behind a late guard), kept for A/B; 0 = round 3's kernel
+ *   "cu_share" = n         n > 1: the context's streams are confined to one of n equal shares of the compute units (the
+ *                          context's creation ordinal on its device picks the share; measured slower than sharing the whole
+ *                          chip in turns); 0 / 1 = the whole chip
  *   "refine_prefill"       1 (default): the first sweep of a level also fills the second cache way (0: A/B)
  *   "refine_split"         1 (default): a pair that has the GPU to itself (no other context of the device inside rsm_run_pair,
  *                          no per-launch timing) runs the two directions of its time-skewed sections as separate launch chains

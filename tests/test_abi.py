@@ -103,3 +103,15 @@ def test_mock_adapter_program_builds_and_links(tmp_path):
                         "-L" + os.path.dirname(_lib.LIB_PATH), "-lrsm_mi355", "-Wl,-rpath-link,/opt/rocm/lib",
                         "-Wl,--allow-shlib-undefined", "-pthread"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_every_option_of_rsm_set_option_is_documented_in_the_header():
+    """include/rsm.h lists the tuning knobs; a name rsm_set_option accepts and the header does not mention is a knob nobody
+    can find."""
+    import re
+    src = open(os.path.join(ROOT, "reconstruction_amd", "csrc", "rsm_api.hip")).read()
+    names = sorted(set(re.findall(r'!strcmp\(name, "([a-z_0-9]+)"\)', src)))
+    assert len(names) >= 20
+    hdr = open(os.path.join(ROOT, "include", "rsm.h")).read()
+    missing = [n for n in names if '"%s"' % n not in hdr]
+    assert not missing, missing
