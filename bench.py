@@ -49,7 +49,9 @@ def main():
     ap.add_argument("--measure-traffic", type=int, default=1,
                     help="1 (default, N = 1): two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one pair in a child process give "
                          "roofline.traffic; 0: quote profiles/pmc_traffic.json while it still describes this kernel source")
-    ap.add_argument("--adapter-pairs", type=int, default=9,
+    ap.add_argument("--adapter-inflight", type=int, default=0,
+                    help="pairs in flight inside the C++ adapter's MatchAll (0: two more than --inflight: a slot's pair is uploading or downloading part of the time; measured on C2 with 18 pairs: 3 slots 250, 4 271, 5 276, 6 281 Mdisp/s)")
+    ap.add_argument("--adapter-pairs", type=int, default=18,
                     help="pairs matched through the compiled C++ adapter (tests/cpp/adapter_bench.cpp) for value_adapter_pcie_inclusive; 0: skip")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -410,7 +412,7 @@ def main():
             # the drop-in as a maintainer integrates it: the compiled C++ adapter's MatchAll (include/rsm_stereo_adapter.hpp),
             # host images in, InsertPoint stream out, PCIe included -- never `value`
             try:
-                out["adapter"] = adapter_bench(cfgs, args.adapter_pairs, F, int(res.v_top))
+                out["adapter"] = adapter_bench(cfgs, args.adapter_pairs, args.adapter_inflight if args.adapter_inflight > 0 else F + 2, int(res.v_top))
                 out["value_adapter_pcie_inclusive"] = out["adapter"]["value"]
             except Exception as e:  # noqa: BLE001
                 out["adapter"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
