@@ -284,6 +284,8 @@ int rsm_stage_refine(rsm_ctx *ctx, const int16_t *disp_in, const uint8_t *img_ow
                      const rsm_boundary *own, double *disp_out);
 /* the specified exp(-t) of DisparityRefine's weights (CStereoMatching.cpp:665-666 call exp) on n values */
 int rsm_stage_exp_neg(rsm_ctx *ctx, const double *t, int64_t n, double *out);
+/* the same through the form the time-skewed refine kernel's common path evaluates (arguments below 512: no special-case code) */
+int rsm_stage_exp_neg_small(rsm_ctx *ctx, const double *t, int64_t n, double *out);
 /* DisparityRefine's two divisions (CStereoMatching.cpp:669,671) as the time-skewed kernel evaluates them on its common path --
  * the hardware's fp64 division sequence without its operand-scaling and fix-up steps -- beside the compiler's a / b, on n operand
  * pairs: the parity tests hold the two equal bit for bit over the operand range the kernel's guard admits */

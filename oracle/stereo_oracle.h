@@ -18,8 +18,10 @@
  *   - Everything else (stages that allocate cv::Mat, pyrDown, erode): PARITY
  *     UNPINNED -- restated line by line from the source, checked only by
  *     known-answer tests derivable from the code.
- *   - DisparityRefine's exp() is evaluated by a fully specified routine shared with the GPU kernels (orc_exp_neg;
- *     the C runtime's exp the reference calls is not bit-specified), see stereo_oracle.c.
+ *   - DisparityRefine's exp() (the C runtime's: MSVC's for the reference, absent here) is evaluated by a fully specified
+ *     routine shared with the GPU kernels: orc_exp_neg = the published table-driven algorithm of glibc 2.35's exp
+ *     (e_exp.c, third-party, pinned version = this image's libm) in the operation order of its FMA build; pinned against
+ *     that libm itself: bit-equal to exp() on 8.7 M arguments (tests/test_oracle_known_answers.py), see stereo_oracle.c.
  */
 #ifndef STEREO_ORACLE_H
 #define STEREO_ORACLE_H
@@ -142,7 +144,7 @@ void orc_rectify_pair(const double *K0, const double *K1, const double *E0, cons
 
 /* the fully specified exp(-t) of the refine weights (see stereo_oracle.c); mode 1 = host libm instead */
 double orc_exp_neg(double t);
-void orc_set_exp_mode(int libm);
+void orc_set_exp_mode(int mode); /* 0 specified, 1 host libm exp, 2 host expl rounded, 3 rounds 3-4's Taylor chain (control) */
 void orc_set_exp_soft_fma(int soft); /* 1: evaluate fma() through the C library even where the CPU has the instruction */
 void orc_exp_neg_array(const double *t, long long n, double *out);
 

@@ -478,11 +478,13 @@ class Context:
                                              C.c_double(ws), C.byref(_bd(own)), _p(out)))
         return out
 
-    def exp_neg(self, t):
-        """The specified exp(-t) of DisparityRefine's smoothness weights, evaluated on the device."""
+    def exp_neg(self, t, small_form: bool = False):
+        """The specified exp(-t) of DisparityRefine's smoothness weights, evaluated on the device (small_form: through the
+        time-skewed kernel's common-path form for arguments below 512)."""
         t = np.ascontiguousarray(t, np.float64).ravel()
         out = np.zeros(t.shape, np.float64)
-        self._chk(self._lib.rsm_stage_exp_neg(self._h, _p(t), C.c_int64(t.size), _p(out)))
+        fn = self._lib.rsm_stage_exp_neg_small if small_form else self._lib.rsm_stage_exp_neg
+        self._chk(fn(self._h, _p(t), C.c_int64(t.size), _p(out)))
         return out
 
     def div_unscaled(self, a, b):

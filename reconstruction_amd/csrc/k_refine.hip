@@ -16,75 +16,104 @@
 
 #include <limits.h>
 
-// exp(-t), t >= 0, for the smoothness weights (.cpp:665-666).  The reference calls the C runtime's exp, whose last
-// bit is not specified, and the sweep amplifies one-ulp differences chaotically (a 5-level test pair: agreement to
-// 1e-15 after 20 sweeps, 1.8 percent of the pixels off by up to 7e-3 after 150, between glibc's exp and the device
-// library's).  So the weights come from ONE fully specified evaluation, restated identically in the CPU oracle
-// (oracle/stereo_oracle.c: orc_exp_neg): x = -t = k ln2 + r, k = trunc(fma(1/ln2, x, -0.5)), r = fma(-k, ln2LO,
-// fma(-k, ln2HI, x)) (ln2 split so that k * ln2HI is exact; |r| <= 0.35), exp(r) by the degree-13 Taylor polynomial
-// as a Horner chain of 13 fused multiply-adds (coefficients 1/n! correctly rounded), times 2^k with one rounding
-// (exact unless the result is subnormal).  Every operation is a correctly rounded IEEE-754 operation (fma included),
-// so the bits are the same on every conforming machine; within 1 ulp of glibc's exp.  With it DisparityRefine is
-// bit-identical to the oracle.  (Rounds 1-2 specified the same polynomial with separate multiplies and adds: 44
-// instead of 22 fp64 instructions per call, two calls per pixel update.)
-__device__ __forceinline__ double exp_neg(double t) {
-    const double ln2HI = 0x1.62e42feep-1, ln2LO = 0x1.a39ef35793c76p-33, invln2 = 0x1.71547652b82fep+0;
-    double r = -t;
-    const int k = (int)__builtin_fma(invln2, r, -0.5); // saturates for huge t; the result is 0 then anyway (below)
-    const double tk = (double)k;
-    r = __builtin_fma(-tk, ln2LO, __builtin_fma(-tk, ln2HI, r)); // tk * ln2HI is exact
-    double p = 0x1.6124613a86d09p-33;                 // 1/13!
-    p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);   // 1/12!
-    p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);   // 1/11!
-    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);   // 1/10!
-    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);   // 1/9!
-    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);   // 1/8!
-    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);   // 1/7!
-    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);   // 1/6!
-    p = __builtin_fma(p, r, 0x1.1111111111111p-7);    // 1/5!
-    p = __builtin_fma(p, r, 0x1.5555555555555p-5);    // 1/4!
-    p = __builtin_fma(p, r, 0x1.5555555555555p-3);    // 1/3!
-    p = __builtin_fma(p, r, 0x1.0000000000000p-1);    // 1/2!
-    p = __builtin_fma(p, r, 1.0);                     // 1/1!
-    p = __builtin_fma(p, r, 1.0);                     // 1/0!
-    // p * 2^k, rounded once: v_ldexp_f64 (fp64 denormals are on).  p is in [0.70, 1.42], so the product is exact
-    // whenever it is normal (k >= -1021) and a single round-to-nearest-even into the subnormal range otherwise.
-    const double v = __builtin_ldexp(p, k);
-    return (t > 745.13321910194110842) ? 0.0 : v;     // underflow threshold of exp; also covers the saturated k
+// exp(-t), t >= 0, for the smoothness weights (.cpp:665-666).  The reference calls its C runtime's exp, whose last bit is not
+// specified, and the sweep amplifies last-bit differences chaotically (tests/test_oracle_exp_control.py).  So the weights come
+// from ONE fully specified evaluation, restated identically in the CPU oracle (oracle/stereo_oracle.c: orc_exp_neg) -- since
+// round 5 the exp of a real C runtime: glibc 2.35's table-driven exp (sysdeps/ieee754/dbl-64/e_exp.c, EXP_TABLE_BITS 7,
+// EXP_POLY_ORDER 5; <= 0.509 ulp) with exactly the operations of its FMA build (__exp_fma):
+//     kd = fma(x, 128/ln2, 0x1.8p52);  ki = bits(kd);  kd -= 0x1.8p52           x = -t = (128 e + j) ln2/128 + r
+//     r  = fma(kd, -ln2lo/128, fma(kd, -ln2hi/128, x))                           |r| <= ln2/256
+//     tmp = fma(r2*r2, fma(r, C5, C4), fma(fma(r, C3, C2), r2, r + T[j]))        r2 = r*r
+//     exp = fma(s, tmp, s),  s = 2^e H[j]  (table word + (ki << 45): one integer add on the high dword)
+// and glibc's specialcase() for |x| in [512, 1024) (where s alone may underflow); 0 beyond.  Every operation is a correctly
+// rounded IEEE-754 operation (fma included; fp64 denormals are on), so the bits are those of the oracle and of the host libm's
+// exp on every glibc >= 2.28 FMA host (0 of 8.7 M arguments differ).  12 fp64 + 3 integer vector instructions and ONE 16-byte
+// LDS read per call on an 8-deep dependent chain (rounds 3-4: a degree-13 Taylor Horner chain, 19 instructions 19 deep, whose
+// last bit differed from glibc's in 5.9 % of the arguments).  The 2 KB table {bits(T[j]), bits(H[j]) - (j << 45)} lives in
+// LDS: every refine kernel stages it first (exp_tab_stage), the gather then costs one LDS round trip beside the polynomial.
+#include "exp_table.h"
+#define EXP_INVLN2N 0x1.71547652b82fep+7
+#define EXP_SHIFT 0x1.8p52
+#define EXP_NEGLN2HIN (-0x1.62e42fefa0000p-8)
+#define EXP_NEGLN2LON (-0x1.cf79abc9e3b3ap-47)
+#define EXP_C2 0x1.ffffffffffdbdp-2
+#define EXP_C3 0x1.555555555543cp-3
+#define EXP_C4 0x1.55555cf172b91p-5
+#define EXP_C5 0x1.1111167a4d017p-7
+typedef const double2 *ExpTab; // the table in LDS: 128 x {tail, scale word}
+
+// every thread of the workgroup, before anything returns; the caller's barrier (__syncthreads) makes it visible
+__device__ __forceinline__ void exp_tab_stage(double2 *s_tab) {
+    unsigned long long *w = (unsigned long long *)s_tab;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) w[i] = RSM_EXP_TAB[i];
 }
 
-// exp_neg of two arguments with the two (independent) operation chains interleaved in program order: a 13-step Horner
-// chain of dependent fp64 fmas leaves the pipe idle between steps unless another wave fills in.  Same operations, same
-// values as two exp_neg calls.
-__device__ __forceinline__ void exp_neg2(double t1, double t2, double &w1, double &w2) {
-    const double ln2HI = 0x1.62e42feep-1, ln2LO = 0x1.a39ef35793c76p-33, invln2 = 0x1.71547652b82fep+0;
-    double r1 = -t1, r2 = -t2;
-    const int k1 = (int)__builtin_fma(invln2, r1, -0.5), k2 = (int)__builtin_fma(invln2, r2, -0.5);
-    const double tk1 = (double)k1, tk2 = (double)k2;
-    r1 = __builtin_fma(-tk1, ln2HI, r1);
-    r2 = __builtin_fma(-tk2, ln2HI, r2);
-    r1 = __builtin_fma(-tk1, ln2LO, r1);
-    r2 = __builtin_fma(-tk2, ln2LO, r2);
-    double p1 = 0x1.6124613a86d09p-33, p2 = 0x1.6124613a86d09p-33;
-#define RF_H(c)                      \
-    p1 = __builtin_fma(p1, r1, (c)); \
-    p2 = __builtin_fma(p2, r2, (c));
-    RF_H(0x1.1eed8eff8d898p-29) RF_H(0x1.ae64567f544e4p-26) RF_H(0x1.27e4fb7789f5cp-22) RF_H(0x1.71de3a556c734p-19)
-    RF_H(0x1.a01a01a01a01ap-16) RF_H(0x1.a01a01a01a01ap-13) RF_H(0x1.6c16c16c16c17p-10) RF_H(0x1.1111111111111p-7)
-    RF_H(0x1.5555555555555p-5) RF_H(0x1.5555555555555p-3) RF_H(0x1.0000000000000p-1) RF_H(1.0) RF_H(1.0)
-#undef RF_H
-    const double v1 = __builtin_ldexp(p1, k1), v2 = __builtin_ldexp(p2, k2);
-    w1 = (t1 > 745.13321910194110842) ? 0.0 : v1;
-    w2 = (t2 > 745.13321910194110842) ? 0.0 : v2;
+// the part before the final scaling: tmp ~ exp(r) - 1 + tail, s = 2^(ki/128)'s table word (may be below the normal range for t >= 512)
+__device__ __forceinline__ void exp_core(double x, ExpTab tab, double &tmp, double &s) {
+    const double kd0 = __builtin_fma(x, EXP_INVLN2N, EXP_SHIFT);
+    const uint32_t ki = (uint32_t)__double2loint(kd0); // ki mod 2^32: two's complement in the low mantissa bits
+    const double kd = kd0 - EXP_SHIFT;
+    double r = __builtin_fma(kd, EXP_NEGLN2HIN, x);
+    r = __builtin_fma(kd, EXP_NEGLN2LON, r);
+    const double2 e = tab[ki & 127u];
+    const double r2 = r * r;
+    const double pa = __builtin_fma(r, EXP_C3, EXP_C2), lo = r + e.x, pb = __builtin_fma(r, EXP_C5, EXP_C4);
+    tmp = __builtin_fma(pa, r2, lo);
+    const double r4 = r2 * r2;
+    tmp = __builtin_fma(r4, pb, tmp);
+    s = __hiloint2double(__double2hiint(e.y) + (int)(ki << 13), __double2loint(e.y)); // + (ki << 45)
 }
 
-// test entry: the specified exp on an array (rsm_stage_exp_neg)
-__global__ void k_exp_neg(const double *t, double *out, long long n) {
+// t < 512 (callers guarantee it with a wave-uniform test): the result and the scale are normal
+__device__ __forceinline__ double exp_neg_small(double t, ExpTab tab) {
+    double tmp, s;
+    exp_core(-t, tab, tmp, s);
+    return __builtin_fma(s, tmp, s);
+}
+__device__ __forceinline__ void exp_neg2_small(double t1, double t2, double &w1, double &w2, ExpTab tab) {
+    double tmp1, s1, tmp2, s2;
+    exp_core(-t1, tab, tmp1, s1);
+    exp_core(-t2, tab, tmp2, s2);
+    w1 = __builtin_fma(s1, tmp1, s1);
+    w2 = __builtin_fma(s2, tmp2, s2);
+}
+
+// any t >= 0
+__device__ __forceinline__ double exp_neg(double t, ExpTab tab) {
+    double tmp, s;
+    exp_core(-t, tab, tmp, s);
+    double v = __builtin_fma(s, tmp, s);
+    if (__builtin_expect(!(t < 512.0), 0)) { // e_exp.c: specialcase(), k < 0 (rare: |ex| or |ey| > 22.6 px)
+        const double s2 = __hiloint2double(__double2hiint(s) + 0x3fe00000, __double2loint(s)); // 2^1022 s
+        const double st = s2 * tmp; // (a separate multiply and add there, as glibc's build has them)
+        double y = s2 + st;
+        if (y < 1.0) { // the result is subnormal: re-round y as 1 + y would be, so that the final scaling rounds once
+            double lo = s2 - y + st;
+            const double hi = 1.0 + y;
+            lo = 1.0 - hi + y + lo;
+            y = (hi + lo) - 1.0;
+            if (y == 0.0) y = 0.0;
+        }
+        v = 0x1p-1022 * y;
+        if (t >= 1024.0) v = 0.0; // e_exp.c: __math_uflow
+    }
+    return v;
+}
+__device__ __forceinline__ void exp_neg2(double t1, double t2, double &w1, double &w2, ExpTab tab) {
+    w1 = exp_neg(t1, tab);
+    w2 = exp_neg(t2, tab);
+}
+
+// test entry: the specified exp on an array (rsm_stage_exp_neg); flag = 1: the t < 512 form on every argument below 512
+__global__ void k_exp_neg(const double *t, double *out, long long n, int small_form) {
+    __shared__ double2 s_exp[128];
+    exp_tab_stage(s_exp);
+    __syncthreads();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = exp_neg(t[i]);
+    if (i < n) out[i] = (small_form && t[i] < 512.0) ? exp_neg_small(t[i], s_exp) : exp_neg(t[i], s_exp);
 }
-void launch_exp_neg(const double *t, double *out, long long n, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(k_exp_neg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, out, n);
+void launch_exp_neg(const double *t, double *out, long long n, hipStream_t st, int small_form) {
+    if (n > 0) hipLaunchKernelGGL(k_exp_neg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, out, n, small_form);
 }
 
 __global__ void k_refine_init(StageArgs a) {
@@ -110,7 +139,7 @@ void launch_refine_init(const StageArgs &a, hipStream_t st) {
 
 // The update of .cpp:652-672 given the data term (pwp, delta = pdp - dCenter).
 __device__ __forceinline__ double refine_update(int mode, double dC, double dE, double dW, double dN, double dS,
-                                                double pwp, double delta, double ws) {
+                                                double pwp, double delta, double ws, ExpTab tab) {
     // pwp == 0 only happens for index 1 (.cpp:642-643: pdp = 0)
     const double pdp = (pwp == 0) ? 0.0 : dC + delta;
     if (mode == 1) return (pdp * pwp + ws * (dE + dW) / 2) / (pwp + ws); // .cpp:658
@@ -118,33 +147,11 @@ __device__ __forceinline__ double refine_update(int mode, double dC, double dE, 
     const double ex = fabs(dE - dC) - fabs(dW - dC);
     const double ey = fabs(dS - dC) - fabs(dN - dC);
     double wx, wy;
-    exp_neg2(ex * ex, ey * ey, wx, wy); // .cpp:665-666
+    exp_neg2(ex * ex, ey * ey, wx, wy, tab); // .cpp:665-666
     double ds;
     if (wx + wy == 0) ds = (dE + dW + dS + dN) / 4;
     else ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));
     return (pdp * pwp + ws * ds) / (pwp + ws); // .cpp:671
-}
-
-// exp_neg2 without the underflow selects: the same bits for t1, t2 <= 745.13 (callers guarantee it with a wave-uniform test).
-__device__ __forceinline__ void exp_neg2_small(double t1, double t2, double &w1, double &w2) {
-    const double ln2HI = 0x1.62e42feep-1, ln2LO = 0x1.a39ef35793c76p-33, invln2 = 0x1.71547652b82fep+0;
-    double r1 = -t1, r2 = -t2;
-    const int k1 = (int)__builtin_fma(invln2, r1, -0.5), k2 = (int)__builtin_fma(invln2, r2, -0.5);
-    const double tk1 = (double)k1, tk2 = (double)k2;
-    r1 = __builtin_fma(-tk1, ln2HI, r1);
-    r2 = __builtin_fma(-tk2, ln2HI, r2);
-    r1 = __builtin_fma(-tk1, ln2LO, r1);
-    r2 = __builtin_fma(-tk2, ln2LO, r2);
-    double p1 = 0x1.6124613a86d09p-33, p2 = 0x1.6124613a86d09p-33;
-#define RF_H(c)                      \
-    p1 = __builtin_fma(p1, r1, (c)); \
-    p2 = __builtin_fma(p2, r2, (c));
-    RF_H(0x1.1eed8eff8d898p-29) RF_H(0x1.ae64567f544e4p-26) RF_H(0x1.27e4fb7789f5cp-22) RF_H(0x1.71de3a556c734p-19)
-    RF_H(0x1.a01a01a01a01ap-16) RF_H(0x1.a01a01a01a01ap-13) RF_H(0x1.6c16c16c16c17p-10) RF_H(0x1.1111111111111p-7)
-    RF_H(0x1.5555555555555p-5) RF_H(0x1.5555555555555p-3) RF_H(0x1.0000000000000p-1) RF_H(1.0) RF_H(1.0)
-#undef RF_H
-    w1 = __builtin_ldexp(p1, k1);
-    w2 = __builtin_ldexp(p2, k2);
 }
 
 // fp64 division a / b as the hardware sequence the compiler emits for it (v_div_scale x2, v_rcp, two Newton steps, quotient,
@@ -179,6 +186,7 @@ void launch_div_unscaled(const double *a, const double *b, double *q_fast, doubl
 // a select / branch condition at no cost.  A ballot of a COMBINED bool costs two vector instructions (v_cndmask 0 / 1 + v_cmp).
 #define RF_FNE(x, y) __builtin_amdgcn_fcmp((x), (y), 14) // unordered or not equal: C's !=
 #define RF_FGT(x, y) __builtin_amdgcn_fcmp((x), (y), 2)  // ordered and greater: C's >
+#define RF_FUGE(x, y) __builtin_amdgcn_fcmp((x), (y), 11) // unordered or greater-equal: C's !(x < y)
 #define RF_IEQ(x, y) __builtin_amdgcn_sicmp((x), (y), 32)
 #define rf_sel(m) __builtin_amdgcn_inverse_ballot_w64(m)
 
@@ -188,13 +196,13 @@ void launch_div_unscaled(const double *a, const double *b, double *q_fast, doubl
 // neighbours; pwp == 0 with ws * ds == 0: (dC + delta) * 0 = +-0 otherwise adds like .cpp:642-643's pdp = 0) -- and whenever ws is
 // outside [2^-200, 2^200] (wsok: pwp is in [0, 1], so pwp + ws is in range with it).
 __device__ __forceinline__ double refine_update3m(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws,
-                                                  unsigned long long m_lv, bool wsok) {
+                                                  unsigned long long m_lv, bool wsok, ExpTab tab) {
     const double ex = fabs(dE - dC) - fabs(dW - dC);
     const double ey = fabs(dS - dC) - fabs(dN - dC);
     const double tx = ex * ex, ty = ey * ey;
     if (wsok) { // kernel-uniform
         double wx, wy;
-        exp_neg2_small(tx, ty, wx, wy); // .cpp:665-666; the same bits as exp_neg for t <= 745 (guard below: <= 200)
+        exp_neg2_small(tx, ty, wx, wy, tab); // .cpp:665-666; the same bits as exp_neg for t < 512 (guard below: <= 200)
         const double a1 = wx * (dE + dW) + wy * (dN + dS);
         const double ds = div_unscaled(a1, 2 * (wx + wy)); // the denominator is in [2^-287, 4]
         const double a2 = (dC + delta) * pwp + ws * ds;
@@ -204,7 +212,7 @@ __device__ __forceinline__ double refine_update3m(double dC, double dE, double d
     }
     const double pdp = (pwp == 0) ? 0.0 : dC + delta;
     double wx, wy;
-    exp_neg2(tx, ty, wx, wy); // .cpp:665-666
+    exp_neg2(tx, ty, wx, wy, tab); // .cpp:665-666
     const double sw = wx + wy;
     double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
     ds = (sw == 0) ? (dE + dW + dS + dN) / 4 : ds; // .cpp:667-668
@@ -214,19 +222,19 @@ __device__ __forceinline__ double refine_update3m(double dC, double dE, double d
 // refine_update3 with its one wave-uniform test taken from lane masks (no ballot of a combined bool) and nothing else changed:
 // the general divisions, the test early in the chain (k_refine_skew variant 8).
 __device__ __forceinline__ double refine_update3e(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws,
-                                                  unsigned long long m_lv) {
+                                                  unsigned long long m_lv, ExpTab tab) {
     const double ex = fabs(dE - dC) - fabs(dW - dC);
     const double ey = fabs(dS - dC) - fabs(dN - dC);
     const double tx = ex * ex, ty = ey * ey;
-    if (!(m_lv & (RF_FGT(fmax(tx, ty), 700.0) | ~RF_FNE(pwp, 0.0)))) { // wave-uniform; the usual case
+    if (!(m_lv & (RF_FUGE(fmax(tx, ty), 512.0) | ~RF_FNE(pwp, 0.0)))) { // wave-uniform; the usual case
         double wx, wy;
-        exp_neg2_small(tx, ty, wx, wy); // .cpp:665-666; both weights >= exp(-700) > 0
+        exp_neg2_small(tx, ty, wx, wy, tab); // .cpp:665-666; both weights > exp(-512) > 0
         const double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));
         return ((dC + delta) * pwp + ws * ds) / (pwp + ws); // .cpp:671
     }
     const double pdp = (pwp == 0) ? 0.0 : dC + delta;
     double wx, wy;
-    exp_neg2(tx, ty, wx, wy); // .cpp:665-666
+    exp_neg2(tx, ty, wx, wy, tab); // .cpp:665-666
     const double sw = wx + wy;
     double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
     ds = (sw == 0) ? (dE + dW + dS + dN) / 4 : ds; // .cpp:667-668
@@ -238,19 +246,19 @@ __device__ __forceinline__ double refine_update3e(double dC, double dE, double d
 // (|ex| or |ey| > 27), both weights zero (.cpp:667-668), pwp == 0 (.cpp:642-643) -- are tested ONCE for the whole row (`lv`: the
 // lanes whose result is kept) and handled by the general sequence when any kept lane needs it; otherwise their compares and
 // selects (10 of ~135 vector instructions) are not executed at all.
-__device__ __forceinline__ double refine_update3(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws, bool lv) {
+__device__ __forceinline__ double refine_update3(double dC, double dE, double dW, double dN, double dS, double pwp, double delta, double ws, bool lv, ExpTab tab) {
     const double ex = fabs(dE - dC) - fabs(dW - dC);
     const double ey = fabs(dS - dC) - fabs(dN - dC);
     const double tx = ex * ex, ty = ey * ey;
-    if (!__ballot(lv && (fmax(tx, ty) > 700.0 || pwp == 0))) { // wave-uniform; the usual case
+    if (!__ballot(lv && (!(fmax(tx, ty) < 512.0) || pwp == 0))) { // wave-uniform; the usual case
         double wx, wy;
-        exp_neg2_small(tx, ty, wx, wy); // .cpp:665-666; both weights >= exp(-700) > 0
+        exp_neg2_small(tx, ty, wx, wy, tab); // .cpp:665-666; both weights > exp(-512) > 0
         const double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * (wx + wy));
         return ((dC + delta) * pwp + ws * ds) / (pwp + ws); // .cpp:671
     }
     const double pdp = (pwp == 0) ? 0.0 : dC + delta;
     double wx, wy;
-    exp_neg2(tx, ty, wx, wy); // .cpp:665-666
+    exp_neg2(tx, ty, wx, wy, tab); // .cpp:665-666
     const double sw = wx + wy;
     double ds = (wx * (dE + dW) + wy * (dN + dS)) / (2 * sw);
     if (__ballot(sw == 0)) // both weights underflowed somewhere in the row (|ex|, |ey| > 27): .cpp:667-668, wave-uniform and rare
@@ -492,6 +500,9 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
 // First sweep of a level: every cache entry is empty, so instead of a worklist the kernel walks the whole
 // interior (and also does the mode 0 copy-through).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_refine_first(StageArgs a) {
+    __shared__ double2 s_exp[128]; // the specified exp's table (exp_tab_stage)
+    exp_tab_stage(s_exp);
+    __syncthreads();
     const int W = a.W, H = a.H;
     const DirArgs &d = a.d[blockIdx.z];
     const int x = d.own.XL + 1 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     d.rf_key[cpix] = (int16_t)(key - x);
     d.rf_pwp[cpix] = pwp;
     d.rf_delta[cpix] = delta;
-    const double val = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+    const double val = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws, s_exp);
     d.f64_b[pix] = val;
     // The second cache way, filled ahead of its first use.  The level starts from integers, so int(dC - 1.5) sits in the
     // middle of its interval and the pixel leaves it on the side its first update points to: measured with the oracle
@@ -562,6 +573,9 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
     // them once the iteration has settled -- never waits for a neighbour's ~3 us service chain.
     __shared__ uint32_t s_list[4][RFW_CAP]; // slot of the owner (lane * RF_PPT + i) | (iMatch - x) << 16
     __shared__ double s_res[4][RFW_CAP][2];
+    __shared__ double2 s_exp[128]; // the specified exp's table (exp_tab_stage)
+    exp_tab_stage(s_exp);
+    __syncthreads(); // (the only workgroup barrier: before any wave leaves)
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W, H = a.H;
     const int x = d.own.XL + 1 + blockIdx.x * 256 + (int)threadIdx.x;
@@ -681,7 +695,7 @@ __global__ __launch_bounds__(256) void k_refine_sweep(StageArgs a) {
             d.rf_delta[cpix] = delta[i];
         }
         out[pix] = (mode[i] == 0) ? col[i + 1] /* .cpp:655 */
-                                  : refine_update(mode[i], col[i + 1], dE[i], dW[i], col[i], col[i + 2], pwp[i], delta[i], a.ws);
+                                  : refine_update(mode[i], col[i + 1], dE[i], dW[i], col[i], col[i + 2], pwp[i], delta[i], a.ws, s_exp);
     }
 }
 
@@ -714,13 +728,15 @@ __global__ __launch_bounds__(256) void k_refine_multi(StageArgs a) {
     __shared__ uint8_t tflag[RM_TR + 2][RM_TW];  // way + 1 of a record the first sweep emitted for the pixel
     __shared__ uint32_t s_list[4][64];
     __shared__ double s_res[4][16][2];
+    __shared__ double2 s_exp[128]; // the specified exp's table (exp_tab_stage; the barrier below covers it)
+    exp_tab_stage(s_exp);
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W, H = a.H;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int X0 = d.own.XL + blockIdx.x * (RM_TW - 2); // lane l <-> column X0 + l; lanes 1..62 are this workgroup's
     const int Y0 = d.own.YL + 1 + blockIdx.y * RM_TR;   // own rows Y0 .. Y0+15
     const int xlo = d.own.XL + 1, xhi = d.own.XR - 1, ylo = d.own.YL + 1, yhi = d.own.YR - 1; // the interior
-    if (Y0 > yhi || X0 + 1 > xhi) return; // uniform
+    if (Y0 > yhi || X0 + 1 > xhi) return; // uniform (no barrier has been passed yet)
     const double *__restrict__ in = d.f64_a;
     double *__restrict__ out = d.f64_b;
     for (int e = threadIdx.x; e < (RM_TR + 4) * (RM_TW + 2); e += 256) {
@@ -812,7 +828,7 @@ __global__ __launch_bounds__(256) void k_refine_multi(StageArgs a) {
             } else if (p == 0) {
                 tflag[r][lane] = 0;
             }
-            const double val = !live ? dC : (mode == 0 ? dC /* .cpp:655 */ : refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws));
+            const double val = !live ? dC : (mode == 0 ? dC /* .cpp:655 */ : refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws, s_exp));
             if (p == 0) ts1[r][lane] = val;
             else if (live) out[pix] = val;
         }
@@ -825,6 +841,9 @@ __global__ __launch_bounds__(256) void k_refine_multi(StageArgs a) {
 // level: 1-10 % of the pixels miss, scattered over all waves).  Writes the cache entry and the pixel's update exactly as
 // the sweep would have, and clears the other counter set for the next deferring sweep.
 __global__ __launch_bounds__(256) void k_refine_fixup(StageArgs a) {
+    __shared__ double2 s_exp[128]; // the specified exp's table (exp_tab_stage)
+    exp_tab_stage(s_exp);
+    __syncthreads();
     const int32_t *cnt = a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < RF_UPD_SHARDS) a.upd_cnt[((a.flag3 + 1) & 1) * RF_UPD_SHARDS + threadIdx.x] = 0;
     const int W = a.W, H = a.H;
@@ -845,7 +864,7 @@ __global__ __launch_bounds__(256) void k_refine_fixup(StageArgs a) {
             d.rf_key[cpix] = (int16_t)u.rel;
             d.rf_pwp[cpix] = pwp;
             d.rf_delta[cpix] = delta;
-            d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws);
+            d.f64_b[pix] = refine_update(mode, dC, dE, dW, dN, dS, pwp, delta, a.ws, s_exp);
         }
     }
 }
@@ -877,7 +896,7 @@ __global__ __launch_bounds__(256) void k_refine_apply(StageArgs a) {
 // appended to the update list.
 __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, int W, int H, int x, int x_lane0, int r, int rel, int way, int lane, bool miss,
                                           bool owned, int32_t *cnt, unsigned shard, double2 (*ent_rows)[64], uint32_t *key_row,
-                                          uint8_t *emit_row, uint32_t kk, uint8_t *mlist) {
+                                          unsigned long long *emit_row, uint32_t kk, uint8_t *mlist) {
     const unsigned long long mm = __ballot(miss);
     const int n = __popcll(mm);
     const int rank = __popcll(mm & ((1ull << lane) - 1ull));
@@ -904,8 +923,8 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
         ent_rows[way][lane] = pd;
         key_row[lane] = way ? ((kk & 0xffffu) | ((uint32_t)(rel & 0xffff) << 16)) : ((kk & 0xffff0000u) | (uint32_t)(rel & 0xffff));
     }
-    const unsigned fl = miss ? emit_row[lane] : 0u;
-    const bool emit = miss && owned && !((fl >> way) & 1u);
+    const unsigned long long fl0 = emit_row[0], fl1 = emit_row[1]; // (one wave at a time works on a row slot)
+    const bool emit = miss && owned && !(((way ? fl1 : fl0) >> lane) & 1ull);
     const unsigned long long em = __ballot(emit);
     if (em) {
         const int leader = __builtin_ctzll(em);
@@ -919,7 +938,12 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
             u.pwp = pd.x;
             u.delta = pd.y;
             a.upd_list[(size_t)shard * a.upd_cap + base] = u;
-            emit_row[lane] = (uint8_t)(fl | (1u << way));
+        }
+        const bool listed = emit && base < a.upd_cap;
+        const unsigned long long n0 = __ballot(listed && !way), n1 = __ballot(listed && way);
+        if (lane == 0) {
+            emit_row[0] = fl0 | n0;
+            emit_row[1] = fl1 | n1;
         }
     }
 }
@@ -965,7 +989,9 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     __shared__ double s_d[T][4][66];       // [level][row & 3][lane + 1]
     __shared__ double2 s_ent[NE][2][64];   // [row slot][way][lane] = (pwp, delta)
     __shared__ uint32_t s_key[NE][64];     // key of way 0 | key of way 1 << 16
-    __shared__ uint8_t s_emit[NE][64];     // bit way: this launch already listed a new entry for that cache slot
+    __shared__ unsigned long long s_emit[NE][2]; // [row slot][way]: the lanes whose cache slot this launch already listed a new entry for
+    __shared__ double2 s_exp[128];         // the specified exp's table (exp_tab_stage; 2 KB: the workgroup stays within the 32 000 B that
+                                           // let five of them share a CU -- 31 632 B at T = 4)
     __shared__ uint8_t s_ml[T][64];        // per wave: the lanes of a row's misses, for the four-lanes-per-entry service
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W, H = a.H;
@@ -973,6 +999,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int xa = XL + 1 + (int)blockIdx.x * UW, xb = min(xa + UW, XR);                 // owned columns [xa, xb)
     const int ya = YL + 1 + (int)blockIdx.y * a.skew_rows, yb = min(ya + a.skew_rows, YR); // owned rows [ya, yb)
     if (xa >= XR || ya >= YR) return; // workgroup-uniform
+    exp_tab_stage(s_exp); // (the first update is at least two of the loop's barriers away)
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = wid + 1; // this wave's sweep within the launch
     const int x = xa - T + lane;
     const int xc = min(max(x, 0), W - 1);
@@ -1101,12 +1128,12 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 const double2 pd = (V & 16) ? s_ent[e][way][lane] : (way ? e1 : e0);
                 if (!RF_EXP(2)) {
                     if (!(m_lv & ~(m_ew & m_ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
-                        const double u = (V & 8) ? refine_update3e(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv)
-                                                 : refine_update3m(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv, wsok);
+                        const double u = (V & 8) ? refine_update3e(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv, s_exp)
+                                                 : refine_update3m(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, m_lv, wsok, s_exp);
                         val = rf_sel(m_lv) ? u : dC;
                     } else if (rf_sel(m_lv)) {
                         const int mode = (int)rf_sel(m_ew) + (int)rf_sel(m_ns) * 2; // .cpp:620
-                        if (mode != 0) val = refine_update(mode, dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
+                        if (mode != 0) val = refine_update(mode, dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, s_exp);
                     }
                 }
                 if (t == T && rf_sel(m_lv & m_own)) { // sweep T's computable rows are the owned rows (xc == x there)
@@ -1141,11 +1168,11 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 const double2 pd = way ? e1 : e0;
                 if (!RF_EXP(2)) {
                     if (!__ballot(lv && !(ew && ns))) { // every live pixel of the row is mode 3: straight-line code on all lanes
-                        const double u = refine_update3(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, lv);
+                        const double u = refine_update3(dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, lv, s_exp);
                         val = lv ? u : dC;
                     } else if (lv) {
                         const int mode = (int)ew + (int)ns * 2; // .cpp:620
-                        if (mode != 0) val = refine_update(mode, dC, dE, dW, dN, dS, pd.x, pd.y, a.ws);
+                        if (mode != 0) val = refine_update(mode, dC, dE, dW, dN, dS, pd.x, pd.y, a.ws, s_exp);
                     }
                 }
                 if (t == T && lv && xown) { // sweep T's computable rows are the owned rows (xc == x there)
@@ -1161,7 +1188,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             if (st_lo) {
                 s_d[0][(s + 1) & 3][lane + 1] = nd;
                 s_key[es][lane] = nk0 | (nk1 << 16);
-                s_emit[es][lane] = 0;
+                if (lane < 2) s_emit[es][lane] = 0ull;
             }
             if (st_hi) {
                 s_ent[es][0][lane] = make_double2(np0, nq0);

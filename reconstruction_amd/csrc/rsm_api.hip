@@ -1509,7 +1509,7 @@ extern "C" int rsm_stage_median(rsm_ctx *c, int16_t *disp, const uint8_t *mask_o
 
 // The specified exp(-t) of DisparityRefine's smoothness weights (k_refine.hip: exp_neg) on an array: lets the parity
 // tests hold the device evaluation to the oracle's bit for bit over the whole argument range.
-extern "C" int rsm_stage_exp_neg(rsm_ctx *c, const double *t_in, int64_t n, double *out) {
+static int stage_exp_neg(rsm_ctx *c, const double *t_in, int64_t n, double *out, int small_form) {
     if (!c || !t_in || !out || n < 0) return RSM_E_INVALID;
     if (n == 0) return RSM_OK;
     if (hipSetDevice(c->device) != hipSuccess) return set_err(c, RSM_E_HIP, "hipSetDevice");
@@ -1517,10 +1517,13 @@ extern "C" int rsm_stage_exp_neg(rsm_ctx *c, const double *t_in, int64_t n, doub
     const double *dt = t.up(t_in, (size_t)n);
     double *dout = t.alloc<double>((size_t)n);
     if (!t.ok) return finish(c, t);
-    launch_exp_neg(dt, dout, (long long)n, c->stream);
+    launch_exp_neg(dt, dout, (long long)n, c->stream, small_form);
     t.down(out, dout, (size_t)n);
     return finish(c, t);
 }
+extern "C" int rsm_stage_exp_neg(rsm_ctx *c, const double *t_in, int64_t n, double *out) { return stage_exp_neg(c, t_in, n, out, 0); }
+// the form the time-skewed kernel's common path uses (no special-case code) on every argument below 512, the general one elsewhere
+extern "C" int rsm_stage_exp_neg_small(rsm_ctx *c, const double *t_in, int64_t n, double *out) { return stage_exp_neg(c, t_in, n, out, 1); }
 
 // k_refine_skew's unscaled division beside the compiler's (k_refine.hip: div_unscaled) on arrays of operands
 extern "C" int rsm_stage_div_unscaled(rsm_ctx *c, const double *a_in, const double *b_in, int64_t n, double *q_fast, double *q_ieee) {

@@ -118,7 +118,7 @@ void launch_uniq_f64(double *p, const double *q, int W, int H, Mg own, Mg oth, h
 // d16_in, mask_own -> BL, BR; emit_list: also fill rf_list / ncc_cnt with the pixels Rematch has to evaluate
 void launch_set_boundary(const StageArgs &a, hipStream_t st, bool emit_list = false);
 void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_out (pre-filled NOMATCH)
-void launch_exp_neg(const double *t, double *out, long long n, hipStream_t st); // the specified exp(-t) (tests)
+void launch_exp_neg(const double *t, double *out, long long n, hipStream_t st, int small_form); // the specified exp(-t) (tests)
 // k_refine_skew's division without operand scaling beside the compiler's a / b (tests)
 void launch_div_unscaled(const double *a, const double *b, double *q_fast, double *q_ieee, long long n, hipStream_t st);
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset

@@ -113,3 +113,21 @@ def libm_exp_stats(res_disp, ref_disp):
         out.append(dict(valid=int(both.sum()), nomatch_mismatch=int((na != nb).sum()), above_1e3=int((rel > 1e-3).sum()),
                         above_1e9=int((rel > 1e-9).sum()), max_rel=float(rel.max()) if rel.size else 0.0))
     return out
+
+
+def host_libm_is_glibc_with_fma():
+    """Whether the host libm's exp is the routine the specification restates, run the way it restates it: glibc >= 2.28
+    (the table-driven exp) on an x86-64 CPU with FMA3 (glibc's ifunc then picks __exp_fma)."""
+    import ctypes
+    import platform
+    if platform.machine() != "x86_64":
+        return False
+    try:
+        gnu = ctypes.CDLL(None).gnu_get_libc_version
+        gnu.restype = ctypes.c_char_p
+        major, minor = (int(v) for v in gnu().decode().split(".")[:2])
+    except Exception:
+        return False
+    with open("/proc/cpuinfo") as f:
+        flags = f.read()
+    return (major, minor) >= (2, 28) and " fma " in flags.replace("\n", " ")

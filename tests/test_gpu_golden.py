@@ -85,15 +85,27 @@ test_oracle_high_level_argmax_on_the_gpu_box = cpu_side.test_high_level_match_ag
 
 
 def test_hip_specified_exp_equals_the_oracle_bit_for_bit(ctx):
-    """DisparityRefine's only transcendental: the device evaluation of the specified exp(-t) (k_refine.hip: exp_neg; fma
-    chain + v_ldexp_f64) against the oracle's (explicit exponent arithmetic and one rounding multiply for subnormal
-    results) over 0.5 M arguments incl. every k switch point and the whole subnormal range -- equal bit patterns."""
+    """DisparityRefine's only transcendental: the device evaluation of the specified exp(-t) (k_refine.hip: exp_neg -- glibc
+    2.35's table-driven algorithm, the table in LDS, the scale by an integer add on the table word, glibc's special case for
+    t in [512, 1024)) against the oracle's over 1 M arguments incl. every table-index switch point, the special-case limits
+    and the whole subnormal range -- equal bit patterns, in the general form and in the form the time-skewed kernel's
+    common path uses (t < 512).  On a glibc / FMA host both are the C runtime's exp(-t) itself."""
     from oracle import oracle as orc
+    from helpers import host_libm_is_glibc_with_fma
     from test_oracle_known_answers import exp_test_arguments
     t = exp_test_arguments()
-    g, w = ctx.exp_neg(t), orc.exp_neg_array(t)
-    bad = g.view(np.int64) != w.view(np.int64)
-    assert not bad.any(), (int(bad.sum()), t[bad][:5], g[bad][:5], w[bad][:5])
+    w = orc.exp_neg_array(t)
+    for small in (False, True):
+        g = ctx.exp_neg(t, small_form=small)
+        bad = g.view(np.int64) != w.view(np.int64)
+        assert not bad.any(), (small, int(bad.sum()), t[bad][:5], g[bad][:5], w[bad][:5])
+    if host_libm_is_glibc_with_fma():
+        orc.set_exp_mode(1)
+        try:
+            libm = orc.exp_neg_array(t)
+        finally:
+            orc.set_exp_mode(0)
+        assert np.array_equal(g.view(np.int64), libm.view(np.int64))
 
 
 def test_hip_unscaled_division_is_the_ieee_division_inside_its_guard(ctx):

@@ -12,7 +12,7 @@ import pytest
 from oracle import oracle as orc
 from reconstruction_amd import synth
 
-from helpers import NOMATCH, cloud_scale, diff_report, libm_exp_stats, oracle_stages
+from helpers import NOMATCH, cloud_scale, diff_report, host_libm_is_glibc_with_fma, libm_exp_stats, oracle_stages
 
 pytestmark = pytest.mark.gpu
 
@@ -319,16 +319,22 @@ def test_reference_shaped_mirror_drives_the_pipeline(ctx):
 
 
 def test_libm_exp_sensitivity(ctx):
-    """Why the oracle and the kernels share one specified exp: switch the oracle to the host's libm exp (last bit
-    unspecified, as with the reference's C runtime) and DisparityRefine, bit-identical otherwise, drifts -- agreement to
-    ~1e-15 after 20 sweeps, per-cent-level outliers after the top level's 150."""
+    """Why the oracle and the kernels share one specified exp: switch the oracle to ANOTHER libm-grade exp (the host's expl
+    rounded to double: differs from the specified one in 0.08 % of its last bits) and DisparityRefine, bit-identical
+    otherwise, drifts -- agreement to ~1e-15 after 20 sweeps, up to ~2e-6 after the top level's 150; and against rounds 3-4's
+    1-ulp-grade Taylor chain up to 7e-3.  Against the host libm's exp() call itself nothing drifts on a glibc / FMA host: the
+    specification is that routine."""
     cfg, rec, fin = stages("s512x384_5levels")
     q = [r for r in rec if r["stage"] == "refine" and r["level"] == cfg.pyr_levels - 1][-1]
     k, v = q["level"], q["v"]
     g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], q["iters"], cfg.ws, q["mg"][v])
     assert np.array_equal(g, q["out"])                      # specified exp on both sides: every bit
-    orc.set_exp_mode(1)
     try:
+        orc.set_exp_mode(1)
+        o_libm = orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], q["iters"], cfg.ws, q["mg"][v])
+        orc.set_exp_mode(3)
+        o_taylor = orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], q["iters"], cfg.ws, q["mg"][v])
+        orc.set_exp_mode(2)
         o20 = orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], 20, cfg.ws, q["mg"][v])
         o = orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], q["iters"], cfg.ws, q["mg"][v])
     finally:
@@ -337,9 +343,15 @@ def test_libm_exp_sensitivity(ctx):
     ok = o != NOMATCH
     e20 = np.abs(g20[ok] - o20[ok]) / np.maximum(1.0, np.abs(o20[ok]))
     e = np.abs(g[ok] - o[ok]) / np.maximum(1.0, np.abs(o[ok]))
-    print("libm exp: max rel after 20 sweeps %.2e, after %d sweeps %.2e (%d of %d pixels above 1e-9)"
-          % (e20.max(), q["iters"], e.max(), int((e > 1e-9).sum()), int(ok.sum())))
-    assert e20.max() < 1e-12 and e.max() < 0.1
+    et = np.abs(g[ok] - o_taylor[ok]) / np.maximum(1.0, np.abs(o_taylor[ok]))
+    print("expl-rounded exp: max rel after 20 sweeps %.2e, after %d sweeps %.2e (%d of %d pixels above 1e-9); Taylor-chain exp: %.2e"
+          % (e20.max(), q["iters"], e.max(), int((e > 1e-9).sum()), int(ok.sum()), et.max()))
+    assert e20.max() < 1e-12 and e.max() < 1e-4 and et.max() < 0.1
+    assert np.array_equal(o_libm == NOMATCH, g == NOMATCH)
+    if host_libm_is_glibc_with_fma():
+        assert np.array_equal(g, o_libm)
+    else:
+        assert (np.abs(g[ok] - o_libm[ok]) / np.maximum(1.0, np.abs(o_libm[ok]))).max() < 1e-3
 
 
 @pytest.mark.parametrize("rows", [5, 16, 23, 64])
@@ -367,9 +379,10 @@ def test_refine_band_schedule_is_bit_identical(ctx, rows):
 def test_whole_pair_against_the_libm_exp_oracle(ctx):
     """The honest statement of DisparityRefine parity.  Against the oracle with the SPECIFIED exp the HIP path is
     bit-identical (every other test).  The reference itself calls its C runtime's exp (.cpp:665-666); run the oracle
-    that way (host libm) and the chaotic iteration turns one-ulp differences of exp into visible ones for a small
-    fraction of the pixels.  What holds, and is asserted: the NOMATCH sets and the point count are identical,
-    >= 99.9 % of the pixels agree within north_star's 1e-3 relative, none is off by more than 2e-2."""
+    that way (the host libm's exp() call) on the adversarial 5-level occluded pair on which rounds 1-4 had 7 pixels
+    beyond 1e-3 (their exp was a 1-ulp-grade Taylor chain).  With the libm-grade specified exp north_star's bar holds
+    AS STATED: identical NOMATCH sets and point count, no pixel above 1e-3 -- and on a glibc / FMA host, whose exp the
+    specification restates, every bit of both maps and of the cloud is equal."""
     cfg, rec, fin = stages("s512x384_5levels")
     res = ctx.match_pair(cfg)
     orc.set_exp_mode(1)
@@ -380,10 +393,12 @@ def test_whole_pair_against_the_libm_exp_oracle(ctx):
     st = libm_exp_stats(res.disparity, ref["disparity"])
     print("5-level 512x384 vs libm-exp oracle:", st)
     for s_ in st:
-        assert s_["nomatch_mismatch"] == 0
-        assert s_["above_1e3"] <= 1e-3 * s_["valid"]
-        assert s_["max_rel"] < 2e-2
+        assert s_["nomatch_mismatch"] == 0 and s_["above_1e3"] == 0 and s_["max_rel"] < 1e-4, s_
     assert res.n_points == ref["n_points"]
+    if host_libm_is_glibc_with_fma():
+        for v in range(2):
+            assert np.array_equal(res.disparity[v], ref["disparity"][v])
+        assert np.array_equal(res.xyz, ref["xyz"], equal_nan=True)
 
 
 @pytest.mark.parametrize("span", [(1, 1000), (2, 5), (4, 48), (30, 31)])

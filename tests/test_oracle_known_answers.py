@@ -6,7 +6,7 @@ import pytest
 from oracle import oracle as orc
 from reconstruction_amd import synth
 
-from helpers import NOMATCH, oracle_stages
+from helpers import NOMATCH, host_libm_is_glibc_with_fma, oracle_stages
 
 
 def test_ncc_of_identical_windows_is_one_and_flat_is_zero():
@@ -171,14 +171,19 @@ def test_specified_exp_is_a_faithful_exp():
 
 def exp_test_arguments():
     """Arguments of the specified exp: dense over [0, 2], the whole range up to and beyond the underflow threshold, the
-    k switch points n * ln2 / 2 and their neighbours, the subnormal results (t in [708.4, 745.14]), tiny and huge t."""
+    k switch points n * ln2 / 256 (table index changes) and n * ln2 / 2 with their neighbours, the 512 / 1024 limits of the
+    special-case path, the subnormal results (t in [708.4, 745.14]), tiny and huge t."""
     rng = np.random.default_rng(7)
     ln2 = float(np.log(2.0))
     sw = np.arange(1, 2200) * (ln2 / 2)
+    sw2 = (np.arange(1, 140000) + 0.5) * (ln2 / 128)     # where round-to-nearest switches the table index, up to t = 758
+    edge = np.array([512.0, 1024.0, 708.3964185322641, 745.1332191019411])
     return np.concatenate([rng.random(200000) * 2, rng.random(100000) * 40, rng.random(100000) * 800, 708.0 + rng.random(100000) * 38,
+                           505.0 + rng.random(50000) * 14, 1000.0 + rng.random(20000) * 50,
                            10.0 ** rng.uniform(-300, 0, 20000), 10.0 ** rng.uniform(0, 300, 2000), np.arange(0, 800, 0.25),
-                           sw, np.nextafter(sw, 0), np.nextafter(sw, 1e9),
-                           [0.0, 5e-324, 1e-9, 0.34657359027997264, 0.3465735902799727, 708.3, 709.0, 710.0, 745.0, 745.13,
+                           sw, np.nextafter(sw, 0), np.nextafter(sw, 1e9), sw2, np.nextafter(sw2, 0), np.nextafter(sw2, 1e9),
+                           edge, np.nextafter(edge, 0), np.nextafter(edge, 1e9),
+                           [0.0, 5e-324, 1e-9, 2.0 ** -54, 2.0 ** -53, 0.34657359027997264, 0.3465735902799727, 708.3, 709.0, 710.0, 745.0, 745.13,
                             745.13321910194110842, 745.1332191019412, 745.2, 1e19, 1e300, np.inf]])
 
 
@@ -189,5 +194,56 @@ def test_specified_exp_does_not_depend_on_the_fma_implementation():
     a, b = orc.exp_neg_array(t), orc.exp_neg_array(t, soft_fma=True)
     assert np.array_equal(a.view(np.int64), b.view(np.int64))
     assert a[np.isinf(t)].tolist() == [0.0] and (a >= 0).all() and (a <= 1).all()
+    assert a[t >= 1024.0].max() == 0.0 and a[t == 0.0].min() == 1.0
     ulp = np.abs(a.view(np.int64) - np.exp(-t).view(np.int64))
     assert ulp.max() <= 1, ulp.max()
+
+
+def test_specified_exp_is_the_host_libms_exp():
+    """The pin of DisparityRefine's one libm call (CStereoMatching.cpp:665-666).  The specification restates glibc 2.35's
+    published exp algorithm in the operation order of its FMA build, so on such a host (this image; the GPU box) orc_exp_neg
+    and the C runtime's exp() agree in EVERY bit -- over the weights' range, the table-index switch points, the special-case
+    range [512, 1024), the subnormal results and beyond.  Elsewhere (another libm, no FMA: glibc then runs the same algorithm
+    with separate multiplies and adds) it is held to libm grade: within 1 ulp, last-bit disagreement <= 0.3 %.  A second,
+    independent libm-grade exp (expl rounded to double, i.e. nearly correctly rounded) disagrees in < 0.1 % of the arguments."""
+    rng = np.random.default_rng(3)
+    t = np.concatenate([exp_test_arguments(), rng.random(3000000) * 30, rng.random(1000000) * 1100,
+                        10.0 ** rng.uniform(-320, 3, 500000), 700.0 + rng.random(1000000) * 50])
+    spec = orc.exp_neg_array(t)
+    try:
+        orc.set_exp_mode(1)
+        libm = orc.exp_neg_array(t)
+        orc.set_exp_mode(2)
+        expl = orc.exp_neg_array(t)
+    finally:
+        orc.set_exp_mode(0)
+    d_libm = spec.view(np.int64) != libm.view(np.int64)
+    d_expl = spec.view(np.int64) != expl.view(np.int64)
+    print("specified exp vs host libm exp: %d of %d differ; vs expl rounded: %d (%.4f %%)" % (d_libm.sum(), t.size, d_expl.sum(), 100 * d_expl.mean()))
+    if host_libm_is_glibc_with_fma():
+        assert d_libm.sum() == 0, t[d_libm][:10]
+    else:
+        assert d_libm.mean() <= 3e-3 and np.abs(spec.view(np.int64) - libm.view(np.int64)).max() <= 1
+    assert d_expl.mean() < 1e-3 and np.abs(spec.view(np.int64) - expl.view(np.int64)).max() <= 1
+
+
+def test_exp_table_is_derived_from_first_principles():
+    """Both generated copies of the 128-entry table (oracle/exp_table.h, csrc/exp_table.h) are 2^(j/128) split as
+    H (1 + T) -- re-derived here with 200-bit arithmetic, not copied from a libm."""
+    import os
+    import re
+    import struct
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    want = []
+    for j in range(128):
+        ex = mp.power(2, mp.mpf(j) / 128)
+        H = float(ex)
+        T = float((ex - mp.mpf(H)) / mp.mpf(H))
+        assert abs(T) < 2.0 ** -53 and 1.0 <= H < 2.0
+        want += [struct.unpack("<Q", struct.pack("<d", T))[0], struct.unpack("<Q", struct.pack("<d", H))[0] - (j << 45)]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel in ("oracle/exp_table.h", "reconstruction_amd/csrc/exp_table.h"):
+        with open(os.path.join(root, rel)) as f:
+            got = [int(v, 16) for v in re.findall(r"0x([0-9a-f]{16})ull", f.read())]
+        assert got == want, rel
