@@ -412,8 +412,14 @@ def main():
             # the drop-in as a maintainer integrates it: the compiled C++ adapter's MatchAll (include/rsm_stereo_adapter.hpp),
             # host images in, InsertPoint stream out, PCIe included -- never `value`
             try:
-                out["adapter"] = adapter_bench(cfgs, args.adapter_pairs, args.adapter_inflight if args.adapter_inflight > 0 else F + 2, int(res.v_top))
-                out["value_adapter_pcie_inclusive"] = out["adapter"]["value"]
+                ab = adapter_bench(cfgs, args.adapter_pairs, args.adapter_inflight if args.adapter_inflight > 0 else F + 2, int(res.v_top))
+                out["adapter"] = ab["records16"]
+                out["value_adapter_pcie_inclusive"] = ab["records16"]["value"]
+                # the same loop with CCloudOptimization::filter's first half (CCloudOptimization.cpp:82-121, once per pair inside
+                # MatchAllLayer, CStereoMatching.cpp:31) on the pair's GPU, inside the loop: MatchAllFiltered
+                out["adapter_with_filter"] = ab["gpu_filter"]
+                out["value_with_filter"] = ab["gpu_filter"]["value"]
+                out["adapter_fp64_points"] = ab["fp64"]
             except Exception as e:  # noqa: BLE001
                 out["adapter"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and not args.no_cpu_baseline:
@@ -584,16 +590,26 @@ def adapter_bench(cfgs, n_pairs, inflight, v_top):
                 for a in (c.image[0], c.image[1], c.mask[0], c.mask[1]):
                     f.write(np.ascontiguousarray(a, np.uint8).tobytes())
         env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-        r = subprocess.run([exe, os.path.join(tmp, "in.bin"), str(n_pairs), str(inflight)], capture_output=True, text=True, env=env, timeout=300)
-        if r.returncode != 0:
-            raise RuntimeError("adapter_bench rc %d: %s" % (r.returncode, r.stderr[-200:]))
-        d = json.loads(r.stdout.strip().splitlines()[-1])
-        d["value"] = round(n_pairs * v_top / d["seconds"] / 1e6, 3)
-        d["ms_per_pair"] = round(d["seconds"] / n_pairs * 1e3, 3)
-        d["what"] = ("RsmStereoAdapter::MatchAll compiled from include/rsm_stereo_adapter.hpp: %d pairs, %d in flight, pageable host images "
-                     "in, page-locked fp64 clouds out, InsertPoint (float xyz push_back) per point and filter(pair) replayed in pair order; "
-                     "fp64 disparity maps not downloaded (the reference never reads them after CStereoMatching.cpp:29)" % (n_pairs, inflight))
-        return d
+        what = {"records16": "RsmStereoAdapter::MatchAll compiled from include/rsm_stereo_adapter.hpp: %d pairs, %d in flight, pageable host images in, "
+                             "the cloud as 16-byte records (InsertPoint's float xyz + BGR, packed on the GPU) into page-locked buffers, InsertPoint "
+                             "((double)float -> float push_back) per point and filter(pair) replayed in pair order; fp64 disparity maps not "
+                             "downloaded (the reference never reads them after CStereoMatching.cpp:29)",
+                "fp64": "the same with fp64 xyz + BGR (27 B per point) over PCIe: round 4's form (6 pairs)",
+                "gpu_filter": "RsmStereoAdapter::MatchAllFiltered: %d pairs, %d in flight; after each pair's match its GPU runs the first half of "
+                              "CCloudOptimization::filter (StatisticalOutlierRemoval k = 100 / 1 sigma, radius-2.5 normals, the turn toward CamCenter: "
+                              "CCloudOptimization.cpp:82-121) while the other slots' pairs are matched; the surviving points (16-byte records) and their "
+                              "normals come down instead of the raw cloud and are copied out per pair"}
+        res = {}
+        for key, flags, n in (("records16", 0, n_pairs), ("gpu_filter", 2, n_pairs), ("fp64", 1, min(n_pairs, 6))):
+            r = subprocess.run([exe, os.path.join(tmp, "in.bin"), str(n), str(inflight), "0", str(flags), "1"], capture_output=True, text=True, env=env, timeout=300)
+            if r.returncode != 0:
+                raise RuntimeError("adapter_bench (%s) rc %d: %s" % (key, r.returncode, r.stderr[-200:]))
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            d["value"] = round(n * v_top / d["seconds"] / 1e6, 3)
+            d["ms_per_pair"] = round(d["seconds"] / n * 1e3, 3)
+            d["what"] = what[key] % (n, inflight) if "%d" in what[key] else what[key]
+            res[key] = d
+        return res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -10,7 +10,9 @@
 //   ...
 //   void CStereoMatching::MatchAllLayer()         // the whole loop, .cpp:15-34, three pairs in flight on GPU 0
 //   {
-//       static RsmStereoMI355 gpu(0, 3);          // one per process and GPU
+//       static RsmStereoMI355 gpu(0, 3);          // one per process
+//       // -- or, on a node with several MI355X: three pairs in flight on EACH visible GPU, pair p on GPU p % n --
+//       // static RsmStereoMI355 gpu(RsmStereoMI355::AllDevices(), 3);
 //       // Rectify is private (CStereoMatching.h:49-50): a lambda written inside this member function may call it
 //       RsmCvTraits::rectify() = [](CStereoMatching &s, int CamPair) { s.Rectify(CamPair, s.Q); };   // .cpp:20
 //       std::vector<int> status(m_data->m_CampairNum);
@@ -85,6 +87,22 @@ struct RsmCvTraits {
 #else
         (void)s; (void)pair;
 #endif
+    }
+    // MatchAllFiltered (the first half of CCloudOptimization::filter on the GPU): the viewpoint the normals are turned toward,
+    // cam[pair][0].CamCenter (CV_32FC1 3x1, CManageData.cpp:61-62; CCloudOptimization.cpp:51,114-121) ...
+    static void cam_center(Stereo &s, int pair, float c[3]) {
+        const cv::Mat &m = s.m_data->cam[pair][0].CamCenter;
+        for (int i = 0; i < 3; i++) c[i] = (m.type() == CV_32FC1 && m.total() >= 3) ? m.at<float>(i) : 0.0f;
+    }
+    // ... and where the pair's filtered cloud goes: the reference's `cloud_normal` (CCloudOptimization.cpp:110-121) is a local
+    // of filter(); a pipeline that adopts the GPU filter installs the function that takes it over from there (:123 onwards)
+    typedef void (*FilteredFn)(Stereo &, int pair, const rsm_point16 *points, const float *normals4, int64_t n_kept, int64_t n_raw);
+    static FilteredFn &filtered_sink() {
+        static FilteredFn fn = 0;
+        return fn;
+    }
+    static void filtered_cloud(Stereo &s, int pair, const rsm_point16 *points, const float *normals4, int64_t n_kept, int64_t n_raw) {
+        if (filtered_sink()) filtered_sink()(s, pair, points, normals4, n_kept, n_raw);
     }
 };
 

@@ -74,6 +74,10 @@ typedef struct rsm_pair_out {
     double *xyz;            /* 3*max_points fp64: R_final*X + T_final, InsertPoint order     */
     uint8_t *bgr;           /* 3*max_points: colour of imagePyrm[top][0] (.cpp:756)          */
     int64_t v_top;          /* masked view-0 pixels inside margin[0] at the top level        */
+    struct rsm_point16 *points16; /* max_points 16-byte records {float x, y, z; u8 b, g, r, pad}: the cloud as
+                             * CCloudOptimization::InsertPoint keeps it (the fp64 point cast to float,
+                             * CloudOptimization/CCloudOptimization.cpp:61) + the colour, packed on the GPU --
+                             * 16 instead of 27 bytes per point over PCIe; NULL skips it (xyz / bgr likewise)  */
 } rsm_pair_out;
 
 typedef struct rsm_ctx rsm_ctx;
@@ -83,6 +87,8 @@ int rsm_create(rsm_ctx **ctx, int hip_device);
 void rsm_destroy(rsm_ctx *ctx);
 const char *rsm_last_error(const rsm_ctx *ctx);
 const char *rsm_version(void);
+/* GPUs visible to this process (hipGetDeviceCount; 0 when there is none or no HIP runtime) */
+int rsm_device_count(void);
 
 /* ---- one pair: host buffers in, host buffers out (replaces the loop body .cpp:20-31) ----- */
 int rsm_match_pair(rsm_ctx *ctx, const rsm_pair_in *in, rsm_pair_out *out);
@@ -290,6 +296,11 @@ int rsm_stage_exp_neg_small(rsm_ctx *ctx, const double *t, int64_t n, double *ou
  * the hardware's fp64 division sequence without its operand-scaling and fix-up steps -- beside the compiler's a / b, on n operand
  * pairs: the parity tests hold the two equal bit for bit over the operand range the kernel's guard admits */
 int rsm_stage_div_unscaled(rsm_ctx *ctx, const double *a, const double *b, int64_t n, double *q_fast, double *q_ieee);
+/* DisparityRefine's matching costs xi = (1 - arma::dot(vecL, vecR) / (normL * normR)) / 2 (CStereoMatching.cpp:624-629) of 3x3x3
+ * windows, as the device restatements of the data term compute them (form 0: the first sweep's, 1: a lane per cache miss, 2: four
+ * lanes per cache miss): out[c][((y-1) (W-2) + (x-1)) (W-2) + col] = xi(own column x, row y, other view's window left edge col + c),
+ * c = 0..2, y in [1, H-1), x in [1, W-1), col in [0, W-3]; out holds 3 (H-2) (W-2)^2 doubles.  BGR images, W x H x 3. */
+int rsm_stage_refine_xi(rsm_ctx *ctx, const uint8_t *img_own, const uint8_t *img_oth, int W, int H, int form, double *out);
 int rsm_stage_cloud(rsm_ctx *ctx, const double *disp, const uint8_t *mask_org, const uint8_t *img_own,
                     int W, int H, const double *Q, double scale, const double *R_final,
                     const double *T_final, const rsm_boundary *own, double *xyz, uint8_t *bgr,
@@ -335,6 +346,8 @@ int rsm_stage_erode_gray(rsm_ctx *ctx, const uint8_t *src, int W, int H, int ksi
  * records): binary_little_endian, per vertex float x,y,z (the fp64 point cast to float, .cpp:754) and uchar
  * blue,green,red.  Host-only (no GPU needed). Returns 0 or RSM_E_INVALID. */
 int rsm_write_ply(const char *path, const double *xyz, const uint8_t *bgr, int64_t n_points);
+/* the same file from 16-byte records (rsm_pair_out.points16: float xyz + BGR = one PLY vertex each) */
+int rsm_write_ply16(const char *path, const struct rsm_point16 *points, int64_t n_points);
 
 /* ---- per-pair cloud filter (CCloudOptimization::filter, CloudOptimization/CCloudOptimization.cpp:82-121) -- */
 typedef struct rsm_filter_params {
@@ -354,6 +367,11 @@ int rsm_filter_cloud(rsm_ctx *ctx, const float *xyz, int64_t n, const rsm_filter
  * in caller-owned DEVICE buffers of capacity max_points. */
 int rsm_filter_last_cloud(rsm_ctx *ctx, const rsm_filter_params *params, rsm_point16 *d_points, float *d_normals,
                           int64_t max_points, int64_t *n_kept, double *stats);
+/* The same with HOST output buffers (page-locked ones from rsm_host_alloc arrive at the link's rate): what a pipeline that
+ * replaces the first half of CCloudOptimization::filter (CCloudOptimization.cpp:82-121) downloads instead of the raw cloud --
+ * the surviving points and their oriented normals (the reference's cloud_normal, :110-121).  h_normals may be NULL. */
+int rsm_filter_last_cloud_host(rsm_ctx *ctx, const rsm_filter_params *params, rsm_point16 *h_points, float *h_normals,
+                               int64_t max_points, int64_t *n_kept, double *stats);
 
 /* ---- kernel microbenchmark (MDE/s: pixel x candidate NCC evaluations) -------------------- */
 /* Runs the NCC interval-argmax kernel `iters` times on a resident level-sized problem with

@@ -351,6 +351,16 @@ def exp_neg(t: float) -> float:
     return float(L.orc_exp_neg(float(t)))
 
 
+def refine_xi_table(img_own, img_oth) -> np.ndarray:
+    """DisparityRefine's matching cost xi (CStereoMatching.cpp:624-629) for every row y in [1, H-1), own column x in
+    [1, W-1) and other-view window left edge col in [0, W-3]: array [H-2, W-2, W-2]."""
+    img_own, img_oth = _u8(img_own), _u8(img_oth)
+    H, W = img_own.shape[:2]
+    out = np.zeros((H - 2, W - 2, W - 2), np.float64)
+    lib().orc_refine_xi_table(_p(img_own), _p(img_oth), W, H, _p(out))
+    return out
+
+
 def exp_neg_array(t, soft_fma: bool = False) -> np.ndarray:
     """orc_exp_neg over an array; soft_fma forces the C library's fma() instead of the CPU instruction."""
     L = lib()

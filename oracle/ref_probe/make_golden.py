@@ -87,7 +87,43 @@ def build_inputs():
             a["uq_p_%d" % i], a["uq_q_%d" % i] = p, q
         a["uq_margins_%d" % i] = np.array(own + oth, np.int32)
     build_inputs_round3(a)
+    build_inputs_round5(a)
     return a
+
+
+def build_inputs_round5(a):
+    """Round 5: DisparityRefine's data term (.cpp:624-629) -- 3x3x3 windows of whole rows, every (own column, right-window
+    left edge) pair: 8-bit noise, a band-limited texture with its shifted + noisy partner (what the bench data look like),
+    two- and three-level textures (equal costs reached through different summation orders), flat and saturated regions
+    (norm 0 -> 1 on either side, on both)."""
+    rng = np.random.default_rng(20261001)
+    kinds = ["random", "smooth_shifted", "two_level", "three_level", "flat_regions", "saturated"]
+    for i, kind in enumerate(kinds):
+        Hh, Ww = 6, 64
+        if kind == "random":
+            A = rng.integers(0, 256, (Hh, Ww, 3))
+            B = rng.integers(0, 256, (Hh, Ww, 3))
+        elif kind == "smooth_shifted":
+            base = rng.integers(0, 256, (Hh + 4, Ww + 12, 3)).astype(np.float64)
+            for _ in range(2):
+                base = (base[:, :-4] + 4 * base[:, 1:-3] + 6 * base[:, 2:-2] + 4 * base[:, 3:-1] + base[:, 4:]) / 16
+                base = (base[:-2] + 2 * base[1:-1] + base[2:]) / 4
+            A = np.round(base[:Hh, :Ww])
+            B = np.round(base[:Hh, 3:Ww + 3]) + rng.integers(-2, 3, (Hh, Ww, 3))
+        elif kind == "two_level":
+            A = rng.choice([0, 255], (Hh, Ww, 1)).repeat(3, 2)
+            B = rng.choice([0, 255], (Hh, Ww, 1)).repeat(3, 2)
+        elif kind == "three_level":
+            A = rng.choice([10, 100, 250], (Hh, Ww, 3))
+            B = np.where(rng.random((Hh, Ww, 3)) < 0.7, np.roll(A, 2, axis=1), rng.choice([10, 100, 250], (Hh, Ww, 3)))
+        elif kind == "flat_regions":
+            A = rng.integers(0, 256, (Hh, Ww, 3)); A[:, 10:20] = 93; A[:, 40:44] = 0
+            B = rng.integers(0, 256, (Hh, Ww, 3)); B[:, 15:30] = 93; B[:, 50:] = 255
+        else:
+            A = rng.integers(200, 300, (Hh, Ww, 3))
+            B = rng.integers(-40, 60, (Hh, Ww, 3))
+        a["xi_imgA_%d" % i] = np.clip(A, 0, 255).astype(np.uint8)
+        a["xi_imgB_%d" % i] = np.clip(B, 0, 255).astype(np.uint8)
 
 
 def build_inputs_round3(a):

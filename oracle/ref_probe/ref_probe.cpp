@@ -208,6 +208,37 @@ int main(int argc, char **argv) {
         }
         snprintf(key, sizeof key, "ncc_scores_%d", i); out[key] = sc;
     }
+    // ---- DisparityRefine's data term (.cpp:624-629), evaluated with the reference's own WindowToVec and Armadillo exactly as
+    //      the call site does: normL = WindowToVec(window_ptrL, x-1, 3, vecL); normR = WindowToVec(window_ptrR, iMatch+i, 3, vecR);
+    //      xi = (1 - arma::dot(vecL, vecR) / (normL * normR)) / 2.  Output: for every row y in [1, H-1), own column x in
+    //      [1, W-1) and right-window left edge col in [0, W-3] the matching cost.
+    for (int i = 0;; i++) {
+        snprintf(key, sizeof key, "xi_imgA_%d", i);
+        if (!in.count(key)) break;
+        Arr &A = in[key];
+        snprintf(key, sizeof key, "xi_imgB_%d", i);
+        Arr &B = in[key];
+        const int H = (int)A.dims[0], W = (int)A.dims[1];
+        Arr tb = make(3, {H - 2, W - 2, W - 2});
+        for (int y = 1; y < H - 1; y++) {
+            uchar *window_ptrL[3], *window_ptrR[3];
+            for (int k = -1; k <= 1; k++) {
+                window_ptrL[k + 1] = A.p<uchar>() + (size_t)(y + k) * W * 3;
+                window_ptrR[k + 1] = B.p<uchar>() + (size_t)(y + k) * W * 3;
+            }
+            for (int x = 1; x < W - 1; x++) {
+                arma::vec vecL(27), vecR(27);
+                double normL = data.WindowToVec(window_ptrL, x - 1, 3, vecL);
+                for (int col = 0; col <= W - 3; col++) {
+                    double normR = data.WindowToVec(window_ptrR, col, 3, vecR);
+                    double xi = (1 - arma::dot(vecL, vecR) / (normL * normR)) / 2;
+                    tb.p<double>()[((size_t)(y - 1) * (W - 2) + (x - 1)) * (W - 2) + col] = xi;
+                }
+            }
+        }
+        snprintf(key, sizeof key, "xi_table_%d", i); out[key] = tb;
+    }
+    fprintf(stderr, "probe: refine data term done\n");
     write_blob(argv[2], out);
     printf("ref_probe: %zu outputs\n", out.size());
     return 0;

@@ -880,6 +880,27 @@ void orc_median_filter(int16_t *disp, const uint8_t *mask, int W, int H,
 /* DisparityRefine, CStereoMatching.cpp:572-680                        */
 /* ------------------------------------------------------------------ */
 #define SQUARE_(x) ((x) * (x))
+/* The matching cost of DisparityRefine's data term, CStereoMatching.cpp:624-629: 3x3x3 windows, left edge of the own
+ * window x - 1, of the other view's window `col` (= iMatch + i), rows y-1..y+1; normL / vecL come from the caller
+ * (computed once per pixel, :624).  PINNED: tests/golden/ref_probe_golden.npz holds the reference's own
+ * (1 - arma::dot(vecL, vecR) / (normL * normR)) / 2 for every (x, col) of whole rows (oracle/ref_probe/ref_probe.cpp). */
+static double refine_xi(const double *vecL, double normL, const uint8_t *img_oth, long total, int W, int y, int col) {
+    double vecR[27];
+    const double normR = window_to_vec_flat(img_oth, total, (long)W * 3, y - 1, col, 3, vecR);
+    return (1 - orc_arma_dot(vecL, vecR, 27) / (normL * normR)) / 2;
+}
+/* test entry: xi for every row y in [1, H-1), own column x in [1, W-1) and other-view left edge col in [0, W-3]:
+ * out[((y-1) * (W-2) + (x-1)) * (W-2) + col] */
+void orc_refine_xi_table(const uint8_t *img_own, const uint8_t *img_oth, int W, int H, double *out) {
+    const long total = (long)W * H * 3;
+    for (int y = 1; y < H - 1; y++)
+        for (int x = 1; x < W - 1; x++) {
+            double vecL[27];
+            const double normL = window_to_vec_flat(img_own, total, (long)W * 3, y - 1, x - 1, 3, vecL);
+            for (int col = 0; col <= W - 3; col++)
+                out[((long)(y - 1) * (W - 2) + (x - 1)) * (W - 2) + col] = refine_xi(vecL, normL, img_oth, total, W, y, col);
+        }
+}
 void orc_disparity_refine(const int16_t *disp_in, double *disp_out_final,
                           const uint8_t *img_own, const uint8_t *img_oth,
                           int W, int H, int iterations, double ws,
@@ -898,7 +919,7 @@ void orc_disparity_refine(const int16_t *disp_in, double *disp_out_final,
             const double *pdis1 = out + (long)y * W;
             const double *pdis2 = out + (long)(y + 1) * W;
             double *pcur = cur + (long)y * W;
-            double vecL[27], vecR[27];
+            double vecL[27];
             double xi[3];
             double pdp = 0, pwp = 0;
             for (int x = XL + 1; x <= XR - 1; x++) {
@@ -913,10 +934,7 @@ void orc_disparity_refine(const int16_t *disp_in, double *disp_out_final,
                 if (mode != 0) {
                     const double normL = window_to_vec_flat(img_own, total, (long)W * 3, y - 1, x - 1, 3, vecL);
                     const int iMatch = (int)(dCenter - 1.5) + x; /* :625 */
-                    for (int i = 0; i < 3; i++) {
-                        const double normR = window_to_vec_flat(img_oth, total, (long)W * 3, y - 1, iMatch + i, 3, vecR);
-                        xi[i] = (1 - orc_arma_dot(vecL, vecR, 27) / (normL * normR)) / 2;
-                    }
+                    for (int i = 0; i < 3; i++) xi[i] = refine_xi(vecL, normL, img_oth, total, W, y, iMatch + i); /* :626-629 */
                     int index = xi[0] >= xi[1];
                     if (xi[index] > xi[2]) index = 2;
                     switch (index) {

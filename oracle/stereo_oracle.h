@@ -147,6 +147,8 @@ double orc_exp_neg(double t);
 void orc_set_exp_mode(int mode); /* 0 specified, 1 host libm exp, 2 host expl rounded, 3 rounds 3-4's Taylor chain (control) */
 void orc_set_exp_soft_fma(int soft); /* 1: evaluate fma() through the C library even where the CPU has the instruction */
 void orc_exp_neg_array(const double *t, long long n, double *out);
+/* DisparityRefine's matching cost xi (CStereoMatching.cpp:624-629) for every (row, own column, other-view left edge) of a small image pair */
+void orc_refine_xi_table(const uint8_t *img_own, const uint8_t *img_oth, int W, int H, double *out);
 
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

@@ -50,7 +50,7 @@ class PairIn(C.Structure):
 class PairOut(C.Structure):
     _fields_ = [("disparity", C.c_void_p * 2), ("margin", Boundary * 2),
                 ("n_points", C.c_int64), ("max_points", C.c_int64),
-                ("xyz", C.c_void_p), ("bgr", C.c_void_p), ("v_top", C.c_int64)]
+                ("xyz", C.c_void_p), ("bgr", C.c_void_p), ("v_top", C.c_int64), ("points16", C.c_void_p)]
 
 
 class FilterParams(C.Structure):
@@ -72,13 +72,13 @@ class RectifyOut(C.Structure):
 
 # every symbol include/rsm.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
-    "rsm_create", "rsm_destroy", "rsm_last_error", "rsm_version", "rsm_match_pair", "rsm_upload_pair",
+    "rsm_create", "rsm_destroy", "rsm_last_error", "rsm_version", "rsm_device_count", "rsm_filter_last_cloud_host", "rsm_match_pair", "rsm_upload_pair",
     "rsm_upload_pair_device", "rsm_run_pair", "rsm_download_pair", "rsm_result_device", "rsm_export_cloud_device",
     "rsm_set_option", "rsm_profile_enable", "rsm_profile_stage_count", "rsm_profile_stage_name", "rsm_profile_get",
     "rsm_stage_find_margin", "rsm_stage_pyr_down", "rsm_stage_erode_ellipse", "rsm_stage_initial_match",
     "rsm_stage_smooth", "rsm_stage_order", "rsm_stage_uniqueness_pass_s16", "rsm_stage_uniqueness_pass_f64",
-    "rsm_stage_set_boundary", "rsm_stage_rematch", "rsm_stage_median", "rsm_stage_refine", "rsm_stage_exp_neg", "rsm_stage_exp_neg_small", "rsm_stage_div_unscaled", "rsm_stage_cloud",
-    "rsm_bench_ncc", "rsm_write_ply", "rsm_rectify_pair", "rsm_stereo_rectify", "rsm_stage_rect_map",
+    "rsm_stage_set_boundary", "rsm_stage_rematch", "rsm_stage_median", "rsm_stage_refine", "rsm_stage_exp_neg", "rsm_stage_exp_neg_small", "rsm_stage_div_unscaled", "rsm_stage_refine_xi", "rsm_stage_cloud",
+    "rsm_bench_ncc", "rsm_write_ply", "rsm_write_ply16", "rsm_rectify_pair", "rsm_stereo_rectify", "rsm_stage_rect_map",
     "rsm_stage_remap", "rsm_stage_erode_gray", "rsm_run_pairs", "rsm_run_pairs_repeat", "rsm_match_pairs", "rsm_match_pairs_multi_gpu",
     "rsm_pack_cloud16", "rsm_comm_unique_id", "rsm_comm_create", "rsm_comm_destroy", "rsm_comm_last_error",
     "rsm_gather_clouds", "rsm_gather_counts", "rsm_gather_meta_fill", "rsm_gather_plan", "rsm_comm_create_transport",

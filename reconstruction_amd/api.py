@@ -301,6 +301,33 @@ class Context:
         return PairResult(disparity=d, margin=[pout.margin[0].astuple(), pout.margin[1].astuple()],
                           n_points=n, xyz=xyz, bgr=bgr, v_top=int(pout.v_top))
 
+    POINT16 = np.dtype([("x", np.float32), ("y", np.float32), ("z", np.float32), ("b", np.uint8), ("g", np.uint8), ("r", np.uint8), ("pad", np.uint8)])
+
+    def download_points16(self, pinned=False) -> np.ndarray:
+        """The last cloud as rsm_point16 records (float xyz = InsertPoint's cast, CCloudOptimization.cpp:61, + BGR), packed on
+        the GPU and downloaded through rsm_pair_out.points16: a structured array of n_points records."""
+        n = self.n_points
+        rec = (host_empty((max(n, 1),), self.POINT16) if pinned else np.zeros(max(n, 1), self.POINT16))
+        pout = PairOut()
+        pout.max_points = n
+        pout.points16 = rec.ctypes.data
+        self._chk(self._lib.rsm_download_pair(self._h, C.byref(pout)))
+        return rec[:n]
+
+    def filter_last_cloud_host(self, mean_k=100, std_mul=1.0, normal_radius=2.5, cam_center=(0.0, 0.0, 0.0), want_normals=True):
+        """rsm_filter_last_cloud_host: the per-pair filter on the GPU, its output -- the surviving points as rsm_point16 records
+        and their oriented normals (nx, ny, nz, curvature) -- downloaded.  Returns (records, normals or None, stats dict)."""
+        n = self.n_points
+        rec = np.zeros(max(n, 1), self.POINT16)
+        nrm = np.zeros((max(n, 1), 4), np.float32) if want_normals else None
+        m = C.c_int64()
+        st = (C.c_double * 4)()
+        prm = self._filter_params(mean_k, std_mul, normal_radius, cam_center)
+        self._chk(self._lib.rsm_filter_last_cloud_host(self._h, C.byref(prm), _p(rec), _p(nrm) if want_normals else None,
+                                                       C.c_int64(n), C.byref(m), st))
+        k = int(m.value)
+        return rec[:k], (nrm[:k] if want_normals else None), dict(mean=st[0], stddev=st[1], threshold=st[2], exhaustive=int(st[3]))
+
     def match_pair(self, cfg, want_cloud=True) -> PairResult:
         self.upload_pair(cfg)
         self.run_pair()
@@ -485,6 +512,15 @@ class Context:
         out = np.zeros(t.shape, np.float64)
         fn = self._lib.rsm_stage_exp_neg_small if small_form else self._lib.rsm_stage_exp_neg
         self._chk(fn(self._h, _p(t), C.c_int64(t.size), _p(out)))
+        return out
+
+    def refine_xi(self, img_own, img_oth, form: int = 0):
+        """DisparityRefine's matching costs xi (CStereoMatching.cpp:624-629) as the device computes them: array [3, H-2, W-2, W-2],
+        [c, y-1, x-1, col] = xi(x, y, col + c); form 0 / 1 / 2 = the first sweep's / lane-per-miss / four-lanes-per-miss routine."""
+        img_own, img_oth = _u8(img_own), _u8(img_oth)
+        H, W = img_own.shape[:2]
+        out = np.zeros((3, H - 2, W - 2, W - 2), np.float64)
+        self._chk(self._lib.rsm_stage_refine_xi(self._h, _p(img_own), _p(img_oth), W, H, int(form), _p(out)))
         return out
 
     def div_unscaled(self, a, b):

@@ -70,12 +70,31 @@ __device__ __forceinline__ double exp_neg_small(double t, ExpTab tab) {
     exp_core(-t, tab, tmp, s);
     return __builtin_fma(s, tmp, s);
 }
+// Two arguments at once, both table reads issued FIRST: they need only the first fma of each chain, and their LDS round
+// trip (the one latency of the routine that is not arithmetic) then runs beside the two reductions and polynomials
+// instead of in front of `r + tail` (the scheduler otherwise sinks a read below the reduction it does not depend on).
 __device__ __forceinline__ void exp_neg2_small(double t1, double t2, double &w1, double &w2, ExpTab tab) {
-    double tmp1, s1, tmp2, s2;
-    exp_core(-t1, tab, tmp1, s1);
-    exp_core(-t2, tab, tmp2, s2);
-    w1 = __builtin_fma(s1, tmp1, s1);
-    w2 = __builtin_fma(s2, tmp2, s2);
+    const double ka = __builtin_fma(-t1, EXP_INVLN2N, EXP_SHIFT), kb = __builtin_fma(-t2, EXP_INVLN2N, EXP_SHIFT);
+    const uint32_t kia = (uint32_t)__double2loint(ka), kib = (uint32_t)__double2loint(kb);
+    const double2 ea = tab[kia & 127u], eb = tab[kib & 127u];
+#ifndef RF_EXP_NO_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    const double kda = ka - EXP_SHIFT, kdb = kb - EXP_SHIFT;
+    double ra = __builtin_fma(kda, EXP_NEGLN2HIN, -t1), rb = __builtin_fma(kdb, EXP_NEGLN2HIN, -t2);
+    ra = __builtin_fma(kda, EXP_NEGLN2LON, ra);
+    rb = __builtin_fma(kdb, EXP_NEGLN2LON, rb);
+    const double ra2 = ra * ra, rb2 = rb * rb;
+    const double paa = __builtin_fma(ra, EXP_C3, EXP_C2), pab = __builtin_fma(rb, EXP_C3, EXP_C2);
+    const double pba = __builtin_fma(ra, EXP_C5, EXP_C4), pbb = __builtin_fma(rb, EXP_C5, EXP_C4);
+    const double ra4 = ra2 * ra2, rb4 = rb2 * rb2;
+    const double sa = __hiloint2double(__double2hiint(ea.y) + (int)(kia << 13), __double2loint(ea.y));
+    const double sb = __hiloint2double(__double2hiint(eb.y) + (int)(kib << 13), __double2loint(eb.y));
+    double ta = __builtin_fma(paa, ra2, ra + ea.x), tb = __builtin_fma(pab, rb2, rb + eb.x);
+    ta = __builtin_fma(ra4, pba, ta);
+    tb = __builtin_fma(rb4, pbb, tb);
+    w1 = __builtin_fma(sa, ta, sa);
+    w2 = __builtin_fma(sb, tb, sb);
 }
 
 // any t >= 0
@@ -449,7 +468,7 @@ __device__ __forceinline__ double refine_cost_left(const RfLeft &L, const uint32
 // combines.  Each value is produced by the same operation sequence as in refine_data_term_packed.
 __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
                                                       int W, int H, int x, int y, int key, int q, double &pwp,
-                                                      double &delta) {
+                                                      double &delta, double *xi_own = nullptr) {
     const long long npx = (long long)W * H;
     const int c = q > 0 ? q - 1 : 0;
     uint32_t aP[3][3], bP[3][3];
@@ -492,9 +511,46 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
     if (normL == 0) normL = 1;
     if (normR == 0) normR = 1;
     const double xi = (1 - (d1 + d2) / (normL * normR)) / 2; // .cpp:629
+    if (xi_own) *xi_own = xi; // (test entry: this lane's own matching cost)
     const int qb = (int)(threadIdx.x & 63) & ~3; // the quad's first lane
     const double x0 = __shfl(xi, qb + 1), x1 = __shfl(xi, qb + 2), x2 = __shfl(xi, qb + 3);
     refine_entry(x0, x1, x2, pwp, delta);
+}
+
+// test entry (rsm_stage_refine_xi): the matching costs xi (.cpp:624-629) as each of the three device restatements of the data
+// term computes them, for every row y in [1, H-1), own column x in [1, W-1) and other-view window left edge col in [0, W-3]:
+// out[c][entry] = xi(x, y, col + c), c = 0..2, entry = ((y-1) (W-2) + (x-1)) (W-2) + col.  form 0: refine_left + refine_cost_left
+// (k_refine_first), 1: refine_data_term_packed (the sweep kernels' lane-per-miss service), 2: refine_data_term_quad (four lanes
+// per miss: k_refine_sweep, k_refine_skew).
+__global__ void k_refine_xi(const uint32_t *A, const uint32_t *B, int W, int H, int form, double *out, long long n) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long e = form == 2 ? (tid >> 2) : tid;
+    const long long ec = e < n ? e : n - 1; // (whole quads stay active: the quad routine shuffles)
+    const int nw = W - 2;
+    const int col = (int)(ec % nw), x = 1 + (int)((ec / nw) % nw), y = 1 + (int)(ec / ((long long)nw * nw));
+    double xs[3] = {0.0, 0.0, 0.0};
+    if (form == 0) {
+        RfLeft L;
+        refine_left(A, W, x, y, L);
+        for (int c = 0; c < 3; c++) xs[c] = refine_cost_left(L, B, W, H, y, col + c);
+    } else if (form == 1) {
+        double p, q;
+        refine_data_term_packed(A, B, W, H, x, y, col, p, q, xs);
+    } else {
+        double p, q, own = 0.0;
+        refine_data_term_quad(A, B, W, H, x, y, col, (int)(tid & 3), p, q, &own);
+        const int qd = (int)(tid & 3);
+        if (e < n && qd >= 1) out[(long long)(qd - 1) * n + e] = own;
+        return;
+    }
+    if (e < n)
+        for (int c = 0; c < 3; c++) out[(long long)c * n + e] = xs[c];
+}
+void launch_refine_xi(const uint32_t *A, const uint32_t *B, int W, int H, int form, double *out, hipStream_t st) {
+    const long long n = (long long)(H - 2) * (W - 2) * (W - 2);
+    if (n <= 0) return;
+    const long long threads = form == 2 ? 4 * n : n;
+    hipLaunchKernelGGL(k_refine_xi, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, A, B, W, H, form, out, n);
 }
 
 // First sweep of a level: every cache entry is empty, so instead of a worklist the kernel walks the whole

@@ -111,6 +111,8 @@ struct rsm_ctx {
     double *d_q = nullptr, *d_R = nullptr, *d_T = nullptr;
     double *xyz = nullptr;
     uint8_t *bgr = nullptr;
+    rsm_point16 *pack16 = nullptr; // the cloud as 16-byte records / the filter's output, staged for a host download (on first use)
+    float *pack_nrm = nullptr;     // ... and the filter's normals
     FilterArena *filt_arena = nullptr; // the cloud filter's scratch (created on first use, grows with the cloud)
 
     // results
@@ -250,7 +252,11 @@ static void ellipse_spans(int k, std::vector<int> &j1, std::vector<int> &j2) {
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" const char *rsm_version(void) { return "rsm-mi355 0.1 (gfx950)"; }
+extern "C" const char *rsm_version(void) { return "rsm-mi355 0.2 (gfx950)"; }
+extern "C" int rsm_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
 
 extern "C" const char *rsm_last_error(const rsm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
@@ -292,6 +298,8 @@ static void free_workspace(rsm_ctx *c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (void *p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
+    c->pack16 = nullptr;
+    c->pack_nrm = nullptr;
     c->cap_px = 0;
     c->have_pair = c->have_result = false;
 }
@@ -1046,6 +1054,14 @@ extern "C" int rsm_download_pair(rsm_ctx *c, rsm_pair_out *out) {
     if (n > (int64_t)c->cap_px) n = (int64_t)c->cap_px;
     if (n > 0 && out->xyz) HIPCHK(c, hipMemcpyAsync(out->xyz, c->xyz, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (n > 0 && out->bgr) HIPCHK(c, hipMemcpyAsync(out->bgr, c->bgr, (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
+    if (n > 0 && out->points16) { // InsertPoint's float cast + the colour packed on the GPU: 16 instead of 27 bytes per point cross PCIe
+        if (!c->pack16) {
+            const int s = dalloc(c, &c->pack16, c->cap_px);
+            if (s != RSM_OK) return s;
+        }
+        launch_pack_cloud16(c->xyz, c->bgr, n, c->pack16, c->stream);
+        HIPCHK(c, hipMemcpyAsync(out->points16, c->pack16, (size_t)n * sizeof(rsm_point16), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RSM_OK;
 }
@@ -1057,7 +1073,7 @@ extern "C" int rsm_download_pair(rsm_ctx *c, rsm_pair_out *out) {
 // caller already owns can be page-locked in place (rsm_host_register).
 extern "C" void *rsm_host_alloc(size_t bytes) {
     void *p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr; // (every GPU of the node may DMA into it)
     return p;
 }
 extern "C" void rsm_host_free(void *p) {
@@ -1579,6 +1595,23 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     return finish(c, t);
 }
 
+// DisparityRefine's matching costs xi (CStereoMatching.cpp:624-629) as the device restatements of the data term compute them:
+// lets the parity tests hold them to the compiled reference's own values (tests/golden: xi_table_*), bit for bit.
+extern "C" int rsm_stage_refine_xi(rsm_ctx *c, const uint8_t *img_own, const uint8_t *img_oth, int W, int H, int form, double *out) {
+    if (!stage_ok(c, W, H) || !img_own || !img_oth || !out || W < 3 || H < 3 || form < 0 || form > 2) return RSM_E_INVALID;
+    Tmp t(c);
+    const size_t px = (size_t)W * H, n = (size_t)(H - 2) * (W - 2) * (W - 2);
+    const uint8_t *io = t.up(img_own, px * 3), *it = t.up(img_oth, px * 3);
+    uint32_t *i4o = t.alloc<uint32_t>(px), *i4t = t.alloc<uint32_t>(px);
+    double *dout = t.alloc<double>(3 * n);
+    if (!t.ok) return finish(c, t);
+    launch_bgr_to_bgrx(io, W, H, i4o, c->stream);
+    launch_bgr_to_bgrx(it, W, H, i4t, c->stream);
+    launch_refine_xi(i4o, i4t, W, H, form, dout, c->stream);
+    t.down(out, (const double *)dout, 3 * n);
+    return finish(c, t);
+}
+
 extern "C" int rsm_stage_cloud(rsm_ctx *c, const double *disp, const uint8_t *mask_org, const uint8_t *img_own, int W,
                                int H, const double *Q, double scale, const double *R_final, const double *T_final,
                                const rsm_boundary *own, double *xyz, uint8_t *bgr, int64_t max_points,
@@ -1829,6 +1862,31 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
     return finish(c, t);
 }
 
+extern "C" int rsm_filter_last_cloud_host(rsm_ctx *c, const rsm_filter_params *prm, rsm_point16 *h_points, float *h_normals,
+                                          int64_t max_points, int64_t *n_kept, double *stats) {
+    if (!c || !n_kept || !h_points || max_points < 0) return RSM_E_INVALID;
+    if (!c->have_result) return set_err(c, RSM_E_STATE, "no result");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->pack16) {
+        const int s = dalloc(c, &c->pack16, c->cap_px);
+        if (s != RSM_OK) return s;
+    }
+    if (h_normals && !c->pack_nrm) {
+        const int s = dalloc(c, &c->pack_nrm, c->cap_px * 4);
+        if (s != RSM_OK) return s;
+    }
+    const int64_t cap = (int64_t)c->cap_px < max_points ? (int64_t)c->cap_px : max_points;
+    const int s = rsm_filter_last_cloud(c, prm, c->pack16, h_normals ? c->pack_nrm : nullptr, cap, n_kept, stats);
+    if (s != RSM_OK) return s;
+    const size_t m = (size_t)*n_kept;
+    if (m > 0) {
+        HIPCHK(c, hipMemcpyAsync(h_points, c->pack16, m * sizeof(rsm_point16), hipMemcpyDeviceToHost, c->stream));
+        if (h_normals) HIPCHK(c, hipMemcpyAsync(h_normals, c->pack_nrm, m * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return RSM_OK;
+}
+
 // ---- PLY writer (CStereoMatching.cpp:723-729, 754-756) ----------------------------------------------
 extern "C" int rsm_write_ply(const char *path, const double *xyz, const uint8_t *bgr, int64_t n) {
     if (!path || n < 0 || (n > 0 && (!xyz || !bgr))) return RSM_E_INVALID;
@@ -1844,6 +1902,22 @@ extern "C" int rsm_write_ply(const char *path, const double *xyz, const uint8_t 
         fwrite(p, sizeof(float), 3, fp);
         fwrite(bgr + 3 * i, 1, 3, fp);
     }
+    const int ok = ferror(fp) == 0;
+    fclose(fp);
+    return ok ? RSM_OK : RSM_E_INVALID;
+}
+
+// the same file from the 16-byte records (float xyz + BGR are exactly a PLY vertex of this header)
+extern "C" int rsm_write_ply16(const char *path, const rsm_point16 *points, int64_t n) {
+    if (!path || n < 0 || (n > 0 && !points)) return RSM_E_INVALID;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return RSM_E_INVALID;
+    fprintf(fp, "ply\n");
+    fprintf(fp, "format binary_little_endian 1.0\n");
+    fprintf(fp, "element vertex %d\n", (int)n);
+    fprintf(fp, "property float x\nproperty float y\nproperty float z\nproperty uchar blue\nproperty uchar green\nproperty uchar red\n");
+    fprintf(fp, "end_header\n");
+    for (int64_t i = 0; i < n; i++) fwrite(&points[i], 1, 15, fp); // x, y, z, b, g, r (the pad byte stays behind)
     const int ok = ferror(fp) == 0;
     fclose(fp);
     return ok ? RSM_OK : RSM_E_INVALID;

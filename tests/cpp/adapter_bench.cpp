@@ -2,7 +2,10 @@
 // reconstruction/CStereoMatching.cpp:17-33) on the bench workload, PCIe included: host images in (pageable, as the
 // reference's cv::Mat), InsertPoint stream out.  Mock CStereoMatching / CManageData behind the traits, no OpenCV.
 // Built and run by bench.py (value_adapter_pcie_inclusive) and tests/test_gpu_cpp_adapter.py.
-//   adapter_bench <in.bin> <n_pairs_total> <pairs_in_flight> [want_disparity]
+//   adapter_bench <in.bin> <n_pairs_total> <pairs_in_flight> [want_disparity] [flags] [n_devices]
+//   flags (bit set): 1 fp64 points over PCIe (27 B per point; default: the 16-byte records); 2 MatchAllFiltered (the per-pair
+//   cloud filter on the GPU inside the loop, CCloudOptimization.cpp:82-121); n_devices: the first n visible GPUs, pairs_in_flight
+//   slots on each (default 1 = device 0; 0 = all)
 // in.bin: the format of mock_adapter.cpp; its pairs are cycled until n_pairs_total pairs have been matched.  One
 // untimed MatchAll over pairs_in_flight pairs first (contexts, workspaces, page-locked buffers), then the timed one.
 // stdout: one JSON line.
@@ -27,7 +30,7 @@ struct BStereo {
     std::vector<BPair> pairs; // the distinct inputs; pair p of the run uses pairs[p % size]
     std::vector<float> cloud; // what InsertPoint keeps: float xyz (CCloudOptimization.cpp:61); sized once, filled through `fill`
     size_t fill;
-    int64_t points, filters;
+    int64_t points, filters, kept;
 };
 struct BTraits {
     typedef BStereo Stereo;
@@ -60,6 +63,21 @@ struct BTraits {
         s.filters++;
         s.fill = 0; // (the reference's filter() consumes cloud_in and clears it, CCloudOptimization.cpp:84-121)
     }
+    static void cam_center(Stereo &, int, float c[3]) { c[0] = c[1] = c[2] = 0.0f; }
+    static void filtered_cloud(Stereo &s, int, const rsm_point16 *pts, const float *nrm, int64_t n_kept, int64_t n_raw) {
+        // the reference's cloud_normal (PointNormal: xyz + normal + curvature), CCloudOptimization.cpp:110-123: copied out of the
+        // page-locked buffers as `*cloud_normals += *cloud_normal` would
+        float *d = &s.cloud[0];
+        for (int64_t i = 0; i < n_kept; i++) {
+            d[0] = pts[i].x + nrm[4 * i];
+            d[1] = pts[i].y + nrm[4 * i + 1];
+            d[2] = pts[i].z + nrm[4 * i + 2];
+            d += 3;
+        }
+        s.points += n_raw;
+        s.kept += n_kept;
+        s.filters++;
+    }
 };
 
 template <typename T>
@@ -71,6 +89,8 @@ int main(int argc, char **argv) {
     if (!fi) return 2;
     const int n_total = atoi(argv[2]), inflight = atoi(argv[3]);
     const bool want_disp = argc > 4 && atoi(argv[4]) != 0;
+    const int flags = argc > 5 ? atoi(argv[5]) : 0;
+    int n_dev = argc > 6 ? atoi(argv[6]) : 1;
     int32_t hdr[9];
     BStereo s;
     if (!rd(fi, hdr, 9) || !rd(fi, &s.ws, 1)) return 2;
@@ -86,22 +106,31 @@ int main(int argc, char **argv) {
         for (int v = 0; v < 2; v++) { bp.msk[v].resize(px); if (!rd(fi, bp.msk[v].data(), px)) return 2; }
     }
     fclose(fi);
-    RsmStereoAdapter<BTraits> gpu(0, inflight);
+    std::vector<int> devs = RsmStereoAdapter<BTraits>::AllDevices();
+    if (devs.empty()) { fprintf(stderr, "no GPU\n"); return 3; }
+    if (n_dev > 0 && n_dev < (int)devs.size()) devs.resize((size_t)n_dev);
+    n_dev = (int)devs.size();
+    RsmStereoAdapter<BTraits> gpu(devs, inflight);
     if (!gpu.Ok()) { fprintf(stderr, "%s\n", gpu.LastError()); return 3; }
     gpu.want_disparity = want_disp;
+    gpu.fp64_points = (flags & 1) != 0;
+    const bool filtered = (flags & 2) != 0;
     s.cloud.assign(px * 3, 0.0f); // a cloud can hold a point per pixel
     s.fill = 0;
-    s.points = s.filters = 0;
-    { // warm-up: contexts, workspaces and page-locked buffers of every slot
+    s.points = s.filters = s.kept = 0;
+    { // warm-up: contexts, workspaces and page-locked buffers of every slot (the filter's arena too)
         BStereo w = s;
-        if (gpu.MatchAll(w, inflight) != inflight) { fprintf(stderr, "warm-up: %s\n", gpu.LastError()); return 4; }
+        const int nw = gpu.Slots();
+        if ((filtered ? gpu.MatchAllFiltered(w, nw) : gpu.MatchAll(w, nw)) != nw) { fprintf(stderr, "warm-up: %s\n", gpu.LastError()); return 4; }
     }
     std::vector<int> status((size_t)n_total, 0);
     const auto t0 = std::chrono::steady_clock::now();
-    const int ok = gpu.MatchAll(s, n_total, status.data());
+    const int ok = filtered ? gpu.MatchAllFiltered(s, n_total, status.data()) : gpu.MatchAll(s, n_total, status.data());
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (ok != n_total) { fprintf(stderr, "MatchAll: %d of %d pairs, %s\n", ok, n_total, gpu.LastError()); return 5; }
-    printf("{\"pairs\": %d, \"pairs_in_flight\": %d, \"seconds\": %.6f, \"points\": %lld, \"filters\": %lld, \"v_top_last\": %lld, \"want_disparity\": %d}\n",
-           n_total, inflight, dt, (long long)s.points, (long long)s.filters, (long long)gpu.LastVTop(), want_disp ? 1 : 0);
+    printf("{\"pairs\": %d, \"pairs_in_flight\": %d, \"devices\": %d, \"seconds\": %.6f, \"points\": %lld, \"kept\": %lld, \"filters\": %lld, \"v_top_last\": %lld, "
+           "\"want_disparity\": %d, \"fp64_points\": %d, \"gpu_filter\": %d, \"caller_submit_s\": %.4f, \"caller_wait_s\": %.4f, \"caller_replay_s\": %.4f}\n",
+           n_total, inflight, n_dev, dt, (long long)s.points, (long long)s.kept, (long long)s.filters, (long long)gpu.LastVTop(), want_disp ? 1 : 0, (flags & 1) ? 1 : 0,
+           filtered ? 1 : 0, gpu.LastSubmitSeconds(), gpu.LastWaitSeconds(), gpu.LastReplaySeconds());
     return 0;
 }

@@ -2,17 +2,23 @@
 // for real: mock stand-ins of CStereoMatching / CManageData behind a traits type, no OpenCV.  Built with g++ on the
 // GPU box by tests/test_gpu_cpp_adapter.py, linked against librsm_mi355.so.
 //   mock_adapter <in.bin> <out.bin>
-//   mock_adapter <in.bin> <out.bin> [mode]      mode 0: a MatchPair call per pair (default); N >= 1: ONE MatchAll call
-//                                               with N pairs in flight
+//   mock_adapter <in.bin> <out.bin> [mode] [flags]   mode 0: a MatchPair call per pair (default); N >= 1: ONE MatchAll call
+//                                               with N pairs in flight per device
+//   flags (bit set): 1 fp64_points (fp64 xyz + BGR cross PCIe instead of the 16-byte records); 2 MatchAllFiltered (the per-pair
+//   cloud filter on the GPU: out.bin then holds the kept records + normals instead of the InsertPoint stream); 4 the adapter
+//   is given the device list {0, 0} (two "GPUs", both ordinal 0: the several-devices code path on a one-GPU box); 8 the
+//   mock's filter() throws at the third pair of a first MatchAll, which must leave the adapter usable for the second one
 // in.bin : int32 n_pairs, W, H, levels, radius, offset, origin_w, isoutput, bad_pair; double ws;
 //          per pair: double Q[16], R[9], T[3]; u8 img0[WH3], img1[WH3], mask0[WH], mask1[WH]
 // out.bin: per pair: int32 ok, status; int32 margin[2][6]; int64 n_points (InsertPoint calls); int32 filter_arg;
 //          double xyz[n_points*3] as handed to InsertPoint; double disparity0[WH]
+//          (flags & 2: int64 n_kept, n_raw; rsm_point16 points[n_kept]; float normals[n_kept*4]; double disparity0[WH])
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <stdexcept>
 #include <vector>
 
 #include "rsm_stereo_adapter.hpp"
@@ -36,8 +42,12 @@ struct MockStereo { // the fields of CStereoMatching + CManageData the adapter t
         bool seen;
         std::vector<double> xyz, disp0;
         int filter_arg;
-        Got() : seen(false), filter_arg(-1) {}
+        std::vector<rsm_point16> kept; // MatchAllFiltered
+        std::vector<float> normals;
+        int64_t n_raw;
+        Got() : seen(false), filter_arg(-1), n_raw(0) {}
     };
+    int throw_at; // filter() throws at this pair (-1: never)
     std::vector<Got> got;
     const std::vector<double> *adapter_disp0; // the adapter's `disparity[0]`
     std::vector<int> prepared;                // order of the prepare (Rectify) calls
@@ -76,7 +86,19 @@ struct MockTraits {
         return true;
     }
     static void insert_point(Stereo &s, const double xyz[3]) { s.inserted.insert(s.inserted.end(), xyz, xyz + 3); }
+    static void cam_center(Stereo &, int pair, float c[3]) { c[0] = 10.0f * pair; c[1] = -5.0f; c[2] = 3.0f; }
+    static void filtered_cloud(Stereo &s, int pair, const rsm_point16 *pts, const float *nrm, int64_t n_kept, int64_t n_raw) {
+        s.filtered.push_back(pair);
+        MockStereo::Got &g = s.got[pair];
+        g.seen = true;
+        g.filter_arg = pair;
+        g.kept.assign(pts, pts + n_kept);
+        g.normals.assign(nrm, nrm + 4 * n_kept);
+        g.n_raw = n_raw;
+        if (s.adapter_disp0) g.disp0 = *s.adapter_disp0;
+    }
     static void filter(Stereo &s, int pair) {
+        if (pair == s.throw_at) throw std::runtime_error("mock filter failed");
         s.filtered.push_back(pair);
         MockStereo::Got &g = s.got[pair];
         g.seen = true;
@@ -117,15 +139,36 @@ int main(int argc, char **argv) {
     }
     fclose(fi);
     const int mode = argc > 3 ? atoi(argv[3]) : 0;
-    RsmStereoAdapter<MockTraits> gpu(0, mode > 0 ? mode : 1);
+    const int flags = argc > 4 ? atoi(argv[4]) : 0;
+    std::vector<int> devs(1, 0);
+    if (flags & 4) devs.push_back(0);
+    RsmStereoAdapter<MockTraits> gpu(devs, mode > 0 ? mode : 1);
     if (!gpu.Ok()) { fprintf(stderr, "%s\n", gpu.LastError()); return 3; }
+    if ((flags & 4) && (gpu.Slots() != 2 * (mode > 0 ? mode : 1) || gpu.DeviceOfSlot(1) != 0)) return 7;
     gpu.want_disparity = true;
+    gpu.fp64_points = (flags & 1) != 0;
+    s.throw_at = -1;
     s.adapter_disp0 = &gpu.disparity[0];
     s.got.resize(n_pairs);
     std::vector<int> status(n_pairs, 0);
     std::vector<int> okv(n_pairs, 0);
+    if (mode > 0 && (flags & 8)) { // a callback throws in the middle of the loop: pairs are in flight at that moment
+        s.throw_at = 2;
+        bool thrown = false;
+        try {
+            gpu.MatchAll(s, n_pairs, status.data());
+        } catch (const std::runtime_error &) {
+            thrown = true;
+        }
+        if (!thrown) { fprintf(stderr, "the callback's exception did not reach the caller\n"); return 8; }
+        s.throw_at = -1; // ... and the adapter must be usable again: the run below is the one that is checked
+        s.prepared.clear();
+        s.filtered.clear();
+        s.inserted.clear();
+        s.got.assign(n_pairs, MockStereo::Got());
+    }
     if (mode > 0) { // the pair loop of MatchAllLayer (.cpp:17-33) in one call, pairs in flight
-        const int nok = gpu.MatchAll(s, n_pairs, status.data());
+        const int nok = (flags & 2) ? gpu.MatchAllFiltered(s, n_pairs, status.data()) : gpu.MatchAll(s, n_pairs, status.data());
         int cnt = 0;
         for (int p = 0; p < n_pairs; p++) { okv[p] = status[p] == RSM_OK; cnt += okv[p]; }
         if (cnt != nok) { fprintf(stderr, "MatchAll returned %d, status says %d\n", nok, cnt); return 4; }
@@ -164,6 +207,12 @@ int main(int argc, char **argv) {
         const int32_t farg = g.seen ? g.filter_arg : -1;
         wr(fo, &farg, 1);
         wr(fo, g.xyz.data(), g.xyz.size());
+        if (flags & 2) {
+            const int64_t kn[2] = {(int64_t)g.kept.size(), g.n_raw};
+            wr(fo, kn, 2);
+            wr(fo, g.kept.data(), g.kept.size());
+            wr(fo, g.normals.data(), g.normals.size());
+        }
         if (g.disp0.size() != px) return 6;
         wr(fo, g.disp0.data(), px);
     }

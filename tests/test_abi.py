@@ -39,7 +39,30 @@ def test_struct_layouts_match_the_header():
     # rsm_boundary = 6 ints; rsm_pair_in: 4 ptr + 4 int + (pad) double + 2 int + 28 double + int
     assert C.sizeof(_lib.Boundary) == 24
     assert C.sizeof(_lib.PairIn) == 4 * 8 + 4 * 4 + 8 + 2 * 4 + 28 * 8 + 8
-    assert C.sizeof(_lib.PairOut) == 2 * 8 + 2 * 24 + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(_lib.PairOut) == 2 * 8 + 2 * 24 + 8 + 8 + 8 + 8 + 8 + 8
+
+
+def test_struct_layouts_as_the_c_compiler_sees_them(tmp_path):
+    """sizeof / offsetof of the header's structs from gcc itself against the ctypes mirror (rsm_pair_out grew a trailing
+    `points16` in round 5: both sides must agree on every member's offset)."""
+    from reconstruction_amd import _lib
+    src = tmp_path / "layout.c"
+    fields = {"rsm_pair_in": ["image", "mask", "width", "height", "pyr_levels", "radius", "ws", "offset", "origin_width", "Q", "R_final", "T_final", "verbose"],
+              "rsm_pair_out": ["disparity", "margin", "n_points", "max_points", "xyz", "bgr", "v_top", "points16"],
+              "rsm_filter_params": ["sor_mean_k", "sor_std_mul", "normal_radius", "cam_center"]}
+    body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (t, t) + "".join('printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (t, f, t, f) for f in fs)
+                   for t, fs in fields.items())
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rsm.h"\nint main(void) {\n%sprintf("rsm_point16 %%zu\\n", sizeof(rsm_point16));\nreturn 0; }\n' % body)
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c99", "-I" + os.path.dirname(HEADER), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    mirror = {"rsm_pair_in": _lib.PairIn, "rsm_pair_out": _lib.PairOut, "rsm_filter_params": _lib.FilterParams}
+    for t, fs in fields.items():
+        assert int(got[t]) == C.sizeof(mirror[t]), t
+        for f in fs:
+            assert int(got["%s.%s" % (t, f)]) == getattr(mirror[t], f).offset, (t, f)
+    assert int(got["rsm_point16"]) == 16
 
 
 def test_no_gpu_means_error_not_fallback():
@@ -87,6 +110,12 @@ def test_cpp_adapter_compiles_against_the_reference_headers(tmp_path, pcl):
                    '    RsmCvTraits::rectify() = [](CStereoMatching &s, int CamPair) { s.Rectify(CamPair, s.Q); };\n'
                    '    std::vector<int> status(m_data->m_CampairNum);\n'
                    '    if (gpu.MatchAll(*this, m_data->m_CampairNum, status.data()) != m_data->m_CampairNum) printf("rsm: %s\\n", gpu.LastError());\n'
+                   '}\n'
+                   # the several-GPU form (every visible device, three pairs in flight on each) and the loop with the filter on the GPU
+                   'int g(CStereoMatching &sm, int n) {\n'
+                   '    static RsmStereoMI355 gpu(RsmStereoMI355::AllDevices(), 3);\n'
+                   '    RsmCvTraits::filtered_sink() = [](CStereoMatching &, int, const rsm_point16 *, const float *, int64_t, int64_t) {};\n'
+                   '    return gpu.MatchAll(sm, n) + gpu.MatchAllFiltered(sm, n);\n'
                    '}\n')
     r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-I/root/reference/include",
                         "-I/root/reference/reconstruction", "-I" + os.path.join(ROOT, "include"), str(src)],

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import test_oracle_golden as cpu_side
-from test_oracle_golden import G, N_FM, N_NCC, N_OC, N_UQ, ncc_expected_disparity
+from test_oracle_golden import G, N_FM, N_NCC, N_OC, N_UQ, N_XI, ncc_expected_disparity
 
 pytestmark = pytest.mark.gpu
 NOMATCH = -10000
@@ -77,6 +77,23 @@ def test_hip_high_level_match_equals_the_reference_scores_argmax(ctx, i):
 test_oracle_armadillo_on_the_gpu_box = cpu_side.test_armadillo_mean_norm_dot
 test_oracle_median_on_the_gpu_box = cpu_side.test_armadillo_median
 test_oracle_window_to_vec_on_the_gpu_box = cpu_side.test_window_to_vec
+@pytest.mark.parametrize("form", [0, 1, 2])
+@pytest.mark.parametrize("i", range(N_XI))
+def test_hip_refine_data_term_equals_the_reference(ctx, i, form):
+    """The three device restatements of DisparityRefine's matching cost (k_refine.hip: refine_left + refine_cost_left of the
+    first sweep, refine_data_term_packed = a lane per cache miss, refine_data_term_quad = four lanes per miss) against the
+    COMPILED reference's own (1 - arma::dot(vecL, vecR) / (normL * normR)) / 2 (CStereoMatching.cpp:624-629) on whole rows,
+    through the C ABI with no oracle in between: every bit, flat windows and equal-cost textures included."""
+    A, B = G["in__xi_imgA_%d" % i], G["in__xi_imgB_%d" % i]
+    ref = G["ref__xi_table_%d" % i]
+    got = ctx.refine_xi(A, B, form)
+    nw = ref.shape[2]
+    for c in range(3):   # [c, y, x, col] = xi(x, y, col + c): compared wherever col + c is a window inside the row
+        a, b = got[c, :, :, :nw - c], ref[:, :, c:]
+        assert np.array_equal(a.view(np.int64), b.view(np.int64)), (form, c, int((a.view(np.int64) != b.view(np.int64)).sum()))
+
+
+test_oracle_refine_data_term_on_the_gpu_box = cpu_side.test_refine_data_term_against_the_reference
 test_oracle_find_margin_on_the_gpu_box = cpu_side.test_find_margin
 test_oracle_order_constraint_on_the_gpu_box = cpu_side.test_order_constraint
 test_oracle_uniqueness_on_the_gpu_box = cpu_side.test_uniqueness_three_passes

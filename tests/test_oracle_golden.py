@@ -156,3 +156,19 @@ def test_high_level_match_against_reference_scores(i):
         parent = np.full(((H + 1) // 2 + 1, (W + 1) // 2 + 1), pd, np.float64)
         got = orc.high_level_initial_match(A, B, mask, mask, r, offset, mg, mg, parent)
         assert np.array_equal(got, ncc_expected_high_level(G["ref__ncc_scores_%d" % i], r, H, W, pd, offset)), (i, pd, offset)
+
+
+N_XI = _n("xi_imgA_")
+
+
+@pytest.mark.parametrize("i", range(N_XI))
+def test_refine_data_term_against_the_reference(i):
+    """DisparityRefine's only non-trivial arithmetic besides exp -- the matching cost xi of 3x3x3 windows
+    (CStereoMatching.cpp:624-629) -- against the compiled reference's own WindowToVec + arma::dot in its call-site
+    expression (1 - dot / (normL * normR)) / 2, for every (own column, right-window left edge) pair of whole rows: 8-bit
+    noise, the bench's band-limited texture, two- / three-level textures, flat and saturated windows (norm 0 -> 1).  The
+    oracle's refine loop calls this very function (stereo_oracle.c: refine_xi).  Bit for bit."""
+    A, B = G["in__xi_imgA_%d" % i], G["in__xi_imgB_%d" % i]
+    got, ref = orc.refine_xi_table(A, B), G["ref__xi_table_%d" % i]
+    assert got.shape == ref.shape
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64)), int((got.view(np.int64) != ref.view(np.int64)).sum())
