@@ -53,9 +53,18 @@ def main():
                     help="pairs in flight inside the C++ adapter's MatchAll (0: two more than --inflight: a slot's pair is uploading or downloading part of the time; measured on C2 with 18 pairs: 3 slots 250, 4 271, 5 276, 6 281 Mdisp/s)")
     ap.add_argument("--adapter-pairs", type=int, default=18,
                     help="pairs matched through the compiled C++ adapter (tests/cpp/adapter_bench.cpp) for value_adapter_pcie_inclusive; 0: skip")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: what carries the per-pair clouds to rank 0 -- rccl (default): the library's own rsm_comm_create + rsm_gather_clouds "
+                         "(csrc/rsm_comm.hip: what a C++ pipeline links, the replacement of CCloudOptimization.cpp:61,123), posted by a gather thread per rank; "
+                         "torch: torch.distributed's batched isend / irecv (reconstruction_amd/dist.py).  The gloo stand-in of the tests always uses torch")
+    ap.add_argument("--one-process", action="store_true",
+                    help="with --gpus N: ONE process drives the N GPUs through rsm_match_pairs_multi_gpu (contexts on different devices, host buffers in "
+                         "and out, no RCCL): an auxiliary PCIe-inclusive figure, not the driver's scaling run")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.one_process:
+        raise SystemExit(one_process(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` started plainly: become the launcher of N ranks (one process per GPU)
         raise SystemExit(self_launch(args.gpus))
@@ -129,6 +138,20 @@ def main():
             c.upload_pair_device(cfg, [t.data_ptr() for t in t_img], [t.data_ptr() for t in t_msk])
             ctxs.append(c); cfgs.append(cfg); keep.append((t_img, t_msk))
     ctx, cfg = ctxs[0], cfgs[0]
+    # N > 1: the transport of the per-pair clouds.  rccl = the product's own path (rsm_comm_create + rsm_gather_clouds on a
+    # communicator of its own; the 128-byte id travels through torch.distributed's store, a side channel only)
+    # RSM_BENCH_SELF_GATHER=1 (tests): at N = 1 the step still packs its clouds and hands them to the gather thread, which runs
+    # rsm_gather_clouds on a one-rank communicator -- the whole N > 1 control flow of this file on a one-GPU box
+    exchange = world > 1 or os.environ.get("RSM_BENCH_SELF_GATHER") == "1"
+    transport = args.transport if (exchange and backend == "nccl") else "torch"
+    comm = None
+    if exchange and transport == "rccl":
+        from reconstruction_amd.dist import Comm
+        ids = [Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm = Comm(ids[0], rank, world, local_rank)
+    n_pairs_total = N_RIG if rig else world * F   # pair ids of one step's gather
     if args.pmc_child:  # the profiled child of measure_traffic(): one pair, nothing else
         ctx.run_pair()
         torch.cuda.synchronize()
@@ -146,7 +169,7 @@ def main():
     vtop_of = {}   # rig: V_top of every local pair (learnt in the first step)
 
     def run_steps(k):
-        if world == 1 and not rig:
+        if world == 1 and not rig and not exchange:
             # K steps = every context matches its pair K times.  The contexts are not made to meet between steps: as in
             # rsm_match_pairs (a stream of pairs over a pool of contexts) one pair's launch-bound small levels run under
             # the other's top-level sweeps, also across step boundaries.
@@ -165,7 +188,7 @@ def main():
                         c.run_pair()
                         if rig and p not in vtop_of:
                             vtop_of[p] = c.download_pair(want_cloud=False, want_disparity=False).v_top
-                        if world > 1:
+                        if exchange:
                             n = c.n_points
                             rec = torch.empty((n, 16), dtype=torch.uint8, device=dev)  # rsm_point16 records: 16 B per point
                             c.pack_cloud16(rec.data_ptr(), n)
@@ -177,6 +200,26 @@ def main():
         threads = [threading.Thread(target=worker, args=(i, c)) for i, c in enumerate(ctxs)]
         for t in threads:
             t.start()
+        # rccl transport: rsm_gather_clouds is synchronous, so a gather thread per rank posts the steps' gathers in order
+        # (collectives are posted alike on every rank) while the workers match the next step
+        gq, gerr = queue.Queue(maxsize=2), []
+
+        def gatherer():
+            torch.cuda.set_device(local_rank)
+            while True:
+                item = gq.get()
+                if item is None:
+                    return
+                try:
+                    if not gerr:
+                        comm.gather(item, n_pairs_total, root=0)
+                except BaseException as e:  # noqa: BLE001
+                    gerr.append(e)
+
+        gth = None
+        if comm is not None:
+            gth = threading.Thread(target=gatherer)
+            gth.start()
         pending = None
         for _ in range(k):
             local = []
@@ -185,13 +228,20 @@ def main():
                 if isinstance(recs, BaseException):
                     raise recs
                 local += recs
-            if world > 1:
+            if comm is not None:
+                gq.put(sorted(local, key=lambda t: t[0]))   # at most one gather in flight + one queued: the records stay alive in the queue
+            elif world > 1:
                 h = gather_clouds_async(sorted(local, key=lambda t: t[0]), dst=0)
                 if pending is not None:
                     pending.wait()
                 pending = h
         if pending is not None:
             pending.wait()
+        if gth is not None:
+            gq.put(None)
+            gth.join()
+            if gerr:
+                raise gerr[0]
         for t in threads:
             t.join()
 
@@ -291,7 +341,11 @@ def main():
                 dom = k
         top = prof_acc[dom]
         spl = int(round(top["bytes"] / max(1, top["launches"]) / light_b)) if light_b > 0 else 1  # sweeps per launch
-        kname = {"refine_skew_top": "k_refine_skew<%d,1, (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level; the third template argument is the variant: option refine_skew_variant)" % (spl, spl),
+        variant = 28   # the library's default (rsm.h: refine_skew_variant), unless an --opt overrides it
+        for o in args.opt:
+            if o.startswith("refine_skew_variant="):
+                variant = int(o.split("=")[1])
+        kname = {"refine_skew_top": "k_refine_skew<%d,1,%d> (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level; template arguments: sweeps per launch, top level, variant = option refine_skew_variant)" % (spl, variant if spl == 4 else 0, spl),
                  "refine_multi_top": "k_refine_multi<1> (DisparityRefine, two Jacobi sweeps per launch, top level)",
                  "refine_light_top": "k_refine_sweep<1,0> (DisparityRefine Jacobi sweep, top level)"}[dom]
         multi = dom != "refine_light_top"
@@ -310,7 +364,7 @@ def main():
             traffic_detail = {"skipped": "bench.py itself runs under a profiler"}
         if world == 1 and args.measure_traffic and not profiled:
             try:
-                traffic_detail = measure_traffic(kname.split(" ")[0], args)
+                traffic_detail = measure_traffic(kname.split(" ")[0].rstrip(">"), args)
                 traffic = traffic_detail["traffic_bytes_per_launch"]
                 traffic_source = "measured"
             except Exception as e:  # noqa: BLE001
@@ -319,7 +373,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     pj = json.load(f)
-                if pj.get("kernel_src_sha256") == kernel_src_sha() and pj.get("workload") == cfg.name and pj.get("kernel") == kname.split(" ")[0]:
+                if pj.get("kernel_src_sha256") == kernel_src_sha() and pj.get("workload") == cfg.name and pj.get("kernel") in (kname.split(" ")[0], kname.split(" ")[0].rsplit(",", 1)[0] + ","):
                     traffic = pj["traffic_bytes_per_launch"]
                     traffic_source = "quoted"
             except Exception:
@@ -339,7 +393,10 @@ def main():
                        "pyr_levels": cfg.pyr_levels,
                        "ncc_window": 2 * cfg.radius + 1, "offset": cfg.offset, "pairs_per_gpu": F, "pairs_in_flight": F,
                        "v_top_per_pair": int(res.v_top), "n_points_last": int(res.n_points),
-                       "parallelism": "pairs sharded 1/GPU + RCCL fan-in gather overlapped with the next pair" if world > 1 else "single GPU"},
+                       "parallelism": ("pairs sharded one process per GPU + fan-in gather of the clouds to rank 0, overlapped with the next step, through %s"
+                                       % ("rsm_comm / rsm_gather_clouds (the library's own RCCL path)" if transport == "rccl" else
+                                          "torch.distributed (%s)" % backend)) if world > 1 else "single GPU",
+                       "transport": transport if exchange else None},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -386,8 +443,8 @@ def main():
             # = all ten pairs matched once + (N > 1) the RCCL fan-in of the ten clouds to rank 0; 10 pairs on 8 GPUs cap at 5x
             ppr = [len([p for p in range(N_RIG) if p % world == r]) for r in range(world)]
             out["config"].update({"pairs": N_RIG, "pairs_per_rank": ppr, "pairs_in_flight": [min(args.inflight, max(1, n)) for n in ppr],
-                                  "parallelism": "10 pairs, pair %% %d -> rank; per-pair clouds gathered to rank 0 over RCCL in every step%s"
-                                                 % (world, "" if world > 1 else " (N = 1: no exchange)"),
+                                  "parallelism": "10 pairs, pair %% %d -> rank; per-pair clouds gathered to rank 0 in every step%s"
+                                                 % (world, (" through " + ("rsm_gather_clouds (RCCL)" if transport == "rccl" else "torch.distributed")) if world > 1 else " (N = 1: no exchange)"),
                                   "speedup_cap": N_RIG / max(ppr)})
             out["ms_per_pair"] = round(ms_per_step / N_RIG, 3)
         if single is not None:
@@ -427,9 +484,46 @@ def main():
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def one_process(args):
+    """`bench.py --gpus N --one-process`: the single-process form of SURVEY 8(e) -- rsm_match_pairs_multi_gpu drives N GPUs
+    (context i on GPU i % N, --inflight contexts per GPU) over a queue of C2 pairs with HOST buffers in and out (pageable
+    images, the clouds as fp64 xyz + BGR): PCIe-inclusive by construction, no collective.  One JSON line; `value` here is
+    NOT the resident-input figure of the default mode and says so."""
+    from reconstruction_amd import synth
+    from reconstruction_amd.api import match_pairs_multi_gpu
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        print("bench.py: --gpus %d --one-process needs %d visible GPUs, found %d" % (args.gpus, args.gpus, have), file=sys.stderr)
+        return 2
+    make = {"c2": synth.config_c2, "c2s": synth.config_c2_sample, "c1": synth.config_c1, "c3": synth.config_c3, "c4": synth.config_c3,
+            "c4s": synth.config_c3_shipped, "c5": synth.config_c5}[args.config]
+    per = max(1, args.inflight)
+    distinct = [make(pair=p) for p in range(min(3, args.gpus * per))]
+    n_pairs = args.gpus * per * max(1, args.steps)
+    cfgs = [distinct[p % len(distinct)] for p in range(n_pairs)]
+    match_pairs_multi_gpu(cfgs[:args.gpus * per], args.gpus, per, want_cloud=True, want_disparity=False)   # warm-up (contexts are per call)
+    t0 = time.perf_counter()
+    res, status, rc = match_pairs_multi_gpu(cfgs, args.gpus, per, want_cloud=True, want_disparity=False)
+    dt = time.perf_counter() - t0
+    if rc != 0 or any(status):
+        print("bench.py --one-process: rc %d, statuses %s" % (rc, status), file=sys.stderr)
+        return 1
+    v_total = float(sum(r.v_top for r in res))
+    print(json.dumps({"metric": "Mdisparities/s", "value": round(v_total / dt / 1e6, 3), "unit": "Mdisparities/s", "n_gpus": args.gpus,
+                      "steps": args.steps, "warmup": 1, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": distinct[0].name, "pairs": n_pairs, "pairs_in_flight_per_gpu": per,
+                                 "parallelism": "ONE process, rsm_match_pairs_multi_gpu: %d GPUs x %d contexts, host buffers in and out (PCIe-inclusive: "
+                                                "pageable images up, fp64 clouds down; contexts created inside the timed call)" % (args.gpus, per)},
+                      "note": "auxiliary mode: inputs are NOT resident in HBM; the driver's scaling run is `bench.py --gpus N` (one process per GPU)"}), flush=True)
+    return 0
 
 
 def self_launch(n):
@@ -635,9 +729,14 @@ def cpu_baseline(synth):
     t0 = time.perf_counter()
     r = orc.match_pair(cfg, want_cloud=True, threads=cores)
     dt = time.perf_counter() - t0
+    # (a SAMPLE, not the bench pair itself: C2's geometry scaled to a quarter of the area -- same window, levels, offset, half the
+    # candidates at the lowest level.  Round 5 tried a 768-row band of the bench's own pair instead: the rows below an empty parent
+    # row search the whole margin at every level whatever the band's height, 82 of its 115 s, so a band is NOT proportional to the
+    # pair; the whole pair itself takes 41-43 s on the GPU box's 16 cores = 0.133-0.139 Mdisp/s)
     out = {"value": round(r["v_top"] / dt / 1e6, 5), "unit": "Mdisparities/s", "cores": cores, "kind": "port",
-           "sample": "%s: one whole pair at a quarter of the bench workload's area (5 levels, 11x11 NCC, offset 2), %d masked pixels, %.1f s "
-                     "(refine %.1f s, NCC match %.1f s)" % (cfg.name, r["v_top"], dt, r["refine_seconds"], r["match_seconds"])}
+           "sample": "SAMPLE %s: one whole pair of the bench workload's geometry at a quarter of its area (5 levels, 11x11 NCC, offset 2, 64 "
+                     "instead of 128 candidates at the lowest level), %d masked pixels, %.1f s (refine %.1f s, NCC match %.1f s); the bench pair "
+                     "itself measured once: 0.133-0.139 Mdisp/s (41-43 s)" % (cfg.name, r["v_top"], dt, r["refine_seconds"], r["match_seconds"])}
     # the scalar figure ("1 thread"): the same port on ONE thread, on a sample sized for a few seconds
     small = synth.make_pair(640, 480, 3, radius=5, offset=2, pair=0, mask_kind="rect", mask_l0_width=48, border_l0=6,
                             d0_l0=2.0, amp_l0=1.0, name="C2t_640x480_r5_3levels")

@@ -216,8 +216,11 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
 
 /* Tuning / validation knobs.  None of them changes a result (every alternative path is held bit-identical by the tests):
  *   "ncc_bytes" = 1        the generic byte-wise NCC kernel instead of the dot4 one
- *   "wide_rows" = 0 | 1 | 2 | 3   rows of wide pixels: default (= 2) / the one-workgroup-per-pixel kernel / the int8 row GEMM
- *                          on the matrix cores / sliding window sums;  "no_rowgemm" = 1 is wide_rows = 1
+ *   "wide_rows" = 0 | 1 | 2 | 3   rows of wide pixels: 0 (default) = chosen per row on the device (k_rg_rows: the sliding window
+ *                          sums when the row's widest interval has at most ncc_slide_max candidates and the row holds enough
+ *                          wide pixels, the int8 row GEMM on the matrix cores otherwise) / 1 = the one-workgroup-per-pixel kernel
+ *                          only / 2 = every such row through the int8 row GEMM / 3 = every such row through the sliding sums;
+ *                          "no_rowgemm" = 1 is wide_rows = 1
  *   "ncc_mid" / "ncc_slide_max"   which rows of long-interval pixels leave the band kernel (intervals longer than ncc_mid
  *                          candidates; 0 = by window size from the measured crossover) and which of them take the sliding sums
  *                          (widest interval <= ncc_slide_max, default 512) rather than the int8 row GEMM
@@ -232,15 +235,22 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          wave-level predicates as lane masks straight from the compares (5.6 % fewer vector instructions,
  *                          +2 %); 16 only the cache way the state selects is read from LDS (+1.5 %); 1 / 2 = two bit-identical
  *                          restatements measured SLOWER (a row's staging shared by two waves / lane masks + unscaled divisions
- *                          behind a late guard), kept for A/B; 0 = round 3's kernel
+ *                          behind a late guard), kept for A/B; 0 = round 3's kernel.  Only the instantiated sets are accepted:
+ *                          0, 1, 2, 3, 4, 12, 28 (anything else: RSM_E_INVALID)
  *   "cu_share" = n         n > 1: the context's streams are confined to one of n equal shares of the compute units (the
  *                          context's creation ordinal on its device picks the share; measured slower than sharing the whole
- *                          chip in turns); 0 / 1 = the whole chip
+ *                          chip in turns); 0 / 1 = the whole chip.  The masked streams are BLOCKING streams
+ *                          (hipExtStreamCreateWithCUMask has no non-blocking flag): legacy null-stream work of the process then
+ *                          synchronises with them.  RSM_E_STATE while the context is inside rsm_run_pair
+ *   "shared_gpu" = 1       the caller's hint that other contexts use this context's GPU (pairs in flight): the lone-pair split
+ *                          below is never used, whatever the library's own count says at the moment a level is enqueued;
+ *                          rsm_run_pairs / rsm_match_pairs set it themselves, RsmStereoAdapter sets it for its slots
  *   "refine_prefill"       1 (default): the first sweep of a level also fills the second cache way (0: A/B)
  *   "refine_split"         1 (default): a pair that has the GPU to itself (no other context of the device inside rsm_run_pair,
  *                          no per-launch timing) runs the two directions of its time-skewed sections as separate launch chains
  *                          on its two streams (one's low-occupancy tail beside the other's head: one C2 pair 24.1 -> 23.0 ms);
- *                          never used with pairs in flight (measured slower there)
+ *                          not used with pairs in flight (measured slower there): the library counts the contexts of the device
+ *                          that are inside rsm_run_pair when a level is enqueued, and "shared_gpu" rules it out altogether
  *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)
  *   "refine_defer_from" / "refine_defer_to" / "refine_defer_min_px"   sweeps whose data-term cache misses are listed and served
  *                          by a second kernel, a lane per miss, instead of inside the sweep (to = 0 = never, default)

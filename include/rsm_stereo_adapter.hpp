@@ -215,6 +215,7 @@ private:
                 return false;
             }
         }
+        if (nslots_ > (int)devices_.size()) (void)rsm_set_option(s.ctx, "shared_gpu", 1); // several slots per GPU: pairs in flight
         if (!s.worker.joinable()) s.worker = std::thread(&RsmStereoAdapter::worker_loop, this, &s);
         return true;
     }

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(NCC_TX) void k_ncc_bytes(StageArgs a, int mode, int
 //               rows carrying as many evaluations as the rest of the level.)
 #define NCC_G 5
 #define NCC_WIDE 160 // the largest interval the band kernel takes (its LDS staging is sized for it); StageArgs::ncc_wide may lower the threshold
-#define RG_SLOTS 512 // rows per direction k_ncc_rowgemm can take (more: the surplus rows fall back to k_ncc_wide)
+#define RG_SLOTS 512 // row-kernel workgroups per direction in grid.y: every workgroup loops over the listed rows slot by slot (slot, slot + gridDim.y, ...),
+                     // so no listed row is ever left out; k_ncc_wide skips every row that k_rg_rows listed (>= RG_MIN wide pixels)
 #define RG_MIN 48 // wide pixels of a (direction, row) from which the row is matched by k_ncc_rowgemm instead of k_ncc_wide
 #define RG_SLIDE_MIN 1024 // wide pixels of a row from which k_ncc_slide takes it (when its widest interval allows): C2's rows below an empty parent row at
                           // the lower levels (128...1024 pixels x as many candidates) run faster in the GEMM (initial match 1.43 against 1.83 ms)

@@ -104,6 +104,8 @@ struct rsm_ctx {
     RfUpd *upd_list2 = nullptr;     // the second direction's update list / counters while the two run as separate launch chains
     int32_t *upd_cnt2 = nullptr;
     int opt_refine_split = 1;       // a pair that has the GPU to itself runs the two directions of its time-skewed sections on two streams
+    int opt_shared_gpu = 0;         // the caller's hint that other contexts use this GPU (a pool of pairs in flight): never split, whatever g_running says at the moment
+    std::atomic<int> in_run{0};     // inside rsm_run_pair (options that replace the streams refuse to act then)
     int32_t *row_count = nullptr;
     int64_t *row_offset = nullptr;
     int64_t *d_npoints = nullptr;
@@ -171,10 +173,13 @@ struct rsm_ctx {
 static std::atomic<int> g_running[RSM_MAX_DEVICES]; // contexts inside rsm_run_pair, per device
 struct RunningGuard {
     int dev;
-    explicit RunningGuard(int d) : dev(d) {
+    std::atomic<int> *own;
+    RunningGuard(int d, std::atomic<int> *in_run) : dev(d), own(in_run) {
         if (dev < RSM_MAX_DEVICES) g_running[dev].fetch_add(1);
+        own->store(1);
     }
     ~RunningGuard() {
+        own->store(0);
         if (dev < RSM_MAX_DEVICES) g_running[dev].fetch_sub(1);
     }
 };
@@ -521,12 +526,17 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
-    else if (!strcmp(name, "refine_skew_variant")) c->opt_refine_skew_variant = (int)std::max(0LL, std::min(value, 31LL));
+    else if (!strcmp(name, "refine_skew_variant")) { // only these instantiations of k_refine_skew<4, TOP, V> exist
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 12 && value != 28)
+            return set_err(c, RSM_E_INVALID, "refine_skew_variant %lld: the instantiated variants are 0, 1, 2, 3, 4, 12, 28", value);
+        c->opt_refine_skew_variant = (int)value;
+    } else if (!strcmp(name, "shared_gpu")) c->opt_shared_gpu = value != 0;
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "cu_share")) {
         // Contexts that share a GPU each on their own share of the compute units (the `ordinal % n`-th of n equal ranges of the
         // CU mask, hipExtStreamCreateWithCUMask) instead of all of them on the whole chip; 0 / 1 = the whole chip.
         const int n = (int)std::max(0LL, std::min(value, 64LL));
+        if (c->in_run.load()) return set_err(c, RSM_E_STATE, "cu_share: the context is inside rsm_run_pair (its streams are in use)");
         if (hipSetDevice(c->device) != hipSuccess) return set_err(c, RSM_E_HIP, "hipSetDevice");
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return set_err(c, RSM_E_HIP, "hipGetDeviceProperties");
@@ -764,7 +774,7 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         // tail of one or two waves per SIMD, and the other direction's launch fills it.  With pairs in flight the
         // other pairs' kernels do that already, and the split costs throughput (measured): not used there.
         const bool may_split = skew && a.ndir == 2 && c->opt_refine_split && (!c->profile || c->opt_refine_split == 2) && c->stream2 != st && c->upd_list2 &&
-                               c->device < RSM_MAX_DEVICES && (c->opt_refine_split == 2 || g_running[c->device].load() == 1);
+                               c->device < RSM_MAX_DEVICES && (c->opt_refine_split == 2 || (!c->opt_shared_gpu && g_running[c->device].load() == 1));
         auto join = [&]() {
             if (!split_now) return;
             (void)hipEventRecord(c->ev_join, c->stream2);
@@ -773,18 +783,20 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         };
         for (int t = 1; t < iters;) {
             const bool skew_now = skew && t >= c->opt_refine_skew_from && t + skewT <= iters;
-            if (skew_now && may_split && !split_now) { // fork: the second stream continues from here
-                (void)hipMemsetAsync(c->upd_cnt2, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
-                (void)hipEventRecord(c->ev_fork, st);
-                (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-                split_now = true;
-            } else if (!skew_now) join();
+            if (!skew_now) join(); // (before the lane is handed on: the section's end event must cover the second stream's launches)
             if (c && c->opt_heavy_lanes == 2 && (int)skew_now != lane && t >= turn_from) { // the section changes kind: hand its lane on
                 heavy_end(c, held, lane);
                 held = false;
                 lane = (int)skew_now;
             }
             if (t >= turn_from && !held) held = heavy_begin(c, heavy_px, top, lane);
+            if (skew_now && may_split && !split_now) { // fork: the second stream continues from here -- AFTER heavy_begin's wait has
+                                                       // been enqueued on `st`, so the second direction takes turns like the first
+                (void)hipMemsetAsync(c->upd_cnt2, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
+                (void)hipEventRecord(c->ev_fork, st);
+                (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+                split_now = true;
+            }
             if (multi && t >= c->opt_refine_multi_from && t + 1 < iters) {
                 a.flag3 = nmulti++;
                 launch(t, 0, INT_MAX, 2);
@@ -828,7 +840,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     if (!c) return RSM_E_INVALID;
     if (!c->have_pair) return set_err(c, RSM_E_STATE, "rsm_run_pair before rsm_upload_pair");
     HIPCHK(c, hipSetDevice(c->device));
-    RunningGuard running(c->device);
+    RunningGuard running(c->device, &c->in_run);
     hipStream_t st = c->stream;
     const int N = c->N, r = c->in.radius;
     c->have_result = false;
@@ -1149,6 +1161,11 @@ extern "C" int rsm_run_pairs_repeat(rsm_ctx *const *ctxs, int n, int repeats) {
         for (int j = 0; j < i; j++)
             if (ctxs[j] == ctxs[i]) return RSM_E_INVALID; // a context is not re-entrant
     }
+    for (int i = 0; i < n; i++) { // contexts that share a device with another one of the pool: pairs in flight, never the lone-pair split
+        bool shared = false;
+        for (int j = 0; j < n; j++) shared |= j != i && ctxs[j]->device == ctxs[i]->device;
+        ctxs[i]->opt_shared_gpu = shared;
+    }
     std::vector<int> st((size_t)n, RSM_OK);
     auto loop = [&](int i) { // every context runs its resident pair `repeats` times, free of the others
         for (int k = 0; k < repeats && st[(size_t)i] == RSM_OK; k++) st[(size_t)i] = rsm_run_pair(ctxs[i]);
@@ -1170,6 +1187,11 @@ extern "C" int rsm_match_pairs(rsm_ctx *const *ctxs, int n_ctx, const rsm_pair_i
         if (!ctxs[i]) return RSM_E_INVALID;
         for (int j = 0; j < i; j++)
             if (ctxs[j] == ctxs[i]) return RSM_E_INVALID;
+    }
+    for (int i = 0; i < n_ctx; i++) { // (see rsm_run_pairs_repeat)
+        bool shared = false;
+        for (int j = 0; j < n_ctx; j++) shared |= j != i && ctxs[j]->device == ctxs[i]->device;
+        ctxs[i]->opt_shared_gpu = shared;
     }
     std::atomic<int> next(0);
     std::vector<int> st((size_t)n_pairs, RSM_OK);

@@ -119,6 +119,30 @@ def test_bench_runs_with_two_ranks_on_the_gloo_stand_in(launcher):
     assert d["config"]["pairs_per_gpu"] == 3  # bench.py's default --inflight
 
 
+def test_bench_gathers_through_the_librarys_own_rccl_path():
+    """The N > 1 control flow of bench.py with its DEFAULT transport -- rsm_comm_create + rsm_gather_clouds, the product's own
+    RCCL path (csrc/rsm_comm.hip), posted by a gather thread while the next step is matched -- on a one-GPU box: at N = 1
+    RSM_BENCH_SELF_GATHER=1 keeps the packing, the hand-over and the gather (a one-rank communicator: RCCL refuses two ranks on
+    one device).  The line names the transport; the driver's scaling run times exactly this path."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RSM_BENCH_BACKEND")}
+    env["RSM_BENCH_SELF_GATHER"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--config", "c2s", "--no-cpu-baseline",
+                        "--measure-traffic", "0", "--adapter-pairs", "0"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["transport"] == "rccl"
+
+
+def test_bench_one_process_mode_drives_the_gpus_through_the_c_abi():
+    """`bench.py --gpus N --one-process` = rsm_match_pairs_multi_gpu (N = 1 here): an auxiliary, PCIe-inclusive figure."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RSM_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--one-process", "--steps", "2", "--inflight", "2", "--config", "c2s"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["pairs"] == 4 and "rsm_match_pairs_multi_gpu" in d["config"]["parallelism"]
+
+
 def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     """One visible GPU, --gpus 2 on the real (nccl) backend: exit non-zero, never a silent 1-GPU number."""
     if torch.cuda.device_count() >= 2:
