@@ -242,6 +242,8 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          chip in turns); 0 / 1 = the whole chip.  The masked streams are BLOCKING streams
  *                          (hipExtStreamCreateWithCUMask has no non-blocking flag): legacy null-stream work of the process then
  *                          synchronises with them.  RSM_E_STATE while the context is inside rsm_run_pair
+ *   "filter_window"        rsm_filter_last_cloud's pixel-window pass: 1 (default) radius from a sparse probe, 0 off (the generic grid
+ *                          search decides every query), 7 / 12 / 16 / 20 / 24 that radius
  *   "shared_gpu" = 1       the caller's hint that other contexts use this context's GPU (pairs in flight): the lone-pair split
  *                          below is never used, whatever the library's own count says at the moment a level is enqueued;
  *                          rsm_run_pairs / rsm_match_pairs set it themselves, RsmStereoAdapter sets it for its slots
@@ -377,6 +379,13 @@ int rsm_filter_cloud(rsm_ctx *ctx, const float *xyz, int64_t n, const rsm_filter
  * in caller-owned DEVICE buffers of capacity max_points. */
 int rsm_filter_last_cloud(rsm_ctx *ctx, const rsm_filter_params *params, rsm_point16 *d_points, float *d_normals,
                           int64_t max_points, int64_t *n_kept, double *stats);
+/* What the last rsm_filter_last_cloud[_host] of this context did: info[0] = the radius (pixels) of the pixel-window k-nearest pass,
+ * 0 when it did not run (the cloud of a matched pair is a depth map: the k nearest of most points lie within a small pixel window
+ * around their own pixel, proven per point by a bound on the distance to every ray outside it -- csrc/k_filter.hip; the radius --
+ * 7, 12 or 16 -- comes from a sparse probe), info[1] = queries it left to the generic grid search, info[2] = points in, info[3] =
+ * points kept.  Option "filter_window" (rsm_set_option): 1 = probe (default), 0 = no window pass, 7 / 12 / 16 / 20 / 24 = that
+ * radius (A/B; the results are the same bits either way). */
+int rsm_filter_last_info(rsm_ctx *ctx, int64_t info[4]);
 /* The same with HOST output buffers (page-locked ones from rsm_host_alloc arrive at the link's rate): what a pipeline that
  * replaces the first half of CCloudOptimization::filter (CCloudOptimization.cpp:82-121) downloads instead of the raw cloud --
  * the surviving points and their oriented normals (the reference's cloud_normal, :110-121).  h_normals may be NULL. */

@@ -330,6 +330,261 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
     if (lane == 0) dist_orig[orig] = (float)((sum + (double)(want - less) * (double)sqrtf(tau)) / mean_k);
 }
 
+// =================================================================================================================
+// Pixel-window k nearest (rsm_filter_last_cloud, round 5): the cloud of a matched pair is a DEPTH MAP -- point i sits on
+// the ray of its pixel, P = iW (x + q03, y + q13, qz) before the rigid R_final / T_final (DisparityToCloud,
+// CStereoMatching.cpp:732-749) -- so the pixel lattice itself is the search structure: the k nearest of a point are among
+// the points of the (2 WR + 1)^2 pixels around its own, PROVIDED the (k+1)-th smallest distance found there is below the
+// distance from P to every ray OUTSIDE that window.  For a ray through pixel offset (a, b), rho = |(a, b)| >= WR + 1:
+//     dist(P, ray) = |iW| |D x D'| / |D'| >= |iW| |qz| rho / (|D| + rho),   D = (x + q03, y + q13, qz), D' = D + (a, b, 0)
+// (|D x D'|^2 = qz^2 rho^2 + (Dx b - Dy a)^2, |D'| <= |D| + rho), increasing in rho, so with |iW| |qz| = |F2| (the point's
+// depth in the camera frame) and |iW| |D| = |P - T|:
+//     LB = |F2| (WR + 1) / (|P - T| |qz| / |F2| + WR + 1).
+// A query whose (k+1)-th smallest float32 distance stays below LB minus a rounding margin is decided HERE with exactly the
+// values the generic search would find (same float32 squared distances, the k smallest by value, the same exact double
+// sum); every other query -- near a depth edge, a hole, the mask's border, an outlier: the thick or thin parts of the
+// sheet -- is flagged and goes to the grid ladder below.  The selection is per LANE (a query per thread, a 32 x 8 tile of
+// pixels per workgroup, the tile and its halo in LDS as float4): pass 1 bins the window's squared distances into 32
+// per-thread LDS counters over [0, 4 tau_est] (tau_est = the (k+1)/pi lateral spacings^2 of a fronto-parallel sheet), the
+// scan finds the bin holding rank k + 1, pass 2 sums sqrt(d2) of the bins below it in double (exact, order-free) and lists
+// the few values of that bin, whose rank-th smallest is tau.  ~120 wave-instructions per query against ~2000 of the
+// wave-per-query grid search.
+#define WIN_PAD 24  // invalid-pixel border of the lattice copy (>= the largest window radius): no bounds checks in the loops
+#define WIN_TX 32
+#define WIN_TY 8
+#define WIN_NB 32   // distance bins per query over [0, bound^2): the rank's bin holds ~1.5 (k + 1) / (its index) values, a handful
+#define WIN_LCAP 32 // values of the rank's bin a query can list (more: undecided -> the ladder); the list reuses the counters' LDS
+struct WinGeom {
+    int gw, gh;         // lattice copy incl. the border: (XR - XL + 1 + 2 PAD) x (YR - YL + 1 + 2 PAD)
+    double qz;          // Q[2][3] scaled (.cpp:698)
+    double rz[3], T[3]; // third column of R_final (F2 = rz . (P - T)), T_final
+};
+
+// lattice copy of the cloud: float4 (x, y, z as InsertPoint keeps them, bits of the point index) per flagged pixel of the
+// margin's box, NaN elsewhere (the buffer is pre-filled); block = row, the compaction order of k_cloud<1>
+__global__ __launch_bounds__(256) void k_cloud_lattice(const uint8_t *__restrict__ flags, const int64_t *__restrict__ row_offset, int W, int XL, int XR, int YL,
+                                                        const double *__restrict__ xyz, int64_t n, int gw, float4 *__restrict__ lat) {
+    __shared__ int s_w[4];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int y = YL + blockIdx.x;
+    if (tid == 0) s_base = (long long)row_offset[blockIdx.x];
+    __syncthreads();
+    for (int x0 = XL; x0 <= XR; x0 += 256) {
+        const int x = x0 + tid;
+        const bool f = (x <= XR) && flags[(size_t)y * W + x];
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) s_w[wid] = __popcll(b);
+        __syncthreads();
+        if (f) {
+            long long pos = s_base + __popcll(b & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wid; w++) pos += s_w[w];
+            if (pos < n) {
+                const float px = (float)xyz[3 * pos], py = (float)xyz[3 * pos + 1], pz = (float)xyz[3 * pos + 2]; // InsertPoint's cast
+                if (isfinite(px) && isfinite(py) && isfinite(pz)) // (non-finite points take no part in the searches)
+                    lat[(size_t)(blockIdx.x + WIN_PAD) * gw + (x - XL + WIN_PAD)] = make_float4(px, py, pz, __uint_as_float((unsigned int)pos));
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+
+// PROBE: every `tile_step`-th tile in x and y only, nothing written but three counters (queries seen, queries decided, the sum of
+// their bounds): the host picks the smallest window radius that decides most of a sparse sample before it pays for the full pass.
+template <int WR, bool PROBE>
+__global__ __launch_bounds__(256) void k_sor_window(const float4 *__restrict__ lat, WinGeom g, int mean_k, float *__restrict__ dist,
+                                                     unsigned int *__restrict__ undecided, int tile_step, unsigned int *__restrict__ probe_cnt) {
+    constexpr int SW = WIN_TX + 2 * WR, SH = WIN_TY + 2 * WR;
+    __shared__ float4 s_t[SH][SW];
+    __shared__ unsigned int s_u[WIN_NB + 1][256]; // column tid is private to thread tid: first the bin counters (row WIN_NB: the sink of
+                                                  // candidates beyond the bound / pixels without a point), then the list of the rank's bin
+    static_assert(WIN_LCAP <= WIN_NB, "the list reuses the counters' storage");
+    const int tid = threadIdx.x, tx = tid & (WIN_TX - 1), ty = tid / WIN_TX;
+    const int gx0 = WIN_PAD + (int)blockIdx.x * tile_step * WIN_TX - WR, gy0 = WIN_PAD + (int)blockIdx.y * tile_step * WIN_TY - WR; // lattice position of s_t[0][0]
+    for (int e = tid; e < SW * SH; e += 256) {
+        const int r = e / SW, c = e - r * SW;
+        const int gy = min(gy0 + r, g.gh - 1), gx = min(gx0 + c, g.gw - 1); // (the last tiles' overhang re-reads the border: NaN)
+        s_t[r][c] = lat[(size_t)gy * g.gw + gx];
+    }
+#pragma unroll
+    for (int b = 0; b < WIN_NB; b++) s_u[b][tid] = 0u;
+    __syncthreads();
+    const float4 P = s_t[ty + WR][tx + WR];
+    const bool valid = P.x == P.x; // NaN: no point at this pixel
+    if (!__syncthreads_or(valid)) return;
+    // the bound and its rounding margin, in double (once per query)
+    const double dx = (double)P.x - g.T[0], dy = (double)P.y - g.T[1], dz = (double)P.z - g.T[2];
+    const double F2 = fabs(g.rz[0] * dx + g.rz[1] * dy + g.rz[2] * dz), nP = sqrt(dx * dx + dy * dy + dz * dz);
+    const double iw = F2 / fabs(g.qz);                                   // |iW|: the lateral spacing of adjacent pixels at this depth
+    const double LB = F2 * (WR + 1) / (nP / fmax(iw, 1e-300) + (WR + 1));
+    const double coord = fmax(fmax(fabs((double)P.x), fabs((double)P.y)), fabs((double)P.z)) + nP;
+    const double lim = LB * (1.0 - 1e-5) - 4e-7 * coord; // float32 coordinates and float32 distance arithmetic: relative 1e-7 each
+    const float range = (lim > 0.0) ? (float)(lim * lim * (1.0 - 1e-6)) : 0.0f; // tau must stay below this; the bins cover [0, range)
+    const int want = mean_k + 1;
+    const float inv_w = (range > 0.0f) ? (float)WIN_NB / range : 0.0f;
+    bool ok = valid && range > 0.0f && inv_w > 0.0f && isfinite(inv_w);
+    auto bin_of = [&](float d2) { return min((int)(d2 * inv_w), WIN_NB - 1); }; // monotone in d2
+    // One row of the window at a time: all its LDS reads first (16-byte reads, in flight together), then the arithmetic -- a read,
+    // its wait and a data-dependent branch per candidate would expose the LDS latency (2 x 1089 times per query at WR = 16).
+    constexpr int NC = 2 * WR + 1;
+    auto row_d2 = [&](int r, float (&d2)[NC]) {
+        float4 o[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            o[c] = s_t[ty + r][tx + c];
+            asm volatile("" : "+v"(o[c].w)); // (keeps the read a ds_read_b128: twice the LDS rate of the 12-byte form)
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) d2[c] = fdist2(P.x, P.y, P.z, o[c].x, o[c].y, o[c].z); // NaN for a pixel without a point: every test below fails
+    };
+    // pass 1: histogram of the window's squared distances (the point itself included: d2 = 0, as nearestKSearch(k + 1)); branch-free:
+    // what lies beyond the bound goes to the sink row
+    if (ok) {
+        unsigned int *mine = &s_u[0][tid];
+#pragma unroll 1
+        for (int r = 0; r < NC; r++) {
+            float d2[NC];
+            row_d2(r, d2);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int b = (d2[c] < range) ? bin_of(d2[c]) : WIN_NB;
+#if defined(WIN_EXP) && (WIN_EXP & 1) // timing experiment (results invalid): no histogram updates
+                asm volatile("" ::"v"(b));
+#else
+                atomicAdd(mine + 256 * b, 1u); // (no return value: a fire-and-forget ds_add)
+#endif
+            }
+        }
+    }
+    // the bin holding rank `want`
+    int below = 0, bstar = -1, in_bin = 0;
+    if (ok) {
+#pragma unroll 1
+        for (int b = 0; b < WIN_NB; b++) {
+            const int h = (int)s_u[b][tid];
+            if (bstar < 0 && below + h >= want) {
+                bstar = b;
+                in_bin = h;
+            }
+            if (bstar < 0) below += h;
+        }
+        ok = bstar >= 0 && in_bin <= WIN_LCAP; // fewer than k + 1 points within the bound in the window, or too many (nearly) equal distances
+    }
+    // pass 2: the exact sum below the bin, the bin's values listed (over the counters: they are dead now).  The bin tests become
+    // two float compares: t_lo / t_hi = the smallest floats whose bin is >= bstar / > bstar (bin_of is monotone)
+    float *lst = (float *)&s_u[0][0];
+    double sum = 0.0;
+    int nl = 0;
+    if (ok) {
+        auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB - 1
+            float t = (float)b / inv_w;
+            while (t > 0.0f && bin_of(__uint_as_float(__float_as_uint(t) - 1u)) >= b) t = __uint_as_float(__float_as_uint(t) - 1u);
+            while (bin_of(t) < b) t = __uint_as_float(__float_as_uint(t) + 1u);
+            return t;
+        };
+        const float t_lo = bstar > 0 ? first_in(bstar) : 0.0f;
+        const float t_hi = bstar < WIN_NB - 1 ? fminf(first_in(bstar + 1), range) : range;
+#pragma unroll 1
+        for (int r = 0; r < NC; r++) {
+#if defined(WIN_EXP) && (WIN_EXP & 2) // timing experiment (results invalid): no second pass
+            break;
+#endif
+            float d2[NC];
+            row_d2(r, d2);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (d2[c] < t_lo) sum += (double)sqrtf(d2[c]);
+                else if (d2[c] < t_hi) {
+                    lst[nl * 256 + tid] = d2[c];
+                    nl++;
+                }
+            }
+        }
+        // tau = the (want - below)-th smallest of the listed values (by value: ties are equal distances)
+        const int rank = want - below; // 1 .. in_bin
+        float tau = 0.0f;
+        int less = 0;
+#pragma unroll 1
+        for (int i = 0; i < nl; i++) {
+            const float v = lst[i * 256 + tid];
+            int lt = 0, le = 0;
+#pragma unroll 1
+            for (int j = 0; j < nl; j++) {
+                const float u = lst[j * 256 + tid];
+                lt += u < v;
+                le += u <= v;
+            }
+            if (lt < rank && rank <= le) { // v is the rank-th smallest
+                tau = v;
+                less = lt;
+            }
+        }
+#pragma unroll 1
+        for (int i = 0; i < nl; i++) {
+            const float v = lst[i * 256 + tid];
+            if (v < tau) sum += (double)sqrtf(v);
+        }
+        if (nl == in_bin && tau < range) { // every point outside the window is farther than sqrt(tau): the k + 1 smallest are all here
+            const int nless = below + less;
+            if (!PROBE) dist[__float_as_uint(P.w)] = (float)((sum + (double)(want - nless) * (double)sqrtf(tau)) / mean_k);
+        } else {
+            ok = false;
+        }
+    }
+    if (PROBE) {
+        const unsigned long long mv = __ballot(valid), mo = __ballot(valid && ok);
+        float sl = valid ? (float)fmax(lim, 0.0) : 0.0f; // the mean bound: what the queries this radius leaves over have in common (tau >= lim^2)
+        for (int o = 32; o > 0; o >>= 1) sl += __shfl_xor(sl, o);
+        if ((tid & 63) == 0 && mv) {
+            atomicAdd(&probe_cnt[0], (unsigned int)__popcll(mv));
+            atomicAdd(&probe_cnt[1], (unsigned int)__popcll(mo));
+            atomicAdd((float *)&probe_cnt[2], sl);
+        }
+    } else if (valid) {
+        undecided[__float_as_uint(P.w)] = ok ? 0u : 1u;
+    }
+}
+
+void launch_cloud_lattice(const uint8_t *flags, const int64_t *row_offset, int W, int XL, int XR, int YL, int YR, const double *xyz, int64_t n, float4 *lat,
+                          hipStream_t st) {
+    const int gw = XR - XL + 1 + 2 * WIN_PAD, gh = YR - YL + 1 + 2 * WIN_PAD;
+    (void)hipMemsetD32Async((hipDeviceptr_t)lat, 0x7fc00000, (size_t)4 * gw * gh, st);
+    hipLaunchKernelGGL(k_cloud_lattice, dim3((unsigned)(YR - YL + 1)), dim3(256), 0, st, flags, row_offset, W, XL, XR, YL, xyz, n, gw, lat);
+}
+size_t cloud_lattice_bytes(int XL, int XR, int YL, int YR) {
+    return sizeof(float4) * (size_t)(XR - XL + 1 + 2 * WIN_PAD) * (size_t)(YR - YL + 1 + 2 * WIN_PAD);
+}
+// the window pass over the whole lattice: dist / undecided (one entry per cloud point; undecided pre-set to 1 by the caller);
+// tile_step > 1 + probe_cnt: the sparse probe (see k_sor_window)
+void launch_sor_window(const float4 *lat, int XL, int XR, int YL, int YR, double qz, const double *R, const double *T, int mean_k, int radius, float *dist,
+                       unsigned int *undecided, hipStream_t st, int tile_step = 1, unsigned int *probe_cnt = nullptr) {
+    WinGeom g;
+    g.gw = XR - XL + 1 + 2 * WIN_PAD;
+    g.gh = YR - YL + 1 + 2 * WIN_PAD;
+    g.qz = qz;
+    for (int i = 0; i < 3; i++) {
+        g.rz[i] = R[3 * i + 2];
+        g.T[i] = T[i];
+    }
+    const int tx = (XR - XL + 1 + WIN_TX - 1) / WIN_TX, ty = (YR - YL + 1 + WIN_TY - 1) / WIN_TY;
+    const dim3 grid((unsigned)((tx + tile_step - 1) / tile_step), (unsigned)((ty + tile_step - 1) / tile_step));
+#define WIN_LAUNCH(R_)                                                                                                                     \
+    do {                                                                                                                                   \
+        if (probe_cnt) hipLaunchKernelGGL((k_sor_window<R_, true>), grid, dim3(256), 0, st, lat, g, mean_k, dist, undecided, tile_step, probe_cnt); \
+        else hipLaunchKernelGGL((k_sor_window<R_, false>), grid, dim3(256), 0, st, lat, g, mean_k, dist, undecided, tile_step, probe_cnt);          \
+    } while (0)
+    switch (radius) {
+    case 7: WIN_LAUNCH(7); break;
+    case 12: WIN_LAUNCH(12); break;
+    case 16: WIN_LAUNCH(16); break;
+    case 20: WIN_LAUNCH(20); break;
+    default: WIN_LAUNCH(24); break;
+    }
+#undef WIN_LAUNCH
+}
+
 // ---- the few queries no grid level could decide (isolated points -- what this filter removes -- and clusters smaller
 // than k): against ALL points, the whole chip on every query.  Three-pass radix select of the (k+1)-th smallest squared
 // distance (bits 30..20, 19..9, 8..0 of its pattern): per pass every workgroup histograms its slice of the points for
@@ -828,6 +1083,14 @@ static int build_grid(FilterArena *A, const float *d_xyz, int64_t n, int64_t nv,
     return RSM_OK;
 }
 
+// (pixel-window pass) every finite point starts undecided; the others take no part in the searches (distance 0, as PCL)
+__global__ void k_finite_flags(const float *__restrict__ xyz, int64_t n, unsigned int *__restrict__ flag, unsigned int *__restrict__ iota) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (isfinite(xyz[3 * i]) && isfinite(xyz[3 * i + 1]) && isfinite(xyz[3 * i + 2])) ? 1u : 0u;
+    iota[i] = (unsigned int)i;
+}
+
 __global__ void k_compact_list(const unsigned int *__restrict__ src, const unsigned int *__restrict__ flag, const unsigned int *__restrict__ pos,
                                int n, unsigned int *__restrict__ dst, int *__restrict__ count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -849,9 +1112,11 @@ static void launch_knn(const float *d_xyz, const FilterGridDev &G, int nv, float
 
 // d_xyz: n x 3 float (device).  Outputs (device): kept_index [n] (first *n_kept valid), fxyz [3n], normals [n] float4.
 // A: reserved by the caller (filter_arena_reserve) with at least filter_arena_bytes(n) free.
+// pre (optional): the cloud is the depth map of a matched pair -- its pixel lattice decides most queries (k_sor_window),
+// the grid ladder only sees the rest.
 int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius,
                         const float cam_center[3], int32_t *d_kept_index, float *d_fxyz, float4 *d_normals, int64_t *n_kept,
-                        double stats[4], hipStream_t st) {
+                        double stats[4], hipStream_t st, const FilterLattice *pre) {
     *n_kept = 0;
     if (n <= 0) return RSM_OK;
     if (n >= (1ll << 31) || mean_k < 1 || !A) return RSM_E_INVALID;
@@ -916,13 +1181,62 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     const unsigned int *queries = nullptr;
     int s = RSM_OK;
     const size_t mark = A->off;
+    bool prepassed = false;
+    if (pre && mean_k <= 128 && nv > 0) { // the pixel-window pass: what it cannot decide becomes the ladder's first query list
+        float4 *lat = A->get<float4>(cloud_lattice_bytes(pre->XL, pre->XR, pre->YL, pre->YR) / sizeof(float4));
+        if (!lat) return RSM_E_NOMEM;
+        hipLaunchKernelGGL(k_finite_flags, dim3(blocks), dim3(256), 0, st, d_xyz, n, d_flag, d_redo2);
+        launch_cloud_lattice(pre->flags, pre->row_offset, pre->W, pre->XL, pre->XR, pre->YL, pre->YR, pre->xyz64, n, lat, st);
+        // which window?  pre->radius > 0: the caller's; 0: the smallest of 7 / 12 / 16 pixels that decides >= 85 % of a sparse
+        // sample of the tiles (every 6th in x and y: ~3 % of the queries) -- a thin sheet (depth noise below the lateral
+        // spacing, the reference's rig geometry) is decided inside 15 x 15 pixels, a thick one (the synthetic bench rig: a
+        // disparity step of 0.05 pixel is 6 lateral spacings deep) needs 33 x 33; nothing decides enough: no window pass
+        int radius = pre->radius;
+        if (radius <= 0) {
+            unsigned int *d_pc = (unsigned int *)d_cnt; // (d_cnt has 4 ints)
+            unsigned int *h_pc = (unsigned int *)h_cnt;
+            const int cand[3] = {7, 12, 16};
+            double best = 0.0;
+            for (int ci = 0; ci < 3 && radius <= 0; ci++) {
+                if (hipMemsetAsync(d_pc, 0, 3 * sizeof(unsigned int), st) != hipSuccess) return RSM_E_HIP;
+                launch_sor_window(lat, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, cand[ci], d_dist, d_flag, st, 6, d_pc);
+                if (hipMemcpyAsync(h_pc, d_pc, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                    return RSM_E_HIP;
+                best = h_pc[0] ? (double)h_pc[1] / (double)h_pc[0] : 0.0;
+                if (best >= 0.85 || (ci == 2 && best >= 0.5)) {
+                    radius = cand[ci];
+                    // every query this window leaves over has its (k+1)-th neighbour beyond the window's bound (closer points
+                    // cannot hide outside it): the ladder need not start below that scale
+                    float sum_lim;
+                    memcpy(&sum_lim, &h_pc[2], sizeof sum_lim);
+                    const float h_floor = 0.7f * sum_lim / (float)h_pc[0];
+                    if (std::isfinite(h_floor) && h_floor > h) h = h_floor;
+                }
+            }
+        }
+        if (pre->radius_out) *pre->radius_out = radius > 0 ? radius : 0;
+        if (radius > 0) {
+            launch_sor_window(lat, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, radius, d_dist, d_flag, st);
+            size_t tb = 0;
+            if (rocprim::exclusive_scan(nullptr, tb, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
+            void *tp = A->get<uint8_t>(tb);
+            if (!tp) return RSM_E_NOMEM;
+            if (rocprim::exclusive_scan(tp, tb, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
+            hipLaunchKernelGGL(k_compact_list, dim3(blocks), dim3(256), 0, st, d_redo2, d_flag, d_pos, (int)n, d_redo, d_cnt);
+            if (hipMemcpyAsync(h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
+            nq = h_cnt[0];
+            queries = d_redo; // (the ladder's level l writes its own undecided list to d_redo2 / d_redo alternately, starting with d_redo2)
+            prepassed = true;
+            if (pre->undecided_out) *pre->undecided_out = nq;
+        }
+    }
     FilterGridDev G;
     for (int level = 0; level < KNN_LEVELS && nq > 0; level++, h *= 2.0f) {
         A->off = mark; // the previous level's grid is done (its kernels are ordered before this level's on the stream)
         s = build_grid(A, d_xyz, n, nv, h, glo, ghi, st, G);
         if (s != RSM_OK) return s;
-        if (level == 0) queries = G.vals; // every point, in grid order (coherent waves)
-        unsigned int *out_list = (level & 1) ? d_redo2 : d_redo;
+        if (level == 0 && !prepassed) queries = G.vals; // every point, in grid order (coherent waves)
+        unsigned int *out_list = ((level & 1) != (int)prepassed) ? d_redo2 : d_redo; // never the list being read
         launch_knn(d_xyz, G, (int)nv, h, mean_k, queries, nq, d_dist, d_flag, st);
         { // undecided queries -> the next level's list, in order
             size_t tb = 0;

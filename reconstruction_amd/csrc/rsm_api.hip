@@ -116,6 +116,8 @@ struct rsm_ctx {
     rsm_point16 *pack16 = nullptr; // the cloud as 16-byte records / the filter's output, staged for a host download (on first use)
     float *pack_nrm = nullptr;     // ... and the filter's normals
     FilterArena *filt_arena = nullptr; // the cloud filter's scratch (created on first use, grows with the cloud)
+    int opt_filter_window = 1;         // rsm_filter_last_cloud: the pixel-window k-nearest pass in front of the grid ladder (1: radius from a sparse probe; 0: off; else the radius)
+    int64_t filt_info[4]{};            // last rsm_filter_last_cloud: window pass used, queries it left to the ladder, points in, points kept
 
     // results
     double *res_disp[2]{};
@@ -531,6 +533,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
             return set_err(c, RSM_E_INVALID, "refine_skew_variant %lld: the instantiated variants are 0, 1, 2, 3, 4, 12, 28", value);
         c->opt_refine_skew_variant = (int)value;
     } else if (!strcmp(name, "shared_gpu")) c->opt_shared_gpu = value != 0;
+    else if (!strcmp(name, "filter_window")) c->opt_filter_window = (int)std::max(0LL, std::min(value, 24LL)); // 0 off, 1 default, else the radius
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "cu_share")) {
         // Contexts that share a GPU each on their own share of the compute units (the `ordinal % n`-th of n equal ranges of the
@@ -1822,9 +1825,9 @@ static int filter_params_ok(const rsm_filter_params *p) {
 }
 
 // the filter's buffers come from the context's arena: (re)sized for the cloud at hand, then the caller-visible ones first
-static int filter_buffers(rsm_ctx *c, int64_t n, bool want_normals, float **dx, int32_t **dk, float **df, float4 **dn) {
+static int filter_buffers(rsm_ctx *c, int64_t n, bool want_normals, float **dx, int32_t **dk, float **df, float4 **dn, size_t extra = 0) {
     if (!c->filt_arena) c->filt_arena = filter_arena_create();
-    const size_t own = (size_t)n * (12 + 4 + 12 + 16) + 4096;
+    const size_t own = (size_t)n * (12 + 4 + 12 + 16) + 4096 + extra;
     if (filter_arena_reserve(c->filt_arena, own + filter_arena_bytes(n)) != RSM_OK)
         return set_err(c, RSM_E_NOMEM, "cloud filter: no device memory for %lld points", (long long)n);
     *dx = (float *)filter_arena_alloc(c->filt_arena, sizeof(float) * 3 * (size_t)n);
@@ -1870,18 +1873,59 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
     float *dx, *df;
     int32_t *dk;
     float4 *dn;
-    const int sb = filter_buffers(c, n, d_normals != nullptr, &dx, &dk, &df, &dn);
+    // The cloud is the depth map this context just made: its pixel lattice (k_cloud's flags and row offsets are still in place)
+    // decides most k-nearest queries (k_filter.hip: k_sor_window).  Needs R_final to be a rotation (distances in the cloud =
+    // distances in the camera frame); anything else takes the generic search.
+    const int k = c->N - 1;
+    const Mg &mg = c->mg[k][0];
+    FilterLattice lat{};
+    bool use_lat = c->opt_filter_window && mg.XR >= mg.XL && mg.YR >= mg.YL;
+    if (use_lat) {
+        const double *R = c->in.R_final;
+        for (int i = 0; i < 3 && use_lat; i++)
+            for (int j = 0; j < 3; j++) {
+                double d = 0.0;
+                for (int l = 0; l < 3; l++) d += R[3 * l + i] * R[3 * l + j];
+                if (!(fabs(d - (i == j ? 1.0 : 0.0)) < 1e-9)) use_lat = false;
+            }
+        const double scale = (double)c->Wk[0] / c->in.origin_width * (1 << k); // .cpp:692
+        lat.flags = (const uint8_t *)c->d16a[0];
+        lat.row_offset = c->row_offset;
+        lat.W = c->Wk[k];
+        lat.XL = mg.XL, lat.XR = mg.XR, lat.YL = mg.YL, lat.YR = mg.YR;
+        lat.xyz64 = c->xyz;
+        lat.qz = c->in.Q[11] * scale;
+        memcpy(lat.R, c->in.R_final, sizeof lat.R);
+        memcpy(lat.T, c->in.T_final, sizeof lat.T);
+        if (!(fabs(lat.qz) > 0.0) || !std::isfinite(lat.qz)) use_lat = false;
+    }
+    int left = -1;
+    lat.undecided_out = &left;
+    int used_radius = 0;
+    lat.radius_out = &used_radius;
+    lat.radius = c->opt_filter_window <= 1 ? 0 : (c->opt_filter_window <= 7 ? 7 : (c->opt_filter_window <= 12 ? 12 : (c->opt_filter_window <= 16 ? 16 : (c->opt_filter_window <= 20 ? 20 : 24))));
+    const int sb = filter_buffers(c, n, d_normals != nullptr, &dx, &dk, &df, &dn, use_lat ? cloud_lattice_bytes(mg.XL, mg.XR, mg.YL, mg.YR) + 4096 : 0);
     if (sb != RSM_OK) return sb;
     launch_f64_to_f32x3(c->xyz, n, dx, c->stream); // InsertPoint's cast, CCloudOptimization.cpp:61
     int64_t m = 0;
     const int s = filter_cloud_device(c->filt_arena, dx, n, prm->sor_mean_k, prm->sor_std_mul, prm->normal_radius, prm->cam_center, dk, df, dn, &m, stats,
-                                      c->stream);
+                                      c->stream, use_lat ? &lat : nullptr);
     if (s != RSM_OK) return set_err(c, s, "cloud filter failed");
+    c->filt_info[0] = left >= 0 ? used_radius : 0;
+    c->filt_info[1] = left >= 0 ? left : 0;
+    c->filt_info[2] = n;
+    c->filt_info[3] = m;
     if (m > max_points) return set_err(c, RSM_E_INVALID, "rsm_filter_last_cloud: %lld points survive, capacity %lld", (long long)m, (long long)max_points);
     if (m > 0 && d_points) launch_pack_filtered16(c->xyz, c->bgr, dk, m, d_points, c->stream);
     if (m > 0 && d_normals) HIPCHK(c, hipMemcpyAsync(d_normals, dn, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
     *n_kept = m;
     return finish(c, t);
+}
+
+extern "C" int rsm_filter_last_info(rsm_ctx *c, int64_t info[4]) {
+    if (!c || !info) return RSM_E_INVALID;
+    memcpy(info, c->filt_info, sizeof c->filt_info);
+    return RSM_OK;
 }
 
 extern "C" int rsm_filter_last_cloud_host(rsm_ctx *c, const rsm_filter_params *prm, rsm_point16 *h_points, float *h_normals,

@@ -163,8 +163,23 @@ void filter_arena_destroy(FilterArena *a);
 size_t filter_arena_bytes(int64_t n);                      // scratch one filter call needs for n points
 int filter_arena_reserve(FilterArena *a, size_t bytes);    // makes room, rewinds the arena
 void *filter_arena_alloc(FilterArena *a, size_t bytes);    // caller buffers that live across the call (nullptr: full)
+// The cloud as the depth map it is (rsm_filter_last_cloud): which pixels of the top level's margin box emitted a point (k_cloud's
+// flags + per-row offsets: point index = compaction order), the fp64 points, and the geometry that bounds how far a point outside
+// a pixel window can be (k_filter.hip: k_sor_window).  R_final must be a rotation (the caller checks).
+struct FilterLattice {
+    const uint8_t *flags;
+    const int64_t *row_offset;
+    int W, XL, XR, YL, YR;
+    const double *xyz64;
+    double qz;          // Q[2][3] * scale (CStereoMatching.cpp:698)
+    double R[9], T[3];  // R_final, T_final (host copies)
+    int radius;         // window radius in pixels: 7, 12, 16, 20 or 24; 0 = chosen from a sparse probe (7 / 12 / 16, or no window pass)
+    int *radius_out;    // optional: the radius used (0: the probe found no window worth its pass)
+    int *undecided_out; // optional: queries the window pass left to the grid ladder
+};
+size_t cloud_lattice_bytes(int XL, int XR, int YL, int YR);
 int filter_cloud_device(FilterArena *a, const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius,
                         const float cam_center[3], int32_t *d_kept_index, float *d_fxyz, float4 *d_normals, int64_t *n_kept,
-                        double stats[4], hipStream_t st);
+                        double stats[4], hipStream_t st, const FilterLattice *pre = nullptr);
 void launch_f64_to_f32x3(const double *src, int64_t n, float *dst, hipStream_t st);
 void launch_pack_filtered16(const double *xyz, const uint8_t *bgr, const int32_t *kept, int64_t m, void *dst16, hipStream_t st);

@@ -86,6 +86,69 @@ def test_filter_of_a_matched_pair_on_device_equals_the_host_entry(ctx):
     assert np.array_equal(fx, res.xyz[kept].astype(np.float32)) and np.array_equal(fn, nrm, equal_nan=True)
 
 
+PAIRS_W = [dict(width=320, height=192, levels=3, radius=2, pair=4, mask_l0_width=60, border_l0=4),
+           dict(width=512, height=384, levels=5, radius=3, offset=2, pair=21, mask_l0_width=16, holes=True, occlude=True),
+           dict(width=384, height=256, levels=3, radius=2, pair=2, mask_kind="ellipse"),
+           dict(width=320, height=160, levels=2, radius=4, pair=7, mask_l0_width=100, border_l0=6, occlude=True),
+           dict(width=256, height=192, levels=3, radius=2, pair=5, mask_l0_width=40, border_l0=4, holes=True),
+           # large disparities: f / d = 6, the depth resolution of a close-range rig like the reference's -- a THIN sheet
+           dict(width=512, height=256, levels=3, radius=2, pair=6, mask_l0_width=70, border_l0=4, d0_l0=25.0, amp_l0=2.0, holes=True)]
+
+
+def _filter_sig(ctx, k, cam, window):
+    ctx.set_option("filter_window", window)
+    try:
+        rec, nrm, st = ctx.filter_last_cloud_host(k, 1.0, 2.5, cam)
+        info = ctx.filter_last_info()
+    finally:
+        ctx.set_option("filter_window", 1)
+    return (rec.tobytes(), nrm.tobytes(), (st["mean"], st["stddev"], st["threshold"]), len(rec)), info
+
+
+@pytest.mark.parametrize("case", range(len(PAIRS_W)))
+@pytest.mark.parametrize("k", [100, 30])
+def test_pixel_window_pass_gives_the_generic_searchs_results(ctx, case, k):
+    """rsm_filter_last_cloud's pixel-window k-nearest pass (round 5: the cloud of a matched pair is a depth map, so the k
+    nearest of a point lie inside a pixel window around its own pixel whenever the (k+1)-th smallest distance found there is
+    below the distance to every ray outside the window -- decided per point, a query per lane; the rest goes to the grid
+    ladder) against the same call with the pass switched off (every query through the generic grid search): the same
+    surviving points, the same normals, the same statistics, to the bit -- for the probed radius and for every instantiated
+    one (7, 12, 16, 20, 24), on rectangular and elliptic masks, holes, occlusions (depth edges), both disparity signs,
+    rotated rigs (R_final != I for pair > 0), thick sheets (small disparities: depth noise of many pixel spacings) and a thin
+    one (large disparities), k = 100 and 30."""
+    cfg = synth.config_small(**PAIRS_W[case])
+    res = ctx.match_pair(cfg)
+    assert res.n_points > 5000
+    cam = (3.0 * case, -2.0, 1.0)
+    want, info0 = _filter_sig(ctx, k, cam, 0)
+    assert info0["radius"] == 0 and info0["points"] == res.n_points and info0["kept"] == want[3] and 0 < want[3] < res.n_points
+    for window in (1, 7, 12, 16, 20, 24):
+        got, info = _filter_sig(ctx, k, cam, window)
+        print("case %d k %d window %d: %d points, radius %d, %d (%.1f %%) left to the ladder" % (case, k, window, res.n_points, info["radius"], info["undecided"],
+                                                                                     100.0 * info["undecided"] / res.n_points))
+        assert got == want, (case, k, window)
+        if window > 1:
+            assert info["radius"] == window
+    thin = "d0_l0" in PAIRS_W[case]
+    if thin and k == 100:   # the thin sheet: the probe settles for the small window, which decides nearly everything
+        got, info = _filter_sig(ctx, k, cam, 1)
+        assert info["radius"] == 7 and info["undecided"] < 0.15 * res.n_points, info
+
+
+def test_pixel_window_pass_against_the_brute_force_oracle(ctx):
+    """... and against oracle/cloud_oracle.c (PCL's statistical outlier removal restated by brute force) on a pair small enough
+    for O(n^2): the kept set and the statistics' bits."""
+    cfg = synth.config_small(width=256, height=192, levels=3, radius=2, pair=5, mask_l0_width=40, border_l0=4, holes=True)
+    res = ctx.match_pair(cfg)
+    xyz = res.xyz.astype(np.float32)
+    keep_o, dist_o, (mean_o, std_o, thr_o) = orc.sor_filter(xyz, 100, 1.0)
+    rec, nrm, st = ctx.filter_last_cloud_host(100, 1.0, 2.5, (0.0, 0.0, 0.0))
+    assert ctx.filter_last_info()["window"]
+    assert (st["mean"], st["stddev"], st["threshold"]) == (mean_o, std_o, thr_o)
+    want = xyz[keep_o]
+    assert len(rec) == len(want) and np.array_equal(np.stack([rec["x"], rec["y"], rec["z"]], 1), want, equal_nan=True)
+
+
 @pytest.mark.parametrize("n,k", [(150, 100), (101, 100), (50, 100), (7, 100), (2, 5), (1, 3)])
 def test_tiny_clouds_follow_the_oracle(ctx, n, k):
     """Clouds around and below k + 1 points (every query ends in the whole-cloud search; with fewer than k + 1 points the
