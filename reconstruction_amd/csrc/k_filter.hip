@@ -1209,7 +1209,8 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
                     // cannot hide outside it): the ladder need not start below that scale
                     float sum_lim;
                     memcpy(&sum_lim, &h_pc[2], sizeof sum_lim);
-                    const float h_floor = 0.7f * sum_lim / (float)h_pc[0];
+                    // (1.25 x the mean bound: a level at the bound itself would decide almost none of them)
+                    const float h_floor = 1.25f * sum_lim / (float)h_pc[0];
                     if (std::isfinite(h_floor) && h_floor > h) h = h_floor;
                 }
             }
