@@ -695,6 +695,7 @@ def adapter_bench(cfgs, n_pairs, inflight, v_top):
                               "normals come down instead of the raw cloud and are copied out per pair"}
         res = {}
         for key, flags, n in (("records16", 0, n_pairs), ("gpu_filter", 2, n_pairs), ("fp64", 1, min(n_pairs, 6))):
+            flags |= int(os.environ.get("RSM_ADAPTER_FLAGS_EXTRA", "0"))   # (A/B of the adapter's options, e.g. 4 = no input staging)
             r = subprocess.run([exe, os.path.join(tmp, "in.bin"), str(n), str(inflight), "0", str(flags), "1"], capture_output=True, text=True, env=env, timeout=300)
             if r.returncode != 0:
                 raise RuntimeError("adapter_bench (%s) rc %d: %s" % (key, r.returncode, r.stderr[-200:]))

@@ -110,6 +110,9 @@ public:
     bool want_disparity;              // download the fp64 disparity maps too (into `disparity`)
     std::vector<double> disparity[2]; // the LAST replayed pair's maps when want_disparity (the reference's local, .cpp:22)
     bool fp64_points;                 // download fp64 xyz + BGR (27 B per point) instead of the 16-byte records
+    bool stage_inputs;                // (default) a slot's worker copies the pair's images / masks into page-locked staging of its own before
+                                      // the upload: the reference's cv::Mats are pageable, and the runtime's own staging of pageable uploads is
+                                      // serialised across threads -- five workers copying in parallel keep the DMA at the link's rate
     rsm_filter_params filter_params;  // MatchAllFiltered: CReconstruction.cpp:18's values (100, 1, 2.5); cam_center comes from the traits
 
     // One pair, synchronous.  A failed pair (e.g. RSM_E_DEGENERATE_MARGIN, the reference's exit(0) at .cpp:827-830)
@@ -157,11 +160,13 @@ private:
         bool have_disp, have_fp64, have_nrm;
         rsm_point16 *pts;
         float *nrm;
+        unsigned char *stage; // page-locked copy of the pair's inputs (2 images + 2 masks), or 0
+        bool staged;
         double *xyz, *disp[2];
         unsigned char *bgr;
         std::string err;
         Slot() : ctx(0), device(0), state(IDLE), pair(-1), run_status(RSM_OK), dump(false), filtered(false), busy(false), n_kept(0), cap_px(0),
-                 have_disp(false), have_fp64(false), have_nrm(false), pts(0), nrm(0), xyz(0), bgr(0) {
+                 have_disp(false), have_fp64(false), have_nrm(false), pts(0), nrm(0), stage(0), staged(false), xyz(0), bgr(0) {
             disp[0] = disp[1] = 0;
             memset(&in, 0, sizeof in);
             memset(&out, 0, sizeof out);
@@ -176,6 +181,7 @@ private:
     void init(const std::vector<int> &devices, int per_device) {
         want_disparity = false;
         fp64_points = false;
+        stage_inputs = true;
         memset(&filter_params, 0, sizeof filter_params);
         filter_params.sor_mean_k = 100; // CReconstruction.cpp:18
         filter_params.sor_std_mul = 1.0;
@@ -193,6 +199,8 @@ private:
     static void free_buffers(Slot &s) {
         rsm_host_free(s.pts);
         rsm_host_free(s.nrm);
+        rsm_host_free(s.stage);
+        s.stage = 0;
         rsm_host_free(s.xyz);
         rsm_host_free(s.bgr);
         rsm_host_free(s.disp[0]);
@@ -237,6 +245,20 @@ private:
     }
     // upload -> run -> download of the slot's pair (worker thread, or the caller's for MatchPair)
     static void run_slot(Slot &s) {
+        if (s.staged) { // pageable -> page-locked on this worker's core; the upload below is then one DMA per buffer
+            const size_t px = (size_t)s.in.width * s.in.height;
+            unsigned char *d = s.stage;
+            for (int v = 0; v < 2; v++) {
+                memcpy(d, s.in.image[v], px * 3);
+                s.in.image[v] = d;
+                d += px * 3;
+            }
+            for (int v = 0; v < 2; v++) {
+                memcpy(d, s.in.mask[v], px);
+                s.in.mask[v] = d;
+                d += px;
+            }
+        }
         if (!s.filtered) {
             s.run_status = rsm_match_pair(s.ctx, &s.in, &s.out);
         } else { // ... with the per-pair cloud filter in between: only what survives it (and its normals) comes down
@@ -286,6 +308,7 @@ private:
             const bool keep_fp64 = fp64 || s.have_fp64, keep_nrm = filtered || s.have_nrm;
             free_buffers(s);
             s.pts = (rsm_point16 *)rsm_host_alloc(px * sizeof(rsm_point16));
+            s.stage = stage_inputs ? (unsigned char *)rsm_host_alloc(px * 8) : 0; // (no staging memory: the plain pageable upload)
             if (keep_nrm) s.nrm = (float *)rsm_host_alloc(px * 4 * sizeof(float));
             if (keep_fp64) {
                 s.xyz = (double *)rsm_host_alloc(px * 3 * sizeof(double));
@@ -304,6 +327,7 @@ private:
             s.have_fp64 = keep_fp64;
             s.have_nrm = keep_nrm;
         }
+        s.staged = stage_inputs && s.stage != 0;
         memset(&s.out, 0, sizeof s.out);
         for (int v = 0; v < 2; v++) s.out.disparity[v] = want_disparity ? s.disp[v] : 0;
         if (filtered) { // the raw cloud stays on the GPU; only counts and margins come down before the filter

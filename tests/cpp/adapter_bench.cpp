@@ -4,7 +4,8 @@
 // Built and run by bench.py (value_adapter_pcie_inclusive) and tests/test_gpu_cpp_adapter.py.
 //   adapter_bench <in.bin> <n_pairs_total> <pairs_in_flight> [want_disparity] [flags] [n_devices]
 //   flags (bit set): 1 fp64 points over PCIe (27 B per point; default: the 16-byte records); 2 MatchAllFiltered (the per-pair
-//   cloud filter on the GPU inside the loop, CCloudOptimization.cpp:82-121); n_devices: the first n visible GPUs, pairs_in_flight
+//   cloud filter on the GPU inside the loop, CCloudOptimization.cpp:82-121); 4 no page-locked input staging (the images go up
+//   from pageable memory through the runtime's own staging: A/B); n_devices: the first n visible GPUs, pairs_in_flight
 //   slots on each (default 1 = device 0; 0 = all)
 // in.bin: the format of mock_adapter.cpp; its pairs are cycled until n_pairs_total pairs have been matched.  One
 // untimed MatchAll over pairs_in_flight pairs first (contexts, workspaces, page-locked buffers), then the timed one.
@@ -114,6 +115,7 @@ int main(int argc, char **argv) {
     if (!gpu.Ok()) { fprintf(stderr, "%s\n", gpu.LastError()); return 3; }
     gpu.want_disparity = want_disp;
     gpu.fp64_points = (flags & 1) != 0;
+    gpu.stage_inputs = (flags & 4) == 0; // 4: the plain pageable upload (A/B)
     const bool filtered = (flags & 2) != 0;
     s.cloud.assign(px * 3, 0.0f); // a cloud can hold a point per pixel
     s.fill = 0;
