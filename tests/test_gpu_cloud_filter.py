@@ -66,7 +66,9 @@ def test_filter_of_a_matched_pair_on_device_equals_the_host_entry(ctx):
     rec = torch.empty((res.n_points, 16), dtype=torch.uint8, device="cuda:0")
     nd = torch.empty((res.n_points, 4), dtype=torch.float32, device="cuda:0")
     m, st2 = ctx.filter_last_cloud(rec.data_ptr(), nd.data_ptr(), res.n_points, 100, 1.0, 2.5, cam)
-    assert m == len(kept) and st2 == st and 0 < m < res.n_points
+    # (the statistics' bits; "exhaustive" -- how many queries ended in the whole-cloud search -- is a diagnostic of the route taken:
+    # the device entry decides most queries on the pixel lattice and starts its grid ladder elsewhere)
+    assert m == len(kept) and 0 < m < res.n_points and all(st2[k] == st[k] for k in ("mean", "stddev", "threshold"))
     xyz16, bgr16 = unpack_records(rec[:m])
     assert np.array_equal(xyz16, res.xyz[kept].astype(np.float32)) and np.array_equal(bgr16, res.bgr[kept])
     assert np.array_equal(nd[:m].cpu().numpy(), nrm, equal_nan=True)
