@@ -242,6 +242,8 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          chip in turns); 0 / 1 = the whole chip.  The masked streams are BLOCKING streams
  *                          (hipExtStreamCreateWithCUMask has no non-blocking flag): legacy null-stream work of the process then
  *                          synchronises with them.  RSM_E_STATE while the context is inside rsm_run_pair
+ *   "filter_list"          ... its list passes (a thread per query the tile pass left over, windows read from the lattice copy): bit 0
+ *                          the 49 x 49 pass, bit 1 the 81 x 81 pass on what that leaves; default 3, 0 = tile pass + grid ladder only
  *   "filter_window"        rsm_filter_last_cloud's pixel-window pass: 1 (default) radius from a sparse probe, 0 off (the generic grid
  *                          search decides every query), 7 / 12 / 16 / 20 / 24 that radius
  *   "shared_gpu" = 1       the caller's hint that other contexts use this context's GPU (pairs in flight): the lone-pair split

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
 // scan finds the bin holding rank k + 1, pass 2 sums sqrt(d2) of the bins below it in double (exact, order-free) and lists
 // the few values of that bin, whose rank-th smallest is tau.  ~120 wave-instructions per query against ~2000 of the
 // wave-per-query grid search.
-#define WIN_PAD 24  // invalid-pixel border of the lattice copy (>= the largest window radius): no bounds checks in the loops
+#define WIN_PAD 40  // invalid-pixel border of the lattice copy (>= the largest window radius): no bounds checks in the loops
 #define WIN_TX 32
 #define WIN_TY 8
 #define WIN_NB 32   // distance bins per query over [0, bound^2): the rank's bin holds ~1.5 (k + 1) / (its index) values, a handful
@@ -363,7 +363,8 @@ struct WinGeom {
 // lattice copy of the cloud: float4 (x, y, z as InsertPoint keeps them, bits of the point index) per flagged pixel of the
 // margin's box, NaN elsewhere (the buffer is pre-filled); block = row, the compaction order of k_cloud<1>
 __global__ __launch_bounds__(256) void k_cloud_lattice(const uint8_t *__restrict__ flags, const int64_t *__restrict__ row_offset, int W, int XL, int XR, int YL,
-                                                        const double *__restrict__ xyz, int64_t n, int gw, float4 *__restrict__ lat) {
+                                                        const double *__restrict__ xyz, int64_t n, int gw, float4 *__restrict__ lat,
+                                                        unsigned int *__restrict__ cell_of) {
     __shared__ int s_w[4];
     __shared__ long long s_base;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -381,8 +382,10 @@ __global__ __launch_bounds__(256) void k_cloud_lattice(const uint8_t *__restrict
             for (int w = 0; w < wid; w++) pos += s_w[w];
             if (pos < n) {
                 const float px = (float)xyz[3 * pos], py = (float)xyz[3 * pos + 1], pz = (float)xyz[3 * pos + 2]; // InsertPoint's cast
+                const size_t cell = (size_t)(blockIdx.x + WIN_PAD) * gw + (x - XL + WIN_PAD);
+                cell_of[pos] = (unsigned int)cell;
                 if (isfinite(px) && isfinite(py) && isfinite(pz)) // (non-finite points take no part in the searches)
-                    lat[(size_t)(blockIdx.x + WIN_PAD) * gw + (x - XL + WIN_PAD)] = make_float4(px, py, pz, __uint_as_float((unsigned int)pos));
+                    lat[cell] = make_float4(px, py, pz, __uint_as_float((unsigned int)pos));
             }
         }
         __syncthreads();
@@ -391,6 +394,133 @@ __global__ __launch_bounds__(256) void k_cloud_lattice(const uint8_t *__restrict
     }
 }
 
+// One query of the pixel-window search: P = the query's lattice entry, ld(r, c) = the lattice entry at window row r / column c
+// (0 .. 2 WR), col = the thread's private LDS column (stride 256 words: WIN_NB + 1 words of counters, later the list), CH = the
+// candidates whose reads are in flight together (a divisor of 2 WR + 1).  Returns whether the query is decided; *out = its mean
+// neighbour distance, *lim_out = the bound.
+template <int WR, int CH, class Loader>
+__device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, const WinGeom &g, int mean_k, unsigned int *col, float *out, double *lim_out) {
+    constexpr int NC = 2 * WR + 1;
+    static_assert(NC % CH == 0, "whole chunks");
+    // the bound and its rounding margin, in double (once per query)
+    const double dx = (double)P.x - g.T[0], dy = (double)P.y - g.T[1], dz = (double)P.z - g.T[2];
+    const double F2 = fabs(g.rz[0] * dx + g.rz[1] * dy + g.rz[2] * dz), nP = sqrt(dx * dx + dy * dy + dz * dz);
+    const double iw = F2 / fabs(g.qz);                                   // |iW|: the lateral spacing of adjacent pixels at this depth
+    const double LB = F2 * (WR + 1) / (nP / fmax(iw, 1e-300) + (WR + 1));
+    const double coord = fmax(fmax(fabs((double)P.x), fabs((double)P.y)), fabs((double)P.z)) + nP;
+    const double lim = LB * (1.0 - 1e-5) - 4e-7 * coord; // float32 coordinates and float32 distance arithmetic: relative 1e-7 each
+    *lim_out = lim;
+    const float range = (lim > 0.0) ? (float)(lim * lim * (1.0 - 1e-6)) : 0.0f; // tau must stay below this; the bins cover [0, range)
+    const int want = mean_k + 1;
+    const float inv_w = (range > 0.0f) ? (float)WIN_NB / range : 0.0f;
+    if (!(range > 0.0f && inv_w > 0.0f && isfinite(inv_w))) return false;
+    auto bin_of = [&](float d2) { return min((int)(d2 * inv_w), WIN_NB - 1); }; // monotone in d2
+    // A chunk of a window row at a time: all its reads first (16-byte reads, in flight together), then the arithmetic -- a read,
+    // its wait and a data-dependent branch per candidate would expose the read latency (2 x 1089 times per query at WR = 16).
+    auto chunk_d2 = [&](int r, int c0, float (&d2)[CH]) {
+        float4 o[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            o[i] = ld(r, c0 + i);
+            asm volatile("" : "+v"(o[i].w)); // (keeps the read a 16-byte one: twice the LDS rate of the 12-byte form)
+        }
+#pragma unroll
+        for (int i = 0; i < CH; i++) d2[i] = fdist2(P.x, P.y, P.z, o[i].x, o[i].y, o[i].z); // NaN for a pixel without a point: every test below fails
+    };
+    // pass 1: histogram of the window's squared distances (the point itself included: d2 = 0, as nearestKSearch(k + 1)); branch-free:
+    // what lies beyond the bound goes to the sink row
+#pragma unroll 1
+    for (int r = 0; r < NC; r++) {
+#pragma unroll 1
+        for (int c0 = 0; c0 < NC; c0 += CH) {
+            float d2[CH];
+            chunk_d2(r, c0, d2);
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int b = (d2[i] < range) ? bin_of(d2[i]) : WIN_NB;
+#if defined(WIN_EXP) && (WIN_EXP & 1) // timing experiment (results invalid): no histogram updates
+                asm volatile("" ::"v"(b));
+#else
+                atomicAdd(col + 256 * b, 1u); // (no return value: a fire-and-forget ds_add)
+#endif
+            }
+        }
+    }
+    // the bin holding rank `want`
+    int below = 0, bstar = -1, in_bin = 0;
+#pragma unroll 1
+    for (int b = 0; b < WIN_NB; b++) {
+        const int h = (int)col[256 * b];
+        if (bstar < 0 && below + h >= want) {
+            bstar = b;
+            in_bin = h;
+        }
+        if (bstar < 0) below += h;
+    }
+    if (!(bstar >= 0 && in_bin <= WIN_LCAP)) return false; // fewer than k + 1 points within the bound in the window, or too many (nearly) equal distances
+    // pass 2: the exact sum below the bin, the bin's values listed (over the counters: they are dead now).  The bin tests become
+    // two float compares: t_lo / t_hi = the smallest floats whose bin is >= bstar / > bstar (bin_of is monotone)
+    float *lst = (float *)col;
+    double sum = 0.0;
+    int nl = 0;
+    auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB - 1
+        float t = (float)b / inv_w;
+        while (t > 0.0f && bin_of(__uint_as_float(__float_as_uint(t) - 1u)) >= b) t = __uint_as_float(__float_as_uint(t) - 1u);
+        while (bin_of(t) < b) t = __uint_as_float(__float_as_uint(t) + 1u);
+        return t;
+    };
+    const float t_lo = bstar > 0 ? first_in(bstar) : 0.0f;
+    const float t_hi = bstar < WIN_NB - 1 ? fminf(first_in(bstar + 1), range) : range;
+#pragma unroll 1
+    for (int r = 0; r < NC; r++) {
+#if defined(WIN_EXP) && (WIN_EXP & 2) // timing experiment (results invalid): no second pass
+        break;
+#endif
+#pragma unroll 1
+        for (int c0 = 0; c0 < NC; c0 += CH) {
+            float d2[CH];
+            chunk_d2(r, c0, d2);
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                if (d2[i] < t_lo) sum += (double)sqrtf(d2[i]);
+                else if (d2[i] < t_hi) {
+                    lst[nl * 256] = d2[i];
+                    nl++;
+                }
+            }
+        }
+    }
+    // tau = the (want - below)-th smallest of the listed values (by value: ties are equal distances)
+    const int rank = want - below; // 1 .. in_bin
+    float tau = 0.0f;
+    int less = 0;
+#pragma unroll 1
+    for (int i = 0; i < nl; i++) {
+        const float v = lst[i * 256];
+        int lt = 0, le = 0;
+#pragma unroll 1
+        for (int j = 0; j < nl; j++) {
+            const float u = lst[j * 256];
+            lt += u < v;
+            le += u <= v;
+        }
+        if (lt < rank && rank <= le) { // v is the rank-th smallest
+            tau = v;
+            less = lt;
+        }
+    }
+#pragma unroll 1
+    for (int i = 0; i < nl; i++) {
+        const float v = lst[i * 256];
+        if (v < tau) sum += (double)sqrtf(v);
+    }
+    if (!(nl == in_bin && tau < range)) return false;
+    // every point outside the window is farther than sqrt(tau): the k + 1 smallest are all here
+    *out = (float)((sum + (double)(want - (below + less)) * (double)sqrtf(tau)) / mean_k);
+    return true;
+}
+
+// Tile form: a workgroup = a 32 x 8 tile of pixels, its window halo staged in LDS, a thread = the query of its pixel.
 // PROBE: every `tile_step`-th tile in x and y only, nothing written but three counters (queries seen, queries decided, the sum of
 // their bounds): the host picks the smallest window radius that decides most of a sparse sample before it pays for the full pass.
 template <int WR, bool PROBE>
@@ -409,132 +539,17 @@ __global__ __launch_bounds__(256) void k_sor_window(const float4 *__restrict__ l
         s_t[r][c] = lat[(size_t)gy * g.gw + gx];
     }
 #pragma unroll
-    for (int b = 0; b < WIN_NB; b++) s_u[b][tid] = 0u;
+    for (int b = 0; b <= WIN_NB; b++) s_u[b][tid] = 0u;
     __syncthreads();
     const float4 P = s_t[ty + WR][tx + WR];
     const bool valid = P.x == P.x; // NaN: no point at this pixel
     if (!__syncthreads_or(valid)) return;
-    // the bound and its rounding margin, in double (once per query)
-    const double dx = (double)P.x - g.T[0], dy = (double)P.y - g.T[1], dz = (double)P.z - g.T[2];
-    const double F2 = fabs(g.rz[0] * dx + g.rz[1] * dy + g.rz[2] * dz), nP = sqrt(dx * dx + dy * dy + dz * dz);
-    const double iw = F2 / fabs(g.qz);                                   // |iW|: the lateral spacing of adjacent pixels at this depth
-    const double LB = F2 * (WR + 1) / (nP / fmax(iw, 1e-300) + (WR + 1));
-    const double coord = fmax(fmax(fabs((double)P.x), fabs((double)P.y)), fabs((double)P.z)) + nP;
-    const double lim = LB * (1.0 - 1e-5) - 4e-7 * coord; // float32 coordinates and float32 distance arithmetic: relative 1e-7 each
-    const float range = (lim > 0.0) ? (float)(lim * lim * (1.0 - 1e-6)) : 0.0f; // tau must stay below this; the bins cover [0, range)
-    const int want = mean_k + 1;
-    const float inv_w = (range > 0.0f) ? (float)WIN_NB / range : 0.0f;
-    bool ok = valid && range > 0.0f && inv_w > 0.0f && isfinite(inv_w);
-    auto bin_of = [&](float d2) { return min((int)(d2 * inv_w), WIN_NB - 1); }; // monotone in d2
-    // One row of the window at a time: all its LDS reads first (16-byte reads, in flight together), then the arithmetic -- a read,
-    // its wait and a data-dependent branch per candidate would expose the LDS latency (2 x 1089 times per query at WR = 16).
-    constexpr int NC = 2 * WR + 1;
-    auto row_d2 = [&](int r, float (&d2)[NC]) {
-        float4 o[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            o[c] = s_t[ty + r][tx + c];
-            asm volatile("" : "+v"(o[c].w)); // (keeps the read a ds_read_b128: twice the LDS rate of the 12-byte form)
-        }
-#pragma unroll
-        for (int c = 0; c < NC; c++) d2[c] = fdist2(P.x, P.y, P.z, o[c].x, o[c].y, o[c].z); // NaN for a pixel without a point: every test below fails
-    };
-    // pass 1: histogram of the window's squared distances (the point itself included: d2 = 0, as nearestKSearch(k + 1)); branch-free:
-    // what lies beyond the bound goes to the sink row
-    if (ok) {
-        unsigned int *mine = &s_u[0][tid];
-#pragma unroll 1
-        for (int r = 0; r < NC; r++) {
-            float d2[NC];
-            row_d2(r, d2);
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const int b = (d2[c] < range) ? bin_of(d2[c]) : WIN_NB;
-#if defined(WIN_EXP) && (WIN_EXP & 1) // timing experiment (results invalid): no histogram updates
-                asm volatile("" ::"v"(b));
-#else
-                atomicAdd(mine + 256 * b, 1u); // (no return value: a fire-and-forget ds_add)
-#endif
-            }
-        }
-    }
-    // the bin holding rank `want`
-    int below = 0, bstar = -1, in_bin = 0;
-    if (ok) {
-#pragma unroll 1
-        for (int b = 0; b < WIN_NB; b++) {
-            const int h = (int)s_u[b][tid];
-            if (bstar < 0 && below + h >= want) {
-                bstar = b;
-                in_bin = h;
-            }
-            if (bstar < 0) below += h;
-        }
-        ok = bstar >= 0 && in_bin <= WIN_LCAP; // fewer than k + 1 points within the bound in the window, or too many (nearly) equal distances
-    }
-    // pass 2: the exact sum below the bin, the bin's values listed (over the counters: they are dead now).  The bin tests become
-    // two float compares: t_lo / t_hi = the smallest floats whose bin is >= bstar / > bstar (bin_of is monotone)
-    float *lst = (float *)&s_u[0][0];
-    double sum = 0.0;
-    int nl = 0;
-    if (ok) {
-        auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB - 1
-            float t = (float)b / inv_w;
-            while (t > 0.0f && bin_of(__uint_as_float(__float_as_uint(t) - 1u)) >= b) t = __uint_as_float(__float_as_uint(t) - 1u);
-            while (bin_of(t) < b) t = __uint_as_float(__float_as_uint(t) + 1u);
-            return t;
-        };
-        const float t_lo = bstar > 0 ? first_in(bstar) : 0.0f;
-        const float t_hi = bstar < WIN_NB - 1 ? fminf(first_in(bstar + 1), range) : range;
-#pragma unroll 1
-        for (int r = 0; r < NC; r++) {
-#if defined(WIN_EXP) && (WIN_EXP & 2) // timing experiment (results invalid): no second pass
-            break;
-#endif
-            float d2[NC];
-            row_d2(r, d2);
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                if (d2[c] < t_lo) sum += (double)sqrtf(d2[c]);
-                else if (d2[c] < t_hi) {
-                    lst[nl * 256 + tid] = d2[c];
-                    nl++;
-                }
-            }
-        }
-        // tau = the (want - below)-th smallest of the listed values (by value: ties are equal distances)
-        const int rank = want - below; // 1 .. in_bin
-        float tau = 0.0f;
-        int less = 0;
-#pragma unroll 1
-        for (int i = 0; i < nl; i++) {
-            const float v = lst[i * 256 + tid];
-            int lt = 0, le = 0;
-#pragma unroll 1
-            for (int j = 0; j < nl; j++) {
-                const float u = lst[j * 256 + tid];
-                lt += u < v;
-                le += u <= v;
-            }
-            if (lt < rank && rank <= le) { // v is the rank-th smallest
-                tau = v;
-                less = lt;
-            }
-        }
-#pragma unroll 1
-        for (int i = 0; i < nl; i++) {
-            const float v = lst[i * 256 + tid];
-            if (v < tau) sum += (double)sqrtf(v);
-        }
-        if (nl == in_bin && tau < range) { // every point outside the window is farther than sqrt(tau): the k + 1 smallest are all here
-            const int nless = below + less;
-            if (!PROBE) dist[__float_as_uint(P.w)] = (float)((sum + (double)(want - nless) * (double)sqrtf(tau)) / mean_k);
-        } else {
-            ok = false;
-        }
-    }
+    auto ld = [&](int r, int c) { return s_t[ty + r][tx + c]; };
+    float res = 0.0f;
+    double lim = 0.0;
+    const bool ok = valid && win_query<WR, 2 * WR + 1>(ld, P, g, mean_k, &s_u[0][tid], &res, &lim);
     if (PROBE) {
-        const unsigned long long mv = __ballot(valid), mo = __ballot(valid && ok);
+        const unsigned long long mv = __ballot(valid), mo = __ballot(ok);
         float sl = valid ? (float)fmax(lim, 0.0) : 0.0f; // the mean bound: what the queries this radius leaves over have in common (tau >= lim^2)
         for (int o = 32; o > 0; o >>= 1) sl += __shfl_xor(sl, o);
         if ((tid & 63) == 0 && mv) {
@@ -543,23 +558,41 @@ __global__ __launch_bounds__(256) void k_sor_window(const float4 *__restrict__ l
             atomicAdd((float *)&probe_cnt[2], sl);
         }
     } else if (valid) {
+        if (ok) dist[__float_as_uint(P.w)] = res;
         undecided[__float_as_uint(P.w)] = ok ? 0u : 1u;
     }
 }
 
+// List form: a thread = one listed query (what the tile pass left over -- a seventh of a thick sheet's points, scattered), its
+// window read straight from the lattice copy in global memory (neighbouring queries share its lines in L1 / L2): the wide window
+// the scattered rest needs, at full lane occupancy, where the tile form would run a 49 x 49 window for one lane in seven.
+template <int WR, int CH>
+__global__ __launch_bounds__(256) void k_sor_window_list(const float4 *__restrict__ lat, const unsigned int *__restrict__ cell_of, WinGeom g, int mean_k,
+                                                          const unsigned int *__restrict__ list, int nq, float *__restrict__ dist, unsigned int *__restrict__ undecided) {
+    __shared__ unsigned int s_u[WIN_NB + 1][256];
+    const int tid = threadIdx.x, q = blockIdx.x * 256 + tid;
+#pragma unroll
+    for (int b = 0; b <= WIN_NB; b++) s_u[b][tid] = 0u;
+    if (q >= nq) return; // (no workgroup barrier below: the columns are private)
+    const unsigned int pt = list[q];
+    const unsigned int cell = cell_of[pt]; // the point's lattice position gy * gw + gx
+    const float4 *base = lat + (size_t)cell - (size_t)WR * g.gw - WR;
+    const float4 P = lat[cell];
+    auto ld = [&](int r, int c) { return base[(size_t)r * g.gw + c]; };
+    float res = 0.0f;
+    double lim = 0.0;
+    const bool ok = win_query<WR, CH>(ld, P, g, mean_k, &s_u[0][tid], &res, &lim);
+    if (ok) dist[pt] = res;
+    undecided[q] = ok ? 0u : 1u; // (indexed like the list: the caller compacts it into the ladder's first list)
+}
+
 void launch_cloud_lattice(const uint8_t *flags, const int64_t *row_offset, int W, int XL, int XR, int YL, int YR, const double *xyz, int64_t n, float4 *lat,
-                          hipStream_t st) {
+                          unsigned int *cell_of, hipStream_t st) {
     const int gw = XR - XL + 1 + 2 * WIN_PAD, gh = YR - YL + 1 + 2 * WIN_PAD;
     (void)hipMemsetD32Async((hipDeviceptr_t)lat, 0x7fc00000, (size_t)4 * gw * gh, st);
-    hipLaunchKernelGGL(k_cloud_lattice, dim3((unsigned)(YR - YL + 1)), dim3(256), 0, st, flags, row_offset, W, XL, XR, YL, xyz, n, gw, lat);
+    hipLaunchKernelGGL(k_cloud_lattice, dim3((unsigned)(YR - YL + 1)), dim3(256), 0, st, flags, row_offset, W, XL, XR, YL, xyz, n, gw, lat, cell_of);
 }
-size_t cloud_lattice_bytes(int XL, int XR, int YL, int YR) {
-    return sizeof(float4) * (size_t)(XR - XL + 1 + 2 * WIN_PAD) * (size_t)(YR - YL + 1 + 2 * WIN_PAD);
-}
-// the window pass over the whole lattice: dist / undecided (one entry per cloud point; undecided pre-set to 1 by the caller);
-// tile_step > 1 + probe_cnt: the sparse probe (see k_sor_window)
-void launch_sor_window(const float4 *lat, int XL, int XR, int YL, int YR, double qz, const double *R, const double *T, int mean_k, int radius, float *dist,
-                       unsigned int *undecided, hipStream_t st, int tile_step = 1, unsigned int *probe_cnt = nullptr) {
+static WinGeom win_geom(int XL, int XR, int YL, int YR, double qz, const double *R, const double *T) {
     WinGeom g;
     g.gw = XR - XL + 1 + 2 * WIN_PAD;
     g.gh = YR - YL + 1 + 2 * WIN_PAD;
@@ -568,6 +601,25 @@ void launch_sor_window(const float4 *lat, int XL, int XR, int YL, int YR, double
         g.rz[i] = R[3 * i + 2];
         g.T[i] = T[i];
     }
+    return g;
+}
+// the list form over nq listed queries at radius 24 or 40: dist (per point) / undecided (per list entry)
+void launch_sor_window_list(const float4 *lat, const unsigned int *cell_of, int XL, int XR, int YL, int YR, double qz, const double *R, const double *T, int mean_k,
+                            int radius, const unsigned int *list, int nq, float *dist, unsigned int *undecided, hipStream_t st) {
+    if (nq <= 0) return;
+    const WinGeom g = win_geom(XL, XR, YL, YR, qz, R, T);
+    const dim3 grid((unsigned)((nq + 255) / 256));
+    if (radius <= 24) hipLaunchKernelGGL((k_sor_window_list<24, 7>), grid, dim3(256), 0, st, lat, cell_of, g, mean_k, list, nq, dist, undecided);
+    else hipLaunchKernelGGL((k_sor_window_list<40, 9>), grid, dim3(256), 0, st, lat, cell_of, g, mean_k, list, nq, dist, undecided);
+}
+size_t cloud_lattice_bytes(int XL, int XR, int YL, int YR) {
+    return sizeof(float4) * (size_t)(XR - XL + 1 + 2 * WIN_PAD) * (size_t)(YR - YL + 1 + 2 * WIN_PAD);
+}
+// the window pass over the whole lattice: dist / undecided (one entry per cloud point; undecided pre-set to 1 by the caller);
+// tile_step > 1 + probe_cnt: the sparse probe (see k_sor_window)
+void launch_sor_window(const float4 *lat, int XL, int XR, int YL, int YR, double qz, const double *R, const double *T, int mean_k, int radius, float *dist,
+                       unsigned int *undecided, hipStream_t st, int tile_step = 1, unsigned int *probe_cnt = nullptr) {
+    const WinGeom g = win_geom(XL, XR, YL, YR, qz, R, T);
     const int tx = (XR - XL + 1 + WIN_TX - 1) / WIN_TX, ty = (YR - YL + 1 + WIN_TY - 1) / WIN_TY;
     const dim3 grid((unsigned)((tx + tile_step - 1) / tile_step), (unsigned)((ty + tile_step - 1) / tile_step));
 #define WIN_LAUNCH(R_)                                                                                                                     \
@@ -1184,9 +1236,10 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     bool prepassed = false;
     if (pre && mean_k <= 128 && nv > 0) { // the pixel-window pass: what it cannot decide becomes the ladder's first query list
         float4 *lat = A->get<float4>(cloud_lattice_bytes(pre->XL, pre->XR, pre->YL, pre->YR) / sizeof(float4));
-        if (!lat) return RSM_E_NOMEM;
+        unsigned int *cell_of = A->get<unsigned int>((size_t)n);
+        if (!lat || !cell_of) return RSM_E_NOMEM;
         hipLaunchKernelGGL(k_finite_flags, dim3(blocks), dim3(256), 0, st, d_xyz, n, d_flag, d_redo2);
-        launch_cloud_lattice(pre->flags, pre->row_offset, pre->W, pre->XL, pre->XR, pre->YL, pre->YR, pre->xyz64, n, lat, st);
+        launch_cloud_lattice(pre->flags, pre->row_offset, pre->W, pre->XL, pre->XR, pre->YL, pre->YR, pre->xyz64, n, lat, cell_of, st);
         // which window?  pre->radius > 0: the caller's; 0: the smallest of 7 / 12 / 16 pixels that decides >= 85 % of a sparse
         // sample of the tiles (every 6th in x and y: ~3 % of the queries) -- a thin sheet (depth noise below the lateral
         // spacing, the reference's rig geometry) is decided inside 15 x 15 pixels, a thick one (the synthetic bench rig: a
@@ -1226,8 +1279,32 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
             hipLaunchKernelGGL(k_compact_list, dim3(blocks), dim3(256), 0, st, d_redo2, d_flag, d_pos, (int)n, d_redo, d_cnt);
             if (hipMemcpyAsync(h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
             nq = h_cnt[0];
-            queries = d_redo; // (the ladder's level l writes its own undecided list to d_redo2 / d_redo alternately, starting with d_redo2)
+            queries = d_redo;
             prepassed = true;
+            if (pre->tile_left_out) *pre->tile_left_out = nq;
+            // What a window below 24 pixels leaves over (a thick sheet's points whose neighbours spread wider: scattered, a seventh
+            // of C2's cloud) gets the 49 x 49 window a thread each, straight from the lattice copy (k_sor_window_list); only what
+            // that leaves as well -- depth edges, holes, outliers -- goes to the grid ladder.
+            // What a window below 24 pixels leaves over (a thick sheet's points whose neighbours spread wider: scattered, a seventh
+            // of C2's cloud) gets the 49 x 49 window a thread each, straight from the lattice copy (k_sor_window_list); what THAT
+            // leaves -- the points within a dozen pixels of the mask's border and of depth edges, whose neighbours lie on one
+            // side: 1.6 % of C2's cloud, the queries that cost the grid ladder most (coarse levels: tens of thousands of
+            // candidates in the 27 cells of each) -- an 81 x 81 window; only the rest (holes, outliers, islands) goes to the ladder.
+            unsigned int *cur = d_redo, *oth = d_redo2;
+            const int radii[2] = {24, 40};
+            int last = radius;
+            for (int pass = 0; pass < 2 && nq > 0; pass++) {
+                if (radii[pass] <= last || !((pre->list_pass >> pass) & 1)) continue;
+                launch_sor_window_list(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, radii[pass], cur, nq, d_dist, d_flag, st);
+                if (rocprim::exclusive_scan(tp, tb, d_flag, d_pos, 0u, (size_t)nq, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
+                hipLaunchKernelGGL(k_compact_list, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, cur, d_flag, d_pos, nq, oth, d_cnt);
+                if (hipMemcpyAsync(h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
+                nq = h_cnt[0];
+                std::swap(cur, oth);
+                last = radii[pass]; // (the ladder keeps its start: what is left now is few, and a level whose 27 cells hold tens of
+                                    // thousands of candidates costs a wave-per-query search milliseconds however few the queries)
+            }
+            queries = cur;
             if (pre->undecided_out) *pre->undecided_out = nq;
         }
     }
@@ -1237,7 +1314,7 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
         s = build_grid(A, d_xyz, n, nv, h, glo, ghi, st, G);
         if (s != RSM_OK) return s;
         if (level == 0 && !prepassed) queries = G.vals; // every point, in grid order (coherent waves)
-        unsigned int *out_list = ((level & 1) != (int)prepassed) ? d_redo2 : d_redo; // never the list being read
+        unsigned int *out_list = (queries == d_redo) ? d_redo2 : d_redo; // never the list being read
         launch_knn(d_xyz, G, (int)nv, h, mean_k, queries, nq, d_dist, d_flag, st);
         { // undecided queries -> the next level's list, in order
             size_t tb = 0;

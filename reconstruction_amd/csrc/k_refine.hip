@@ -1049,6 +1049,12 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     __shared__ double2 s_exp[128];         // the specified exp's table (exp_tab_stage; 2 KB: the workgroup stays within the 32 000 B that
                                            // let five of them share a CU -- 31 632 B at T = 4)
     __shared__ uint8_t s_ml[T][64];        // per wave: the lanes of a row's misses, for the four-lanes-per-entry service
+#ifdef RF_SKEW_PAD // timing experiment: what the LDS of 24-byte cache entries (a cached reciprocal of pwp + ws beside pwp and delta: 9 216 B
+                   // more at T = 4) would cost in residency alone -- three workgroups per CU instead of five
+    __shared__ char s_pad[RF_SKEW_PAD];
+    if (threadIdx.x == 0 && a.W < 0) s_pad[a.H & 1023] = 1; // (never true: keeps the array)
+    asm volatile("" ::"v"(&s_pad[threadIdx.x]));
+#endif
     const DirArgs &d = a.d[blockIdx.z];
     const int W = a.W, H = a.H;
     const int XL = d.own.XL, XR = d.own.XR, YL = d.own.YL, YR = d.own.YR;

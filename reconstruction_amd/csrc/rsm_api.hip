@@ -116,7 +116,9 @@ struct rsm_ctx {
     rsm_point16 *pack16 = nullptr; // the cloud as 16-byte records / the filter's output, staged for a host download (on first use)
     float *pack_nrm = nullptr;     // ... and the filter's normals
     FilterArena *filt_arena = nullptr; // the cloud filter's scratch (created on first use, grows with the cloud)
+    int opt_filter_list = 3;           // ... and the 24-pixel window a thread each for what the tile pass leaves over
     int opt_filter_window = 1;         // rsm_filter_last_cloud: the pixel-window k-nearest pass in front of the grid ladder (1: radius from a sparse probe; 0: off; else the radius)
+    int64_t filt_tile_left = 0;        // ... queries the tile pass alone left over
     int64_t filt_info[4]{};            // last rsm_filter_last_cloud: window pass used, queries it left to the ladder, points in, points kept
 
     // results
@@ -533,6 +535,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
             return set_err(c, RSM_E_INVALID, "refine_skew_variant %lld: the instantiated variants are 0, 1, 2, 3, 4, 12, 28", value);
         c->opt_refine_skew_variant = (int)value;
     } else if (!strcmp(name, "shared_gpu")) c->opt_shared_gpu = value != 0;
+    else if (!strcmp(name, "filter_list")) c->opt_filter_list = (int)std::max(0LL, std::min(value, 3LL)); // bit 0: the 24-pixel list pass, bit 1: the 40-pixel one
     else if (!strcmp(name, "filter_window")) c->opt_filter_window = (int)std::max(0LL, std::min(value, 24LL)); // 0 off, 1 default, else the radius
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "cu_share")) {
@@ -1899,12 +1902,14 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
         memcpy(lat.T, c->in.T_final, sizeof lat.T);
         if (!(fabs(lat.qz) > 0.0) || !std::isfinite(lat.qz)) use_lat = false;
     }
-    int left = -1;
+    int left = -1, tile_left = -1;
     lat.undecided_out = &left;
+    lat.tile_left_out = &tile_left;
+    lat.list_pass = c->opt_filter_list;
     int used_radius = 0;
     lat.radius_out = &used_radius;
     lat.radius = c->opt_filter_window <= 1 ? 0 : (c->opt_filter_window <= 7 ? 7 : (c->opt_filter_window <= 12 ? 12 : (c->opt_filter_window <= 16 ? 16 : (c->opt_filter_window <= 20 ? 20 : 24))));
-    const int sb = filter_buffers(c, n, d_normals != nullptr, &dx, &dk, &df, &dn, use_lat ? cloud_lattice_bytes(mg.XL, mg.XR, mg.YL, mg.YR) + 4096 : 0);
+    const int sb = filter_buffers(c, n, d_normals != nullptr, &dx, &dk, &df, &dn, use_lat ? cloud_lattice_bytes(mg.XL, mg.XR, mg.YL, mg.YR) + (size_t)n * 4 + 8192 : 0);
     if (sb != RSM_OK) return sb;
     launch_f64_to_f32x3(c->xyz, n, dx, c->stream); // InsertPoint's cast, CCloudOptimization.cpp:61
     int64_t m = 0;
@@ -1913,6 +1918,7 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
     if (s != RSM_OK) return set_err(c, s, "cloud filter failed");
     c->filt_info[0] = left >= 0 ? used_radius : 0;
     c->filt_info[1] = left >= 0 ? left : 0;
+    c->filt_tile_left = tile_left >= 0 ? tile_left : 0;
     c->filt_info[2] = n;
     c->filt_info[3] = m;
     if (m > max_points) return set_err(c, RSM_E_INVALID, "rsm_filter_last_cloud: %lld points survive, capacity %lld", (long long)m, (long long)max_points);

@@ -175,7 +175,9 @@ struct FilterLattice {
     double R[9], T[3];  // R_final, T_final (host copies)
     int radius;         // window radius in pixels: 7, 12, 16, 20 or 24; 0 = chosen from a sparse probe (7 / 12 / 16, or no window pass)
     int *radius_out;    // optional: the radius used (0: the probe found no window worth its pass)
-    int *undecided_out; // optional: queries the window pass left to the grid ladder
+    int list_pass;      // 1: what the tile pass leaves over gets a 24-pixel window a thread each before the grid ladder
+    int *undecided_out; // optional: queries the window passes left to the grid ladder
+    int *tile_left_out; // optional: queries the tile pass alone left over
 };
 size_t cloud_lattice_bytes(int XL, int XR, int YL, int YR);
 int filter_cloud_device(FilterArena *a, const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius,

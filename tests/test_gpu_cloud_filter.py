@@ -124,7 +124,13 @@ def test_pixel_window_pass_gives_the_generic_searchs_results(ctx, case, k):
     cam = (3.0 * case, -2.0, 1.0)
     want, info0 = _filter_sig(ctx, k, cam, 0)
     assert info0["radius"] == 0 and info0["points"] == res.n_points and info0["kept"] == want[3] and 0 < want[3] < res.n_points
-    for window in (1, 7, 12, 16, 20, 24):
+    ctx.set_option("filter_list", 0)   # the tile pass alone in front of the ladder
+    try:
+        got, info = _filter_sig(ctx, k, cam, 12)
+    finally:
+        ctx.set_option("filter_list", 3)
+    assert got == want and info["radius"] == 12
+    for window in (1, 7, 12, 16, 20, 24):   # (default: what the tile pass leaves over gets the 24-pixel window a thread each)
         got, info = _filter_sig(ctx, k, cam, window)
         print("case %d k %d window %d: %d points, radius %d, %d (%.1f %%) left to the ladder" % (case, k, window, res.n_points, info["radius"], info["undecided"],
                                                                                      100.0 * info["undecided"] / res.n_points))
