@@ -145,12 +145,32 @@ def main():
     exchange = world > 1 or os.environ.get("RSM_BENCH_SELF_GATHER") == "1"
     transport = args.transport if (exchange and backend == "nccl") else "torch"
     comm = None
+    transport_note = None
     if exchange and transport == "rccl":
         from reconstruction_amd.dist import Comm
-        ids = [Comm.unique_id() if rank == 0 else None]
+        err = None
+        try:
+            ids = [Comm.unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001  (librccl not loadable)
+            ids, err = [None], e
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
-        comm = Comm(ids[0], rank, world, local_rank)
+        if ids[0] is not None and err is None:
+            try:
+                comm = Comm(ids[0], rank, world, local_rank)
+            except Exception as e:  # noqa: BLE001
+                err = e
+        else:
+            err = err or RuntimeError("rank 0 could not make the communicator id")
+        # every rank must take the same transport: one failure anywhere sends all of them to torch.distributed (and the line says so)
+        bad = torch.tensor([1.0 if err is not None else 0.0], device=dev)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad[0]) > 0:
+            if comm is not None:
+                comm.close()
+            comm, transport = None, "torch"
+            transport_note = "rsm_comm_create failed on some rank (%s): fell back to torch.distributed" % (str(err)[:120] if err else "another rank")
     n_pairs_total = N_RIG if rig else world * F   # pair ids of one step's gather
     if args.pmc_child:  # the profiled child of measure_traffic(): one pair, nothing else
         ctx.run_pair()
@@ -229,7 +249,11 @@ def main():
                     raise recs
                 local += recs
             if comm is not None:
-                gq.put(sorted(local, key=lambda t: t[0]))   # at most one gather in flight + one queued: the records stay alive in the queue
+                try:   # at most one gather in flight + one queued: the records stay alive in the queue
+                    gq.put(sorted(local, key=lambda t: t[0]), timeout=300)
+                except queue.Full:   # a collective that never completes must end the run with a message, not hang it
+                    print("bench.py: rsm_gather_clouds made no progress for 300 s on rank %d" % rank, file=sys.stderr, flush=True)
+                    os._exit(3)
             elif world > 1:
                 h = gather_clouds_async(sorted(local, key=lambda t: t[0]), dst=0)
                 if pending is not None:
@@ -238,8 +262,15 @@ def main():
         if pending is not None:
             pending.wait()
         if gth is not None:
-            gq.put(None)
-            gth.join()
+            try:
+                gq.put(None, timeout=300)
+            except queue.Full:
+                print("bench.py: rsm_gather_clouds made no progress for 300 s on rank %d" % rank, file=sys.stderr, flush=True)
+                os._exit(3)
+            gth.join(timeout=300)
+            if gth.is_alive():
+                print("bench.py: the last rsm_gather_clouds did not complete within 300 s on rank %d" % rank, file=sys.stderr, flush=True)
+                os._exit(3)
             if gerr:
                 raise gerr[0]
         for t in threads:
@@ -396,7 +427,7 @@ def main():
                        "parallelism": ("pairs sharded one process per GPU + fan-in gather of the clouds to rank 0, overlapped with the next step, through %s"
                                        % ("rsm_comm / rsm_gather_clouds (the library's own RCCL path)" if transport == "rccl" else
                                           "torch.distributed (%s)" % backend)) if world > 1 else "single GPU",
-                       "transport": transport if exchange else None},
+                       "transport": transport if exchange else None, "transport_note": transport_note},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
