@@ -376,7 +376,10 @@ def main():
         for o in args.opt:
             if o.startswith("refine_skew_variant="):
                 variant = int(o.split("=")[1])
-        kname = {"refine_skew_top": "k_refine_skew<%d,1,%d> (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level; template arguments: sweeps per launch, top level, variant = option refine_skew_variant)" % (spl, variant if spl == 4 else 0, spl),
+        skew_name = ("k_refine_skew<%d,1,%d> (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level; template arguments: sweeps per launch, top level, variant = option refine_skew_variant)" % (spl, variant if spl == 4 else 0, spl)
+                     if not (variant & 64 and spl == 4) else
+                     "k_refine_skew1<1> (DisparityRefine, 4 time-skewed Jacobi sweeps per launch by one wave per strip, top level; option refine_skew_variant = 64)")
+        kname = {"refine_skew_top": skew_name,
                  "refine_multi_top": "k_refine_multi<1> (DisparityRefine, two Jacobi sweeps per launch, top level)",
                  "refine_light_top": "k_refine_sweep<1,0> (DisparityRefine Jacobi sweep, top level)"}[dom]
         multi = dom != "refine_light_top"

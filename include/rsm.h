@@ -236,7 +236,11 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          +2 %); 16 only the cache way the state selects is read from LDS (+1.5 %); 1 / 2 = two bit-identical
  *                          restatements measured SLOWER (a row's staging shared by two waves / lane masks + unscaled divisions
  *                          behind a late guard), kept for A/B; 0 = round 3's kernel.  Only the instantiated sets are accepted:
- *                          0, 1, 2, 3, 4, 12, 28 (anything else: RSM_E_INVALID)
+ *                          0, 1, 2, 3, 4, 12, 28, 64 (anything else: RSM_E_INVALID).  64 = k_refine_skew1 (round 5): one wave per
+ *                          strip advances all four sweeps itself, the state rings in registers, neighbours by lane shifts, no
+ *                          barrier, the four rows' updates interleaved -- bit-identical, measured 24 % SLOWER alone (0.37 against
+ *                          0.30 ms per launch; DESIGN.md 4 says why), kept for A/B
+ *   "refine_skew1_strips"  strip-chunks a launch of that kernel aims at (default 2048 = the 8 strips of 18 KB of LDS a CU holds)
  *   "cu_share" = n         n > 1: the context's streams are confined to one of n equal shares of the compute units (the
  *                          context's creation ordinal on its device picks the share; measured slower than sharing the whole
  *                          chip in turns); 0 / 1 = the whole chip.  The masked streams are BLOCKING streams

@@ -15,6 +15,7 @@
 #include "rsm_dev.h"
 
 #include <limits.h>
+#include <type_traits>
 
 // exp(-t), t >= 0, for the smoothness weights (.cpp:665-666).  The reference calls its C runtime's exp, whose last bit is not
 // specified, and the sweep amplifies last-bit differences chaotically (tests/test_oracle_exp_control.py).  So the weights come
@@ -123,6 +124,7 @@ __device__ __forceinline__ void exp_neg2(double t1, double t2, double &w1, doubl
     w2 = exp_neg(t2, tab);
 }
 
+#ifndef RF_SKEW1_TU // (k_refine_skew1.hip includes this file for the device functions only)
 // test entry: the specified exp on an array (rsm_stage_exp_neg); flag = 1: the t < 512 form on every argument below 512
 __global__ void k_exp_neg(const double *t, double *out, long long n, int small_form) {
     __shared__ double2 s_exp[128];
@@ -156,6 +158,7 @@ void launch_refine_init(const StageArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_refine_init, dim3((unsigned)blocks, 1, a.ndir), dim3(256), 0, st, a);
 }
 
+#endif // !RF_SKEW1_TU
 // The update of .cpp:652-672 given the data term (pwp, delta = pdp - dCenter).
 __device__ __forceinline__ double refine_update(int mode, double dC, double dE, double dW, double dN, double dS,
                                                 double pwp, double delta, double ws, ExpTab tab) {
@@ -189,6 +192,7 @@ __device__ __forceinline__ double div_unscaled(double a, double b) {
     return __builtin_fma(rem, y, q);
 }
 
+#ifndef RF_SKEW1_TU // (k_refine_skew1.hip includes this file for the device functions only)
 // test entry (rsm_stage_div_unscaled): the trimmed division beside the compiler's on arrays
 __global__ void k_div_unscaled(const double *a, const double *b, double *q_fast, double *q_ieee, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,12 +205,14 @@ void launch_div_unscaled(const double *a, const double *b, double *q_fast, doubl
     if (n > 0) hipLaunchKernelGGL(k_div_unscaled, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, q_fast, q_ieee, n);
 }
 
+#endif // !RF_SKEW1_TU
 // Lane masks straight from the compare (one v_cmp into a scalar pair), combined with scalar logic; rf_sel turns a mask back into
 // a select / branch condition at no cost.  A ballot of a COMBINED bool costs two vector instructions (v_cndmask 0 / 1 + v_cmp).
 #define RF_FNE(x, y) __builtin_amdgcn_fcmp((x), (y), 14) // unordered or not equal: C's !=
 #define RF_FGT(x, y) __builtin_amdgcn_fcmp((x), (y), 2)  // ordered and greater: C's >
 #define RF_FUGE(x, y) __builtin_amdgcn_fcmp((x), (y), 11) // unordered or greater-equal: C's !(x < y)
 #define RF_IEQ(x, y) __builtin_amdgcn_sicmp((x), (y), 32)
+#define RF_IGE(x, y) __builtin_amdgcn_sicmp((x), (y), 39) // signed >=
 #define rf_sel(m) __builtin_amdgcn_inverse_ballot_w64(m)
 
 // refine_update3 with the predicates as lane masks and both divisions unscaled (k_refine_skew, round 4): m_lv = the lanes whose
@@ -517,6 +523,7 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
     refine_entry(x0, x1, x2, pwp, delta);
 }
 
+#ifndef RF_SKEW1_TU // (k_refine_skew1.hip includes this file for the device functions only)
 // test entry (rsm_stage_refine_xi): the matching costs xi (.cpp:624-629) as each of the three device restatements of the data
 // term computes them, for every row y in [1, H-1), own column x in [1, W-1) and other-view window left edge col in [0, W-3]:
 // out[c][entry] = xi(x, y, col + c), c = 0..2, entry = ((y-1) (W-2) + (x-1)) (W-2) + col.  form 0: refine_left + refine_cost_left
@@ -945,6 +952,7 @@ __global__ __launch_bounds__(256) void k_refine_apply(StageArgs a) {
     }
 }
 
+#endif // !RF_SKEW1_TU
 // k_refine_skew's miss path, entered by the whole wave when any of its lanes misses.  A handful of misses per row is the
 // usual case once the iteration has settled: they are listed in LDS and computed four lanes per entry, 16 entries per
 // round (a third of the instructions of a lane computing its own).  The new entries are
@@ -952,7 +960,7 @@ __global__ __launch_bounds__(256) void k_refine_apply(StageArgs a) {
 // appended to the update list.
 __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, int W, int H, int x, int x_lane0, int r, int rel, int way, int lane, bool miss,
                                           bool owned, int32_t *cnt, unsigned shard, double2 (*ent_rows)[64], uint32_t *key_row,
-                                          unsigned long long *emit_row, uint32_t kk, uint8_t *mlist) {
+                                          unsigned long long *emit_row, uint32_t kk, uint8_t *mlist, unsigned dir) {
     const unsigned long long mm = __ballot(miss);
     const int n = __popcll(mm);
     const int rank = __popcll(mm & ((1ull << lane) - 1ull));
@@ -989,7 +997,7 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
         base = __shfl(base, leader) + __popcll(em & ((1ull << lane) - 1ull));
         if (emit && base < a.upd_cap) {
             RfUpd u;
-            u.pix = (uint32_t)((size_t)r * W + x) | ((uint32_t)blockIdx.z << 31);
+            u.pix = (uint32_t)((size_t)r * W + x) | ((uint32_t)dir << 31);
             u.rel = rel;
             u.pwp = pd.x;
             u.delta = pd.y;
@@ -1004,6 +1012,7 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
     }
 }
 
+#ifndef RF_SKEW1_TU // (k_refine_skew1.hip includes this file for the device functions only)
 // ---------------------------------------------------------------------------------------------------------------
 // T Jacobi sweeps per launch, time-skewed down the rows (option refine_skew_from).
 // A workgroup of T waves owns a strip of 64 columns and a chunk of rows and streams down it: in step s it stages row
@@ -1179,7 +1188,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 // would otherwise sink below it and add a second LDS round trip to every row)
                 if (!(V & 16)) asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
                 if (m_miss) { // wave-uniform, rare
-                    skew_miss(a, d, W, H, x, xa - T, r, rel, way, lane, rf_sel(m_miss), xown && r >= ya && r < yb, cnt, shard, s_ent[e], s_key[e], s_emit[e], kk, s_ml[wid]);
+                    skew_miss(a, d, W, H, x, xa - T, r, rel, way, lane, rf_sel(m_miss), xown && r >= ya && r < yb, cnt, shard, s_ent[e], s_key[e], s_emit[e], kk, s_ml[wid], blockIdx.z);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     operands(); // from LDS again (the entries now with the new ones): nothing lives in registers across the data-term routine
@@ -1216,7 +1225,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 // would otherwise sink below it and add a second LDS round trip to every row)
                 asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e1.x), "+v"(e1.y));
                 if (__ballot(miss)) { // wave-uniform, rare
-                    skew_miss(a, d, W, H, x, xa - T, r, rel, way, lane, miss, xown && r >= ya && r < yb, cnt, shard, s_ent[e], s_key[e], s_emit[e], kk, s_ml[wid]);
+                    skew_miss(a, d, W, H, x, xa - T, r, rel, way, lane, miss, xown && r >= ya && r < yb, cnt, shard, s_ent[e], s_key[e], s_emit[e], kk, s_ml[wid], blockIdx.z);
                     // the operands come from LDS again (the entries now with the new ones) instead of living in
                     // registers across the data-term routine: the common path keeps its 96 registers unspilled
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1270,6 +1279,425 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 #endif
 }
 
+#endif // !RF_SKEW1_TU
+#ifdef RF_SKEW1_TU
+// ---------------------------------------------------------------------------------------------------------------
+// The same four time-skewed sweeps with ONE wave per strip (option refine_skew_variant = 64; round 5).
+// What bounds k_refine_skew is not the vector unit (busy half of the launch) but the time its waves spend outside the
+// update math: a wave per sweep level means a workgroup barrier per row, an LDS round trip for the five state values
+// another wave wrote, and two of four waves waiting while the others stage.  tests/micro/ilp_probe.hip:
+// two resident waves per SIMD already issue dependent fp64 fma chains at 90 % of what any occupancy reaches -- so here
+// a single wave owns the strip and advances all four levels itself, one row each per step:
+//   - the state rings (4 levels x 4 rows) live in REGISTERS: the loop is unrolled by the ring period, every index is
+//     static; E / W neighbours are lane shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1), N / S the ring's other rows;
+//   - no barrier at all (the two waves of a workgroup share nothing but the exp table), no LDS traffic for the state;
+//   - the four row updates of a step are independent (levels two rows apart) and written four wide, straight-line and
+//     branch-free: every special case (a row with a border pixel, a weight argument >= 512, pwp == 0) is detected by
+//     lane masks BESIDE the chain and redone afterwards by the general form -- rare, and nothing waits for the test;
+//   - both cache ways of the 8 rows in flight stay in LDS (32 B per pixel is what limits residency: 18 KB per strip,
+//     8 strips per CU = 2 waves per SIMD); each lane reads only what it wrote itself, or what the miss service wrote
+//     behind a wave fence.
+// Same trapezoid of computable pixels, same miss service (skew_miss), same update list: the bits of four single sweeps.
+__device__ __forceinline__ double lane_from_left(double v) { // lane i <- lane i - 1 (lane 0: 0.0; tests/micro/ilp_probe.hip)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_from_right(double v) { // lane i <- lane i + 1 (lane 63: 0.0)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// The mode-3 update (.cpp:652-672) of N independent rows at once, every operation written N wide and the stages fenced for
+// the scheduler (left alone it finishes one row's chain before it starts the next: a dependent fp64 operation issues every
+// other slot at best).  refine_update3m's arithmetic: the t < 512 form of the specified exp and both divisions as the
+// hardware sequence without its operand scaling and fix-up (div_unscaled: no VCC, so the N sequences interleave) -- the
+// bits of the general form wherever the guard holds; bad[i] = the lanes where it does not (a weight argument above 200, a
+// zero or tiny numerator, which includes pwp == 0 with a zero smoothness term), for the caller to redo.  Nothing waits for
+// the guard: it is evaluated beside the chain.  ws in [2^-200, 2^200] is the caller's test (kernel-uniform).
+#define RF_STAGE // (a stage boundary; the translation unit's scheduling strategy keeps the stages' operations side by side)
+template <int N>
+__device__ __forceinline__ void refine_update3_wide(const double (&dC)[N], const double (&dE)[N], const double (&dW)[N], const double (&dN)[N],
+                                                    const double (&dS)[N], const double2 (&pd)[N], double ws, ExpTab tab, double (&u)[N],
+                                                    unsigned long long (&bad)[N]) {
+    double t[2 * N], w[2 * N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double ex = fabs(dE[i] - dC[i]) - fabs(dW[i] - dC[i]);
+        const double ey = fabs(dS[i] - dC[i]) - fabs(dN[i] - dC[i]);
+        t[2 * i] = ex * ex;
+        t[2 * i + 1] = ey * ey;
+    }
+    constexpr int G = 2 * N < 4 ? 2 * N : 4; // weights per group
+#pragma unroll
+    for (int g = 0; g < 2 * N; g += G) { // exp_neg_small's operations (exp_core + the final fma), stage by stage
+        double k[G], r[G], r2[G], pa[G], pb[G], tm[G];
+        uint32_t ki[G];
+        double2 e[G];
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            k[i] = __builtin_fma(-t[g + i], EXP_INVLN2N, EXP_SHIFT);
+            ki[i] = (uint32_t)__double2loint(k[i]);
+            e[i] = tab[ki[i] & 127u];
+        }
+        RF_STAGE;
+#pragma unroll
+        for (int i = 0; i < G; i++) k[i] = k[i] - EXP_SHIFT;
+#pragma unroll
+        for (int i = 0; i < G; i++) r[i] = __builtin_fma(k[i], EXP_NEGLN2HIN, -t[g + i]);
+        RF_STAGE;
+#pragma unroll
+        for (int i = 0; i < G; i++) r[i] = __builtin_fma(k[i], EXP_NEGLN2LON, r[i]);
+        RF_STAGE;
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            r2[i] = r[i] * r[i];
+            pa[i] = __builtin_fma(r[i], EXP_C3, EXP_C2);
+            pb[i] = __builtin_fma(r[i], EXP_C5, EXP_C4);
+            tm[i] = r[i] + e[i].x;
+        }
+        RF_STAGE;
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            tm[i] = __builtin_fma(pa[i], r2[i], tm[i]);
+            r2[i] = r2[i] * r2[i];
+        }
+        RF_STAGE;
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            tm[i] = __builtin_fma(r2[i], pb[i], tm[i]);
+            k[i] = __hiloint2double(__double2hiint(e[i].y) + (int)(ki[i] << 13), __double2loint(e[i].y)); // the scale 2^e H[j]
+        }
+        RF_STAGE;
+#pragma unroll
+        for (int i = 0; i < G; i++) w[g + i] = __builtin_fma(k[i], tm[i], k[i]);
+        RF_STAGE;
+    }
+    // ds = (wx (dE + dW) + wy (dN + dS)) / (2 (wx + wy)), .cpp:669
+    double a1[N], b1[N], y[N], q[N], ee[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        a1[i] = w[2 * i] * (dE[i] + dW[i]) + w[2 * i + 1] * (dN[i] + dS[i]);
+        b1[i] = 2 * (w[2 * i] + w[2 * i + 1]);
+    }
+#define RF_DIV_WIDE(A, B, Q)                                                      \
+    _Pragma("unroll") for (int i = 0; i < N; i++) y[i] = __builtin_amdgcn_rcp(B[i]); \
+    RF_STAGE;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; i++) ee[i] = __builtin_fma(-B[i], y[i], 1.0); \
+    RF_STAGE;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; i++) y[i] = __builtin_fma(y[i], ee[i], y[i]); \
+    RF_STAGE;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; i++) ee[i] = __builtin_fma(-B[i], y[i], 1.0); \
+    RF_STAGE;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; i++) y[i] = __builtin_fma(y[i], ee[i], y[i]); \
+    RF_STAGE;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; i++) Q[i] = A[i] * y[i];             \
+    RF_STAGE;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; i++) ee[i] = __builtin_fma(-B[i], Q[i], A[i]); \
+    RF_STAGE;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; i++) Q[i] = __builtin_fma(ee[i], y[i], Q[i]); \
+    RF_STAGE;
+    RF_DIV_WIDE(a1, b1, q) // (div_unscaled's eight operations)
+    double a2[N], b2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        a2[i] = (dC[i] + pd[i].y) * pd[i].x + ws * q[i]; // .cpp:671
+        b2[i] = pd[i].x + ws;
+    }
+    RF_DIV_WIDE(a2, b2, u)
+#undef RF_DIV_WIDE
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        bad[i] = RF_FGT(fmax(t[2 * i], t[2 * i + 1]), 200.0) | ~(RF_FGT(fabs(a1[i]), 0x1p-300) & RF_FGT(fabs(a2[i]), 0x1p-300));
+}
+
+// Timing experiments (results invalid; -DRF_SKEW1_EXP=bits: 1 no loads of the cache rows, 2 no update math, 4 no LDS staging writes,
+// 8 no loads of the state, 16 no miss service -- the code-size question, 32 no result store, 128 a store per row whatever happened) exist at compile time only: DESIGN.md 4 quotes them.
+#ifdef RF_SKEW1_EXP
+#define S1_EXP(b) ((RF_SKEW1_EXP) & (b))
+#else
+#define S1_EXP(b) 0
+#endif
+#ifdef RF_SKEW1_TIMING // per-phase shader-clock split of a step (s_memtime), printed by a few waves of launch 12
+#define S1_TICK(i)                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    tq1 = __builtin_amdgcn_s_memtime();                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    tm[i] += tq1 - tq0;                                \
+    tq0 = tq1;
+#else
+#define S1_TICK(i)
+#endif
+template <int TOP>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_refine_skew1(StageArgs a) {
+    constexpr int T = 4, NE = 8, UW = 64 - 2 * T;
+    __shared__ double2 s_exp[128];
+    __shared__ double2 s_ent[2][NE][2][64];        // [wave][row & 7][way][lane] = (pwp, delta)
+    __shared__ uint32_t s_key[2][NE][64];          // key of way 0 | key of way 1 << 16
+    __shared__ unsigned long long s_emit[2][NE][2]; // the lanes whose cache slot this launch already listed a new entry for
+    __shared__ uint8_t s_ml[2][64];                // the lanes of a row's misses (skew_miss)
+    exp_tab_stage(s_exp);
+    __syncthreads(); // (the only one)
+    // Workgroup -> (strip pair, chunk, direction), XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs,
+    // each with its own L2.  Neighbouring strips share 8 of their 64 columns and the two partial 128-byte lines at the ends of
+    // every row segment they write: id = 8 j + k is given the j-th tile of the k-th eighth of the launch, so that an XCD works
+    // on a contiguous range of strips (option: -DRF_SKEW1_NO_XCD_MAP keeps the plain order).
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#ifndef RF_SKEW1_NO_XCD_MAP
+    {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z, lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned per = nwg >> 3, body = per << 3; // (the last nwg % 8 workgroups keep their place)
+        if (lin < body) {
+            const unsigned m = (lin & 7u) * per + (lin >> 3);
+            bx = m % gridDim.x;
+            by = (m / gridDim.x) % gridDim.y;
+            bz = m / (gridDim.x * gridDim.y);
+        }
+    }
+#endif
+    const DirArgs &d = a.d[bz];
+    const int W = a.W, H = a.H;
+    const int XL = d.own.XL, XR = d.own.XR, YL = d.own.YL, YR = d.own.YR;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = (int)bx * 2 + wid;
+    const int xa = XL + 1 + strip * UW, xb = min(xa + UW, XR);                            // owned columns [xa, xb)
+    const int ya = YL + 1 + (int)by * a.skew_rows, yb = min(ya + a.skew_rows, YR); // owned rows [ya, yb)
+    if (xa >= XR || ya >= YR) return; // wave-uniform
+    const int x = xa - T + lane;
+    const int xc = min(max(x, 0), W - 1);
+    const int y0 = max(YL, ya - T), y1 = min(YR, yb - 1 + T); // staged rows [y0, y1]
+    // the five arrays' base pointers stay in scalar registers for the whole launch (laundered: left to itself the compiler
+    // re-reads them from the kernel arguments in every step -- three dependent scalar loads and their waits at the head of a step)
+    // (explicitly global pointers: behind the asm the compiler no longer knows they came from kernel arguments and would use flat accesses)
+    typedef const double __attribute__((address_space(1))) * GCD;
+    typedef double __attribute__((address_space(1))) * GD;
+    typedef const uint16_t __attribute__((address_space(1))) * GCU16;
+    GCD in = (GCD)d.f64_a, c_pwp = (GCD)d.rf_pwp, c_delta = (GCD)d.rf_delta;
+    GD out = (GD)d.f64_b;
+    GCU16 keys = (GCU16)d.rf_key;
+    size_t way1 = a.rf_stride;
+    asm volatile("" : "+s"(in), "+s"(c_pwp), "+s"(c_delta), "+s"(out), "+s"(keys), "+s"(way1));
+    const bool xown = x >= xa && x < xb;
+    const unsigned long long m_own = __builtin_amdgcn_ballot_w64(xown);
+    const unsigned shard = ((unsigned)strip + by * gridDim.x * 2u + bz * 7u) & (RF_UPD_SHARDS - 1);
+    int32_t *cnt = a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS + shard;
+    double2(*ent)[2][64] = s_ent[wid];
+    uint32_t(*key)[64] = s_key[wid];
+    unsigned long long(*emit)[2] = s_emit[wid];
+    const bool wsok = a.ws >= 0x1p-200 && a.ws <= 0x1p200; // refine_update3_wide's division guard
+    // what sweep t (1..4) can compute here: the trapezoid of k_refine_skew.  Columns: sweep t computes x in [max(XL + 1, xa - (T - t)),
+    // min(XR - 1, xb - 1 + (T - t))], i.e. the lanes with t <= tmax (one compare per level instead of four lane masks in scalar
+    // registers); rows: sweep t computes row r of [max(YL + 1, ya - (T - t)), min(YR - 1, yb - 1 + (T - t))], all four of them
+    // while s is in [st_lo, st_hi]
+    const int tmax = (x >= XL + 1 && x <= XR - 1) ? T - max(0, max(xa - x, x - (xb - 1))) : 0;
+    int st_lo = INT_MIN, st_hi = INT_MAX;
+#pragma unroll
+    for (int t = 1; t <= T; t++) {
+        st_lo = max(st_lo, max(YL + 1, ya - (T - t)) + 2 * t - 1);
+        st_hi = min(st_hi, min(YR - 1, yb - 1 + (T - t)) + 2 * t - 1);
+    }
+    double R[T][4];             // [level: 0 = the launch's input, t = sweep t's result][row & 3]
+#ifndef RF_SKEW1_PF
+#define RF_SKEW1_PF 4
+#endif
+    constexpr int PF = RF_SKEW1_PF; // a row's loads are issued PF steps before the step that first uses it (2 or 4: the staging registers
+                                    // are indexed statically by row & (PF - 1)); with 2 a wave waits most of a step for them
+    double gd[PF], gp0[PF], gq0[PF], gp1[PF], gq1[PF]; // staging registers
+    uint16_t gk0[PF], gk1[PF];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) R[t][j] = (double)NOMATCH;
+#pragma unroll
+    for (int j = 0; j < PF; j++) gd[j] = gp0[j] = gq0[j] = gp1[j] = gq1[j] = 0.0, gk0[j] = gk1[j] = 0;
+    unsigned xb8 = (unsigned)xc * 8u, xb2 = (unsigned)xc * 2u; // the column as 32-bit byte offsets beside a scalar row pointer
+    const unsigned lds_lane16 = (unsigned)lane * 16u;
+    double pend_v = 0.0;          // sweep T's row of the previous step: stored AFTER this step's loads have been issued (a store at the
+    unsigned long long pend_m = 0; // end of a step sits in front of the next step's loads in the memory pipeline and holds them up)
+    uint32_t kk[T] = {0u, 0u, 0u, 0u}; // the keys of the four rows of the NEXT step: read a step ahead, off the step's critical path
+
+#ifdef RF_SKEW1_TIMING
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
+    int nsteps = 0;
+#endif
+    // one step: s = the row the input level has reached; level t advances row s - 2t + 1.  PH = s & 3 (static).
+    auto step = [&](int s, auto ph) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph)::value;
+#ifdef RF_SKEW1_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tq0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        nsteps++;
+#endif
+        { // the loads of row s + PF (PF steps ahead of its first use), into the registers of its residue
+            constexpr int g = (PH + PF) & (PF - 1);
+            const size_t p = (size_t)(S1_EXP(256) ? y0 + ((s + PF) & 7) : min(max(s + PF, y0), y1)) * W; // (256, timing only: the same eight rows over and over -- cache hits)
+            asm volatile("" : "+v"(xb8), "+v"(xb2));
+            if (!S1_EXP(8)) gd[g] = *(GCD)((const char __attribute__((address_space(1))) *)(in + p) + xb8);
+            if (!S1_EXP(9)) {
+                gk0[g] = *(GCU16)((const char __attribute__((address_space(1))) *)(keys + p) + xb2);
+                gk1[g] = *(GCU16)((const char __attribute__((address_space(1))) *)(keys + p + way1) + xb2);
+                gp0[g] = *(GCD)((const char __attribute__((address_space(1))) *)(c_pwp + p) + xb8);
+                gq0[g] = *(GCD)((const char __attribute__((address_space(1))) *)(c_delta + p) + xb8);
+                gp1[g] = *(GCD)((const char __attribute__((address_space(1))) *)(c_pwp + p + way1) + xb8);
+                gq1[g] = *(GCD)((const char __attribute__((address_space(1))) *)(c_delta + p + way1) + xb8);
+            }
+        }
+        if (rf_sel(pend_m) && !S1_EXP(32) && (!S1_EXP(512) || a.W < 0)) { // the previous step's result row (s - 1) - 2T + 1; owned lanes: xc == x (512, timing only: the store never executes, the math stays)
+            asm volatile("" : "+v"(xb8));
+            *(GD)((char __attribute__((address_space(1))) *)(out + (size_t)(s - 2 * T) * W) + xb8) = pend_v;
+        }
+        pend_m = 0ull;
+        S1_TICK(0) // staging loads issued
+        const double NM = (double)NOMATCH;
+        double dC[T], val[T];
+        unsigned long long m_lv[T], any_lv = 0ull;
+        unsigned long long rm[T] = {~0ull, ~0ull, ~0ull, ~0ull};
+        if (__builtin_expect(!(s >= st_lo && s <= st_hi), 0)) { // the chunk's first and last steps: not every level has a computable row
+#pragma unroll
+            for (int t = 1; t <= T; t++) {
+                const int r = s - 2 * t + 1;
+                rm[t - 1] = (r >= max(YL + 1, ya - (T - t)) && r <= min(YR - 1, yb - 1 + (T - t))) ? ~0ull : 0ull;
+            }
+        }
+#pragma unroll
+        for (int t = 1; t <= T; t++) {
+            const int i = t - 1;
+            dC[i] = R[i][(PH - 2 * t + 1) & 3];
+            m_lv[i] = RF_FNE(dC[i], NM) & RF_IGE(tmax, t) & rm[i]; // .cpp:613
+            any_lv |= m_lv[i];
+            val[i] = dC[i];
+        }
+        if (any_lv && !S1_EXP(2)) { // (a strip without a live pixel on any of its four rows copies through: the masked parts of the margin's box)
+            int slot[T];
+#pragma unroll
+            for (int i = 0; i < T; i++) slot[i] = (s - 2 * i - 1) & (NE - 1);
+            double dN[T], dS[T], dE[T], dW[T];
+            int rel[T], way[T];
+            unsigned long long m_ew[T], m_ns[T], m_miss[T], any_miss = 0ull;
+#pragma unroll
+            for (int t = 1; t <= T; t++) {
+                const int i = t - 1, c = (PH - 2 * t + 1) & 3;
+                dN[i] = R[i][(c + 3) & 3];
+                dS[i] = R[i][(c + 1) & 3];
+                dE[i] = lane_from_right(dC[i]);
+                dW[i] = lane_from_left(dC[i]);
+                m_ew[i] = RF_FNE(dE[i], NM) & RF_FNE(dW[i], NM); // .cpp:620
+                m_ns[i] = RF_FNE(dS[i], NM) & RF_FNE(dN[i], NM);
+                rel[i] = (int)(dC[i] - 1.5); // .cpp:625 (iMatch - x)
+                way[i] = rel[i] & 1;
+            }
+#pragma unroll
+            for (int i = 0; i < T; i++) {
+                const int crel = (int)(int16_t)(kk[i] >> (way[i] << 4));
+                m_miss[i] = m_lv[i] & (m_ew[i] | m_ns[i]) & ~RF_IEQ(crel, rel[i]);
+                any_miss |= m_miss[i];
+            }
+            S1_TICK(1) // keys arrived, masks
+            if (any_miss && !S1_EXP(16)) { // wave-uniform, rare once the iteration has settled: the miss service, a level at a time
+#pragma unroll 1
+                for (int i = 0; i < T; i++) {
+                    const unsigned long long mm = i == 0 ? m_miss[0] : i == 1 ? m_miss[1] : i == 2 ? m_miss[2] : m_miss[3];
+                    if (!mm) continue;
+                    const int rl = i == 0 ? rel[0] : i == 1 ? rel[1] : i == 2 ? rel[2] : rel[3];
+                    const uint32_t kv = i == 0 ? kk[0] : i == 1 ? kk[1] : i == 2 ? kk[2] : kk[3];
+                    const int r = s - 2 * i - 1, sl = r & (NE - 1);
+                    skew_miss(a, d, W, H, x, xa - T, r, rl, rl & 1, lane, rf_sel(mm), xown && r >= ya && r < yb, cnt, shard, ent[sl], key[sl], emit[sl], kv, s_ml[wid], bz);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            double2 pd[T];
+#pragma unroll
+            for (int i = 0; i < T; i++) // only the way the state selects: [slot][way][lane] of this wave's rows
+                pd[i] = *(const double2 *)((const char *)&ent[0][0][0] + (((unsigned)slot[i] << 11) + ((unsigned)way[i] << 10) + lds_lane16));
+            S1_TICK(2) // miss branch, entry reads issued + arrived (timing build: waited for)
+            double u[T];
+            unsigned long long bad[T], any_bad = 0ull;
+#ifndef RF_SKEW1_WIDTH
+#define RF_SKEW1_WIDTH 2
+#endif
+            constexpr int NW = RF_SKEW1_WIDTH; // rows per call of the wide update (4: more registers than two waves per SIMD have)
+#pragma unroll
+            for (int g = 0; g < T; g += NW) {
+                double gC[NW], gE[NW], gW[NW], gN[NW], gS[NW], gu[NW];
+                double2 gp[NW];
+                unsigned long long gb[NW];
+#pragma unroll
+                for (int i = 0; i < NW; i++) gC[i] = dC[g + i], gE[i] = dE[g + i], gW[i] = dW[g + i], gN[i] = dN[g + i], gS[i] = dS[g + i], gp[i] = pd[g + i];
+                refine_update3_wide<NW>(gC, gE, gW, gN, gS, gp, a.ws, s_exp, gu, gb);
+#pragma unroll
+                for (int i = 0; i < NW; i++) u[g + i] = gu[i], bad[g + i] = gb[i];
+            }
+#pragma unroll
+            for (int i = 0; i < T; i++) {
+                bad[i] = m_lv[i] & ((wsok ? bad[i] : ~0ull) | ~(m_ew[i] & m_ns[i]));
+                any_bad |= bad[i];
+            }
+            S1_TICK(3) // update math
+            if (any_bad) { // wave-uniform: a row with a pixel at the border of the valid region (.cpp:620's other modes) or one of the update's rare cases
+#pragma unroll
+                for (int i = 0; i < T; i++)
+                    if (bad[i]) {
+                        double g = dC[i];
+                        if (rf_sel(m_lv[i])) {
+                            const int mode = (int)rf_sel(m_ew[i]) + (int)rf_sel(m_ns[i]) * 2;
+                            if (mode != 0) g = refine_update(mode, dC[i], dE[i], dW[i], dN[i], dS[i], pd[i].x, pd[i].y, a.ws, s_exp);
+                        }
+                        u[i] = g;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < T; i++) val[i] = rf_sel(m_lv[i]) ? u[i] : dC[i];
+            pend_v = val[T - 1]; // sweep T's computable rows are the owned rows
+            pend_m = m_lv[T - 1] & m_own;
+        }
+        if (S1_EXP(128)) pend_v = dC[T - 1], pend_m = m_own; // (timing only: a store per row even without the math)
+        S1_TICK(4) // rare cases, result store
+#pragma unroll
+        for (int i = 0; i < T; i++) kk[i] = key[(s - 2 * i) & (NE - 1)][lane]; // the next step's rows s - 2i: staged before this step, none of them touched by this step's miss service (rows s - 2i - 1)
+#pragma unroll
+        for (int t = 1; t < T; t++) R[t][(PH - 2 * t + 1) & 3] = val[t - 1];
+        { // row s + 1 (loaded in step s + 1 - PF) becomes visible: the state to the ring, the entries to this wave's LDS rows
+            constexpr int g = (PH + 1) & (PF - 1);
+            asm volatile("" : "+v"(gk0[g]), "+v"(gk1[g])); // (the keys' zero-extension HERE: hoisted, it would wait for the loads steps early)
+            const int es = (s + 1) & (NE - 1);
+            R[0][(PH + 1) & 3] = gd[g];
+            if (!S1_EXP(4)) {
+                key[es][lane] = (uint32_t)gk0[g] | ((uint32_t)gk1[g] << 16);
+                ent[es][0][lane] = make_double2(gp0[g], gq0[g]);
+                ent[es][1][lane] = make_double2(gp1[g], gq1[g]);
+                if (lane < 2) emit[es][lane] = 0ull;
+            }
+        }
+        S1_TICK(5) // staged row to the ring and LDS (waits for its loads)
+    };
+    // the first staged row is y0: its loads go out in step y0 - PF; the loop starts on a multiple of the ring period
+    const int s_first = ((y0 - PF + 8) & ~3) - 8; // (y0 >= 0)
+#pragma unroll 1
+    for (int s = s_first; s <= y1 + 2 * T - 1; s += 4) {
+        step(s, std::integral_constant<int, 0>());
+        step(s + 1, std::integral_constant<int, 1>());
+        step(s + 2, std::integral_constant<int, 2>());
+        step(s + 3, std::integral_constant<int, 3>());
+    }
+    // (nothing is pending here: the loop runs past the last computable row of sweep T by at least one step)
+#ifdef RF_SKEW1_TIMING
+    if (TOP && lane == 0 && a.flag3 == 5 && bz == 0 && (bx % 9) == 4 && (by % 5) == 2)
+        printf("skew1time wg %d %d wave %d steps %d: issue %llu keys %llu entries %llu math %llu rare+store %llu stage %llu\n", (int)bx, (int)by, wid, nsteps,
+               tm[0] / nsteps, tm[1] / nsteps, tm[2] / nsteps, tm[3] / nsteps, tm[4] / nsteps, tm[5] / nsteps);
+#endif
+}
+
+// (its own translation unit, k_refine_skew1.hip: compiled with the max-ILP scheduling strategy, which is what interleaves the rows' chains)
+void launch_refine_skew1(const StageArgs &a, dim3 grid, hipStream_t st) {
+    if (a.flag) hipLaunchKernelGGL(k_refine_skew1<1>, grid, dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(k_refine_skew1<0>, grid, dim3(128), 0, st, a);
+}
+#endif // RF_SKEW1_TU
+
+#ifndef RF_SKEW1_TU
 // T sweeps f64_a -> f64_b in one launch (a.flag3 = launch index, a.skew_rows = rows per chunk) + the launch that applies
 // its cache updates.  T in {2, 3, 4}.
 void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1282,6 +1710,12 @@ void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev
     const int uw = 64 - 2 * T;
     const dim3 grid((cols + uw - 1) / uw, (rows + a.skew_rows - 1) / a.skew_rows, a.ndir);
     if (ev0) (void)hipEventRecord(ev0, st);
+    if (T == 4 && (a.skew_variant & 64)) { // one wave per strip, two strips per workgroup
+        launch_refine_skew1(a, dim3((grid.x + 1) / 2, grid.y, grid.z), st);
+        if (ev1) (void)hipEventRecord(ev1, st);
+        hipLaunchKernelGGL(k_refine_apply, dim3(8, RF_UPD_SHARDS), dim3(256), 0, st, a);
+        return;
+    }
 #define RF_LAUNCH_V(TT, VV)                                                                                   \
     do {                                                                                                      \
         if (a.flag) hipLaunchKernelGGL((k_refine_skew<TT, 1, VV>), grid, dim3(64 * TT), 0, st, a);          \
@@ -1350,3 +1784,5 @@ void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hip
     }
     if (ev1) (void)hipEventRecord(ev1, st);
 }
+
+#endif // !RF_SKEW1_TU

@@ -148,6 +148,7 @@ struct rsm_ctx {
     int opt_refine_skew_T = 4;     // sweeps per time-skewed launch (2..4)
     int opt_refine_skew_min_px = 1000000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
     int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
+    int opt_refine_skew1_strips = 2048;  // strip-chunks a launch of the one-wave-per-strip kernel (refine_skew_variant 64) aims at
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
     int opt_refine_skew_variant = 28;    // T = 4 kernel (k_refine.hip), a bit set: 4 rows without a live pixel skip the update math, 8 the row's predicates as lane masks, 16 only the selected cache way is read (all three default); bits 0 / 1 = two bit-identical restatements measured slower
 
@@ -531,12 +532,13 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_skew_variant")) { // only these instantiations of k_refine_skew<4, TOP, V> exist
-        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 12 && value != 28)
-            return set_err(c, RSM_E_INVALID, "refine_skew_variant %lld: the instantiated variants are 0, 1, 2, 3, 4, 12, 28", value);
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 12 && value != 28 && value != 64)
+            return set_err(c, RSM_E_INVALID, "refine_skew_variant %lld: the instantiated variants are 0, 1, 2, 3, 4, 12, 28, 64", value);
         c->opt_refine_skew_variant = (int)value;
     } else if (!strcmp(name, "shared_gpu")) c->opt_shared_gpu = value != 0;
     else if (!strcmp(name, "filter_list")) c->opt_filter_list = (int)std::max(0LL, std::min(value, 3LL)); // bit 0: the 24-pixel list pass, bit 1: the 40-pixel one
     else if (!strcmp(name, "filter_window")) c->opt_filter_window = (int)std::max(0LL, std::min(value, 24LL)); // 0 off, 1 default, else the radius
+    else if (!strcmp(name, "refine_skew1_strips")) c->opt_refine_skew1_strips = (int)std::max(1LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "cu_share")) {
         // Contexts that share a GPU each on their own share of the compute units (the `ordinal % n`-th of n equal ranges of the
@@ -757,12 +759,17 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         const int skewT = skew ? c->opt_refine_skew_T : 0;
         if (skew) {
             (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
-            int rows = 1, strips = 0;
+            int rows = 1, strips = 0, strips_max = 0;
             for (int v = 0; v < a.ndir; v++) {
                 rows = std::max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
-                strips += (std::max(1, a.d[v].own.XR - a.d[v].own.XL - 1) + (64 - 2 * skewT) - 1) / (64 - 2 * skewT);
+                const int sv = (std::max(1, a.d[v].own.XR - a.d[v].own.XL - 1) + (64 - 2 * skewT) - 1) / (64 - 2 * skewT);
+                strips += sv;
+                strips_max = std::max(strips_max, sv);
             }
-            const int chunks = std::max(1, c->opt_refine_skew_waves / std::max(1, strips));
+            // (variant 64, one wave per strip: 8 strips of 18 KB of LDS are resident per CU, two per workgroup -- the launch's grid is
+            // ceil(widest direction's strips / 2) x chunks x directions workgroups and must not exceed the resident 4 per CU by a few)
+            const int chunks = (c->opt_refine_skew_variant & 64) ? std::max(1, (c->opt_refine_skew1_strips / 2) / std::max(1, a.ndir * ((strips_max + 1) / 2)))
+                                                                 : std::max(1, c->opt_refine_skew_waves / std::max(1, strips));
             a.skew_variant = c->opt_refine_skew_variant;
             a.skew_rows = c->opt_refine_skew_rows > 0 ? c->opt_refine_skew_rows : std::max(4 * skewT, (rows + chunks - 1) / chunks);
         }

@@ -456,14 +456,16 @@ def test_refine_two_sweeps_per_launch_is_bit_identical(ctx, first):
 
 
 @pytest.mark.parametrize("T,first,rows,variant", [(2, 1, 0, 0), (3, 1, 7, 0), (4, 1, 16, 0), (3, 5, 0, 0), (4, 9, 33, 0), (2, 30, 12, 0), (3, 2, 1000, 0),
-                                                 (4, 1, 16, 1), (4, 9, 33, 2), (4, 1, 0, 3), (4, 22, 0, 2), (4, 1, 16, 4), (4, 9, 0, 4), (4, 1, 16, 12), (4, 9, 33, 12), (4, 1, 16, 28), (4, 9, 33, 28), (4, 22, 0, 28)])
+                                                 (4, 1, 16, 1), (4, 9, 33, 2), (4, 1, 0, 3), (4, 22, 0, 2), (4, 1, 16, 4), (4, 9, 0, 4), (4, 1, 16, 12), (4, 9, 33, 12), (4, 1, 16, 28), (4, 9, 33, 28), (4, 22, 0, 28),
+                                                 (4, 1, 16, 64), (4, 9, 33, 64), (4, 22, 0, 64), (4, 1, 0, 64), (4, 2, 5, 64), (4, 3, 1000, 64)])
 def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows, variant):
     """k_refine_skew (T Jacobi sweeps per launch: a wave streams down a 64-column strip with sweep t on row y - t, the
     state rings and both cache ways in its LDS slice, cache updates deferred to the update list) from sweep `first` on
     -- from the first cached sweep, where nearly every pixel misses, to the settled regime -- gives the single-sweep
     result, i.e. the oracle's, bit for bit; chunk heights from 4T rows to the whole level, sweep counts that leave 0..T-1
     single sweeps at the end.  variant != 0: round 4's restatements of the T = 4 kernel (a row's staging shared by two waves;
-    lane-mask predicates and divisions without the hardware sequence's scaling steps; 4: rows without a live
+    lane-mask predicates and divisions without the hardware sequence's scaling steps; 64: k_refine_skew1, one wave per strip with
+    the state rings in registers and the four levels' updates four wide; 4: rows without a live
     pixel skip the update math; 8: the predicates as lane masks, early in the chain; 16: only the selected cache way is read; 28 is the default) -- the same bits."""
     ctx.set_option("refine_skew_variant", variant)
     ctx.set_option("refine_skew_from", first)
