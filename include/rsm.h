@@ -247,7 +247,11 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          (hipExtStreamCreateWithCUMask has no non-blocking flag): legacy null-stream work of the process then
  *                          synchronises with them.  RSM_E_STATE while the context is inside rsm_run_pair
  *   "filter_list"          ... its list passes (a thread per query the tile pass left over, windows read from the lattice copy): bit 0
- *                          the 49 x 49 pass, bit 1 the 81 x 81 pass on what that leaves; default 3, 0 = tile pass + grid ladder only
+ *                          the 49 x 49 pass, bit 1 the 81 x 81 pass on what that leaves, bit 2 (needs bit 0 or a 24-pixel tile pass)
+ *                          a wave per query over windows of 80, 160, 320 ... pixels for the few hundred those leave, then the
+ *                          whole-chip search for the handful beyond -- no grid level at all; bits 3 / 4: the 49 x 49 / 81 x 81 pass in
+ *                          that wave form too (coalesced reads of the lattice rows: 4.0 against 6.8 ms and 1.4 against 3.9 ms on
+ *                          C2's cloud) instead of a thread per query; default 31, 0 = tile pass + grid ladder only
  *   "filter_window"        rsm_filter_last_cloud's pixel-window pass: 1 (default) radius from a sparse probe, 0 off (the generic grid
  *                          search decides every query), 7 / 12 / 16 / 20 / 24 that radius
  *   "shared_gpu" = 1       the caller's hint that other contexts use this context's GPU (pairs in flight): the lone-pair split
@@ -314,6 +318,10 @@ int rsm_stage_exp_neg_small(rsm_ctx *ctx, const double *t, int64_t n, double *ou
  * the hardware's fp64 division sequence without its operand-scaling and fix-up steps -- beside the compiler's a / b, on n operand
  * pairs: the parity tests hold the two equal bit for bit over the operand range the kernel's guard admits */
 int rsm_stage_div_unscaled(rsm_ctx *ctx, const double *a, const double *b, int64_t n, double *q_fast, double *q_ieee);
+/* the cloud filter's square root (PCL's statistical outlier removal sums sqrt of float32 squared distances,
+ * CCloudOptimization.cpp:25-61 via pcl::StatisticalOutlierRemoval) -- the compiler's correctly rounded sequence without its
+ * denormal scaling -- against sqrtf on the n floats with bit patterns first_bits .. first_bits + n - 1: *mismatches = how many differ */
+int rsm_stage_sqrt_check(rsm_ctx *ctx, uint32_t first_bits, int64_t n, int64_t *mismatches);
 /* DisparityRefine's matching costs xi = (1 - arma::dot(vecL, vecR) / (normL * normR)) / 2 (CStereoMatching.cpp:624-629) of 3x3x3
  * windows, as the device restatements of the data term compute them (form 0: the first sweep's, 1: a lane per cache miss, 2: four
  * lanes per cache miss): out[c][((y-1) (W-2) + (x-1)) (W-2) + col] = xi(own column x, row y, other view's window left edge col + c),

@@ -77,7 +77,7 @@ EXPORTS = [
     "rsm_set_option", "rsm_profile_enable", "rsm_profile_stage_count", "rsm_profile_stage_name", "rsm_profile_get",
     "rsm_stage_find_margin", "rsm_stage_pyr_down", "rsm_stage_erode_ellipse", "rsm_stage_initial_match",
     "rsm_stage_smooth", "rsm_stage_order", "rsm_stage_uniqueness_pass_s16", "rsm_stage_uniqueness_pass_f64",
-    "rsm_stage_set_boundary", "rsm_stage_rematch", "rsm_stage_median", "rsm_stage_refine", "rsm_stage_exp_neg", "rsm_stage_exp_neg_small", "rsm_stage_div_unscaled", "rsm_stage_refine_xi", "rsm_stage_cloud",
+    "rsm_stage_set_boundary", "rsm_stage_rematch", "rsm_stage_median", "rsm_stage_refine", "rsm_stage_exp_neg", "rsm_stage_exp_neg_small", "rsm_stage_div_unscaled", "rsm_stage_sqrt_check", "rsm_stage_refine_xi", "rsm_stage_cloud",
     "rsm_bench_ncc", "rsm_write_ply", "rsm_write_ply16", "rsm_rectify_pair", "rsm_stereo_rectify", "rsm_stage_rect_map",
     "rsm_stage_remap", "rsm_stage_erode_gray", "rsm_run_pairs", "rsm_run_pairs_repeat", "rsm_match_pairs", "rsm_match_pairs_multi_gpu",
     "rsm_pack_cloud16", "rsm_comm_unique_id", "rsm_comm_create", "rsm_comm_destroy", "rsm_comm_last_error",

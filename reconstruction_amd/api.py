@@ -539,6 +539,12 @@ class Context:
         self._chk(self._lib.rsm_stage_div_unscaled(self._h, _p(a), _p(b), C.c_int64(a.size), _p(qf), _p(qi)))
         return qf, qi
 
+    def sqrt_check(self, first_bits, n):
+        """How many of the n floats with bit patterns first_bits .. first_bits + n - 1 the cloud filter's trimmed sqrtf gets wrong."""
+        m = C.c_int64()
+        self._chk(self._lib.rsm_stage_sqrt_check(self._h, C.c_uint32(int(first_bits)), C.c_int64(int(n)), C.byref(m)))
+        return int(m.value)
+
     def disparity_to_cloud(self, disp, mask_org, img_own, Q, scale, R, T, own):
         d = np.ascontiguousarray(disp, np.float64); mask_org = _u8(mask_org); img_own = _u8(img_own)
         H, W = d.shape

@@ -54,6 +54,34 @@ __device__ __forceinline__ float fdist2(float ax, float ay, float az, float bx, 
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
     return (dx * dx + dy * dy) + dz * dz;
 }
+// sqrtf, correctly rounded, for the k-nearest sums (PCL adds sqrt of the float32 squared distances): the compiler's own sequence --
+// v_sqrt_f32 (1 ulp), the two neighbouring floats, an fma residual each, two selects -- WITHOUT its input scaling for
+// denormals and its zero / infinity test (8 of 17 instructions): the same bits for every x in [2^-96, FLT_MAX] and for 0
+// (rsm_stage_sqrt_check holds it against sqrtf on ALL of them); anything else takes sqrtf.  The pixel-window search spends its
+// second pass in this function with a tenth of its lanes active.
+__device__ __forceinline__ float sqrtf_rn(float x) {
+    if (__builtin_expect(!(x >= 0x1p-96f || x == 0.0f), 0)) return sqrtf(x); // denormal-range inputs (and NaN / negative): the general sequence
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    s = (r_dn <= 0.0f) ? s_dn : s;
+    s = (r_up > 0.0f) ? s_up : s;
+    return s;
+}
+// test entry (rsm_stage_sqrt_check): sqrtf_rn against sqrtf on the floats with bit patterns first .. first + n - 1
+__global__ void k_sqrt_check(unsigned int first, long long n, unsigned long long *mismatches) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    unsigned int bad = 0;
+    for (long long i = i0; i < n; i += stride) {
+        const float x = __uint_as_float(first + (unsigned int)i);
+        bad += __float_as_uint(sqrtf_rn(x)) != __float_as_uint(sqrtf(x));
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+void launch_sqrt_check(unsigned int first, long long n, unsigned long long *mismatches, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_sqrt_check, dim3(8192), dim3(256), 0, st, first, n, mismatches);
+}
+
 __device__ __forceinline__ int cell_of(float v, float o, float inv_h, int n) {
     const int c = (int)floorf((v - o) * inv_h);
     return min(max(c, 0), n - 1);
@@ -136,82 +164,16 @@ __device__ __forceinline__ void ranges9(const unsigned long long *__restrict__ k
     }
 }
 
-// mean distance to the k nearest neighbours (statistical_outlier_removal.hpp).  One wave per query point: the 27 cells
-// around it are 9 contiguous ranges of the sorted array -- their ends come from the cell table (lanes 0..26 load one
-// cell each: one round trip) or, without a table, from binary searches; the squared distances to the candidates are
-// computed once into registers (lane l holds candidates l, l + 64, ...; the asm fence keeps the compiler from
-// re-loading them in every bisection step -- the first version did, 36 VGPRs and 120 ns per query), the (k+1)-th
-// smallest is found by bisection on its bit pattern with ballots, the sum by a wave reduction.
-// A query with more than 64 * KNN_C candidates re-computes them per bisection step instead.
 #define KNN_C 32    // registers per lane for the candidates within h
 #define KNN_CAP (64 * KNN_C)
 #define KNN_B 16    // candidate loads in flight per lane
-template <int TABLE> // 1: per-cell table, 2: per-row table + a short binary search inside the row, 0: binary search on all keys
-__global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, const float4 *__restrict__ sxyz,
-                                                  const unsigned long long *__restrict__ keys, const int2 *__restrict__ table, int n,
-                                                  FGrid g, float h2, int mean_k, const unsigned int *__restrict__ queries, int nq,
-                                                  float *__restrict__ dist_orig, unsigned int *__restrict__ undecided /* [nq]: 1 = retry on a coarser grid */) {
-    __shared__ float s_d2[4][KNN_CAP];
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= nq) return; // wave-uniform; no workgroup barrier below
-    const unsigned int orig = queries[qi];
-    const float px = xyz[3 * (size_t)orig], py = xyz[3 * (size_t)orig + 1], pz = xyz[3 * (size_t)orig + 2];
-    int ix, iy, iz;
-    grid_cell(g, px, py, pz, ix, iy, iz);
-    int my_s = 0, my_e = 0; // range t in lane t (t < 9)
-    if (TABLE == 2) {
-        if (lane < 9) {
-            const int yy = iy + lane % 3 - 1, zz = iz + lane / 3 - 1;
-            if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-                const unsigned long long row = (unsigned long long)zz * g.ny + yy, base = row * g.nx;
-                const int2 se = table[row];
-                my_s = lower_bound_key_in(keys, se.x, se.y, base + max(ix - 1, 0));
-                my_e = lower_bound_key_in(keys, my_s, se.y, base + min(ix + 1, g.nx - 1) + 1);
-            }
-        }
-    } else if (TABLE == 1) {
-        // lane 3 t + j: cell (ix - 1 + j, iy + t % 3 - 1, iz + t / 3 - 1); its points are [x, y) of the sorted array
-        int cs = 0, ce = 0;
-        if (lane < 27) {
-            const int t = lane / 3, xx = ix - 1 + lane % 3, yy = iy + t % 3 - 1, zz = iz + t / 3 - 1;
-            if (xx >= 0 && xx < g.nx && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-                const int2 se = table[((size_t)zz * g.ny + yy) * g.nx + xx];
-                cs = se.x;
-                ce = se.y;
-            }
-        }
-        // the three x-adjacent cells hold consecutive keys: first non-empty cell's start .. last non-empty cell's end
-        const int s0 = __shfl(cs, 3 * lane), s1 = __shfl(cs, 3 * lane + 1), s2 = __shfl(cs, 3 * lane + 2);
-        const int e0 = __shfl(ce, 3 * lane), e1 = __shfl(ce, 3 * lane + 1), e2 = __shfl(ce, 3 * lane + 2);
-        if (lane < 9) {
-            my_s = e0 > s0 ? s0 : (e1 > s1 ? s1 : s2);
-            my_e = e2 > s2 ? e2 : (e1 > s1 ? e1 : (e0 > s0 ? e0 : my_s));
-            if (!(e0 > s0 || e1 > s1 || e2 > s2)) my_s = my_e = 0;
-        }
-    } else if (lane < 9) {
-        const int yy = iy + lane % 3 - 1, zz = iz + lane / 3 - 1;
-        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-            const unsigned long long base = ((unsigned long long)zz * g.ny + yy) * g.nx;
-            my_s = lower_bound_key(keys, n, base + max(ix - 1, 0));
-            my_e = lower_bound_key(keys, n, base + min(ix + 1, g.nx - 1) + 1);
-        }
-    }
-    int rs[9], pre[10];
-    pre[0] = 0;
-#pragma unroll
-    for (int t = 0; t < 9; t++) {
-        rs[t] = __shfl(my_s, t);
-        pre[t + 1] = pre[t] + (__shfl(my_e, t) - rs[t]);
-    }
-    const int M = pre[9], want = mean_k + 1; // the point itself is the first of the k + 1 results
-    auto cand = [&](int c) -> float { // squared distance to candidate c < M of the concatenated ranges
-        int base = rs[0] - pre[0];
-#pragma unroll
-        for (int t = 1; t < 9; t++) base = c >= pre[t] ? rs[t] - pre[t] : base;
-        const float4 o = sxyz[base + c];
-        return fdist2(px, py, pz, o.x, o.y, o.z);
-    };
+// The selection a wave runs for one query over M candidates `cand(c)` (squared float32 distances, NaN = no candidate): the (k+1)-th
+// smallest among those <= h2 and the exact double sum of the square roots below it.  Returns false -- nothing written but
+// `undecided` -- when fewer than `want` candidates lie within h2.  Shared by the grid search (k_sor_knn: the 27 cells of a query)
+// and the wave form of the pixel-window search (k_sor_window_wave: a window of the lattice copy).
+template <class Cand>
+__device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2, int want, float *mine, int lane, unsigned int *undecided_slot,
+                                              float &tau_out, double &sum_out, int &less_out) {
     const float inf = __uint_as_float(0x7f800000u);
     // Only candidates within h of the query matter (a query is decided here iff k + 1 of them exist): the squared
     // distances are computed in chunks of KNN_B loads per lane in flight, those <= h^2 are compacted into the wave's
@@ -219,10 +181,9 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
     // lane l holding entries l, l + 64, ...; the asm fence keeps the compiler from re-deriving them from memory in
     // every bisection step (the first version did: 120 ns per query).
     if (M < want) { // fewer points in the 27 cells than neighbours wanted: undecidable without looking at them
-        if (lane == 0) undecided[qi] = 1u;
-        return;
+        if (lane == 0) *undecided_slot = 1u;
+        return false;
     }
-    float *mine = s_d2[threadIdx.x >> 6];
     const unsigned long long lt = (1ull << lane) - 1ull;
     int K = 0; // candidates within h so far (uniform)
     for (int c0 = 0; c0 < M; c0 += 64 * KNN_B) { // uniform
@@ -243,8 +204,82 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
     }
     // (a flag per query, compacted by a scan afterwards: appending to one list through a single counter retires ~88
     // appends per microsecond -- 62 ms for a level that decides nothing)
-    if (lane == 0) undecided[qi] = K < want;
-    if (K < want) return; // not decidable inside the 27 cells
+    if (lane == 0) *undecided_slot = K < want;
+    if (K < want) return false; // not decidable among these candidates
+    if (K > KNN_CAP && h2 > 0.0f) {
+        // More candidates within h than the list holds (a wide window over a dense part, a too-coarse grid level): two more passes
+        // narrow them down instead of a 30-step bisection that re-reads them all in every step -- a histogram of the squared
+        // distances over KNN_CAP equal bins of [0, h2] (the list's LDS), the bin b* holding rank `want`, then the list again with
+        // the candidates of bins <= b* only (bin() is monotone: they are exactly the values up to some threshold, the rank's among
+        // them).  Falls through to the bisection only if even that is too many (thousands of equal distances).
+        int *hist = (int *)mine;
+        const float inv_w = (float)KNN_CAP / h2;
+        auto bin_of = [&](float v) { return min((int)(v * inv_w), KNN_CAP - 1); };
+        if (isfinite(inv_w) && inv_w > 0.0f) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < KNN_C; i++) hist[lane + 64 * i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int c0 = 0; c0 < M; c0 += 64 * KNN_B) { // uniform
+                float v[KNN_B];
+#pragma unroll
+                for (int i = 0; i < KNN_B; i++) {
+                    const int c = c0 + lane + 64 * i;
+                    v[i] = (c < M) ? cand(c) : inf;
+                }
+#pragma unroll
+                for (int i = 0; i < KNN_B; i++)
+                    if (v[i] <= h2) atomicAdd(&hist[bin_of(v[i])], 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // lane l owns bins [32 l, 32 l + 32): its total, the wave's exclusive prefix, then the bin inside the owning lane
+            int mine_sum = 0;
+#pragma unroll
+            for (int i = 0; i < KNN_C; i++) mine_sum += hist[lane * KNN_C + i];
+            int incl = mine_sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const unsigned long long has = __ballot(incl >= want);
+            const int owner = __builtin_ctzll(has); // (K >= want: some lane reaches it)
+            int run = __shfl(incl - mine_sum, owner), bstar = owner * KNN_C, upto = 0;
+            for (int i = 0; i < KNN_C; i++) { // uniform: every lane reads the owner's bins
+                const int hcount = hist[owner * KNN_C + i];
+                run += hcount;
+                if (run >= want) {
+                    bstar = owner * KNN_C + i;
+                    upto = run;
+                    break;
+                }
+            }
+            if (upto >= want && upto <= KNN_CAP) {
+                __builtin_amdgcn_wave_barrier();
+                K = 0;
+                for (int c0 = 0; c0 < M; c0 += 64 * KNN_B) { // uniform
+                    float v[KNN_B];
+#pragma unroll
+                    for (int i = 0; i < KNN_B; i++) {
+                        const int c = c0 + lane + 64 * i;
+                        v[i] = (c < M) ? cand(c) : inf;
+                    }
+#pragma unroll
+                    for (int i = 0; i < KNN_B; i++) {
+                        const bool keep = v[i] <= h2 && bin_of(v[i]) <= bstar;
+                        const unsigned long long mm = __ballot(keep);
+                        const int pos = K + __popcll(mm & lt);
+                        if (keep && pos < KNN_CAP) mine[pos] = v[i];
+                        K += __popcll(mm);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            } else {
+                K = KNN_CAP + 1; // (the list's LDS holds the histogram now: the bisection below reads the candidates themselves)
+            }
+        }
+    }
     float tau;
     double sum = 0.0;
     int less = 0;
@@ -327,6 +362,89 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
         sum += __shfl_xor(sum, o);
         less += __shfl_xor(less, o);
     }
+    tau_out = tau;
+    sum_out = sum;
+    less_out = less;
+    return true;
+}
+
+// mean distance to the k nearest neighbours (statistical_outlier_removal.hpp).  One wave per query point: the 27 cells
+// around it are 9 contiguous ranges of the sorted array -- their ends come from the cell table (lanes 0..26 load one
+// cell each: one round trip) or, without a table, from binary searches; the squared distances to the candidates are
+// computed once into registers (lane l holds candidates l, l + 64, ...; the asm fence keeps the compiler from
+// re-loading them in every bisection step -- the first version did, 36 VGPRs and 120 ns per query), the (k+1)-th
+// smallest is found by bisection on its bit pattern with ballots, the sum by a wave reduction.
+// A query with more than 64 * KNN_C candidates re-computes them per bisection step instead.
+template <int TABLE> // 1: per-cell table, 2: per-row table + a short binary search inside the row, 0: binary search on all keys
+__global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, const float4 *__restrict__ sxyz,
+                                                  const unsigned long long *__restrict__ keys, const int2 *__restrict__ table, int n,
+                                                  FGrid g, float h2, int mean_k, const unsigned int *__restrict__ queries, int nq,
+                                                  float *__restrict__ dist_orig, unsigned int *__restrict__ undecided /* [nq]: 1 = retry on a coarser grid */) {
+    __shared__ float s_d2[4][KNN_CAP];
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return; // wave-uniform; no workgroup barrier below
+    const unsigned int orig = queries[qi];
+    const float px = xyz[3 * (size_t)orig], py = xyz[3 * (size_t)orig + 1], pz = xyz[3 * (size_t)orig + 2];
+    int ix, iy, iz;
+    grid_cell(g, px, py, pz, ix, iy, iz);
+    int my_s = 0, my_e = 0; // range t in lane t (t < 9)
+    if (TABLE == 2) {
+        if (lane < 9) {
+            const int yy = iy + lane % 3 - 1, zz = iz + lane / 3 - 1;
+            if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const unsigned long long row = (unsigned long long)zz * g.ny + yy, base = row * g.nx;
+                const int2 se = table[row];
+                my_s = lower_bound_key_in(keys, se.x, se.y, base + max(ix - 1, 0));
+                my_e = lower_bound_key_in(keys, my_s, se.y, base + min(ix + 1, g.nx - 1) + 1);
+            }
+        }
+    } else if (TABLE == 1) {
+        // lane 3 t + j: cell (ix - 1 + j, iy + t % 3 - 1, iz + t / 3 - 1); its points are [x, y) of the sorted array
+        int cs = 0, ce = 0;
+        if (lane < 27) {
+            const int t = lane / 3, xx = ix - 1 + lane % 3, yy = iy + t % 3 - 1, zz = iz + t / 3 - 1;
+            if (xx >= 0 && xx < g.nx && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const int2 se = table[((size_t)zz * g.ny + yy) * g.nx + xx];
+                cs = se.x;
+                ce = se.y;
+            }
+        }
+        // the three x-adjacent cells hold consecutive keys: first non-empty cell's start .. last non-empty cell's end
+        const int s0 = __shfl(cs, 3 * lane), s1 = __shfl(cs, 3 * lane + 1), s2 = __shfl(cs, 3 * lane + 2);
+        const int e0 = __shfl(ce, 3 * lane), e1 = __shfl(ce, 3 * lane + 1), e2 = __shfl(ce, 3 * lane + 2);
+        if (lane < 9) {
+            my_s = e0 > s0 ? s0 : (e1 > s1 ? s1 : s2);
+            my_e = e2 > s2 ? e2 : (e1 > s1 ? e1 : (e0 > s0 ? e0 : my_s));
+            if (!(e0 > s0 || e1 > s1 || e2 > s2)) my_s = my_e = 0;
+        }
+    } else if (lane < 9) {
+        const int yy = iy + lane % 3 - 1, zz = iz + lane / 3 - 1;
+        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+            const unsigned long long base = ((unsigned long long)zz * g.ny + yy) * g.nx;
+            my_s = lower_bound_key(keys, n, base + max(ix - 1, 0));
+            my_e = lower_bound_key(keys, n, base + min(ix + 1, g.nx - 1) + 1);
+        }
+    }
+    int rs[9], pre[10];
+    pre[0] = 0;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        rs[t] = __shfl(my_s, t);
+        pre[t + 1] = pre[t] + (__shfl(my_e, t) - rs[t]);
+    }
+    const int M = pre[9], want = mean_k + 1; // the point itself is the first of the k + 1 results
+    auto cand = [&](int c) -> float { // squared distance to candidate c < M of the concatenated ranges
+        int base = rs[0] - pre[0];
+#pragma unroll
+        for (int t = 1; t < 9; t++) base = c >= pre[t] ? rs[t] - pre[t] : base;
+        const float4 o = sxyz[base + c];
+        return fdist2(px, py, pz, o.x, o.y, o.z);
+    };
+    float tau;
+    double sum;
+    int less;
+    if (!wave_knn_core(cand, M, h2, want, s_d2[threadIdx.x >> 6], lane, &undecided[qi], tau, sum, less)) return;
     if (lane == 0) dist_orig[orig] = (float)((sum + (double)(want - less) * (double)sqrtf(tau)) / mean_k);
 }
 
@@ -482,7 +600,7 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
             chunk_d2(r, c0, d2);
 #pragma unroll
             for (int i = 0; i < CH; i++) {
-                if (d2[i] < t_lo) sum += (double)sqrtf(d2[i]);
+                if (d2[i] < t_lo) sum += (double)sqrtf_rn(d2[i]);
                 else if (d2[i] < t_hi) {
                     lst[nl * 256] = d2[i];
                     nl++;
@@ -512,7 +630,7 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
 #pragma unroll 1
     for (int i = 0; i < nl; i++) {
         const float v = lst[i * 256];
-        if (v < tau) sum += (double)sqrtf(v);
+        if (v < tau) sum += (double)sqrtf_rn(v);
     }
     if (!(nl == in_bin && tau < range)) return false;
     // every point outside the window is farther than sqrt(tau): the k + 1 smallest are all here
@@ -586,6 +704,50 @@ __global__ __launch_bounds__(256) void k_sor_window_list(const float4 *__restric
     undecided[q] = ok ? 0u : 1u; // (indexed like the list: the caller compacts it into the ladder's first list)
 }
 
+// Wave form: a wave = one listed query -- what the list passes leave: the points within a few dozen pixels of the mask's corners,
+// around holes, the outliers this filter exists to remove; hundreds, not millions -- its window of ANY radius read from the lattice
+// copy, candidates lane-strided (wave_knn_core: the grid search's selection).  The same bound as the other forms decides whether
+// the window holds the k + 1 nearest; the window is clipped to the lattice copy (no point lies outside the margin's box).
+__global__ __launch_bounds__(256) void k_sor_window_wave(const float4 *__restrict__ lat, const unsigned int *__restrict__ cell_of, WinGeom g, int mean_k, int WR,
+                                                          const unsigned int *__restrict__ list, int nq, float *__restrict__ dist, unsigned int *__restrict__ undecided) {
+    __shared__ float s_d2[4][KNN_CAP];
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return; // wave-uniform; no workgroup barrier below
+    const unsigned int pt = list[qi];
+    const unsigned int cell = cell_of[pt];
+    const int cy = (int)(cell / (unsigned int)g.gw), cx = (int)(cell - (unsigned int)cy * (unsigned int)g.gw);
+    const float4 P = lat[cell];
+    // the bound and its rounding margin, as win_query forms them
+    const double dx = (double)P.x - g.T[0], dy = (double)P.y - g.T[1], dz = (double)P.z - g.T[2];
+    const double F2 = fabs(g.rz[0] * dx + g.rz[1] * dy + g.rz[2] * dz), nP = sqrt(dx * dx + dy * dy + dz * dz);
+    const double iw = F2 / fabs(g.qz);
+    const double LB = F2 * (WR + 1) / (nP / fmax(iw, 1e-300) + (WR + 1));
+    const double coord = fmax(fmax(fabs((double)P.x), fabs((double)P.y)), fabs((double)P.z)) + nP;
+    const double lim = LB * (1.0 - 1e-5) - 4e-7 * coord;
+    const float range = (lim > 0.0) ? (float)(lim * lim * (1.0 - 1e-6)) : 0.0f; // tau must stay below this
+    if (!(range > 0.0f && isfinite(range))) {
+        if (lane == 0) undecided[qi] = 1u;
+        return;
+    }
+    const float h2 = __uint_as_float(__float_as_uint(range) - 1u); // d2 <= h2 is d2 < range
+    const int x0 = max(cx - WR, 0), x1 = min(cx + WR, g.gw - 1), y0 = max(cy - WR, 0), y1 = min(cy + WR, g.gh - 1);
+    const int ncx = x1 - x0 + 1, M = ncx * (y1 - y0 + 1);
+    const float4 *base = lat + (size_t)y0 * g.gw + x0;
+    const int gw = g.gw;
+    auto cand = [&](int c) -> float { // NaN for a pixel without a point: every comparison fails
+        const int r = c / ncx, col = c - r * ncx;
+        const float4 o = base[(size_t)r * gw + col];
+        return fdist2(P.x, P.y, P.z, o.x, o.y, o.z);
+    };
+    float tau;
+    double sum;
+    int less;
+    const int want = mean_k + 1;
+    if (!wave_knn_core(cand, M, h2, want, s_d2[threadIdx.x >> 6], lane, &undecided[qi], tau, sum, less)) return;
+    if (lane == 0) dist[pt] = (float)((sum + (double)(want - less) * (double)sqrtf(tau)) / mean_k);
+}
+
 void launch_cloud_lattice(const uint8_t *flags, const int64_t *row_offset, int W, int XL, int XR, int YL, int YR, const double *xyz, int64_t n, float4 *lat,
                           unsigned int *cell_of, hipStream_t st) {
     const int gw = XR - XL + 1 + 2 * WIN_PAD, gh = YR - YL + 1 + 2 * WIN_PAD;
@@ -611,6 +773,13 @@ void launch_sor_window_list(const float4 *lat, const unsigned int *cell_of, int 
     const dim3 grid((unsigned)((nq + 255) / 256));
     if (radius <= 24) hipLaunchKernelGGL((k_sor_window_list<24, 7>), grid, dim3(256), 0, st, lat, cell_of, g, mean_k, list, nq, dist, undecided);
     else hipLaunchKernelGGL((k_sor_window_list<40, 9>), grid, dim3(256), 0, st, lat, cell_of, g, mean_k, list, nq, dist, undecided);
+}
+// the wave form over nq listed queries at any radius: dist (per point) / undecided (per list entry)
+void launch_sor_window_wave(const float4 *lat, const unsigned int *cell_of, int XL, int XR, int YL, int YR, double qz, const double *R, const double *T, int mean_k,
+                            int radius, const unsigned int *list, int nq, float *dist, unsigned int *undecided, hipStream_t st) {
+    if (nq <= 0) return;
+    const WinGeom g = win_geom(XL, XR, YL, YR, qz, R, T);
+    hipLaunchKernelGGL(k_sor_window_wave, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, lat, cell_of, g, mean_k, radius, list, nq, dist, undecided);
 }
 size_t cloud_lattice_bytes(int XL, int XR, int YL, int YR) {
     return sizeof(float4) * (size_t)(XR - XL + 1 + 2 * WIN_PAD) * (size_t)(YR - YL + 1 + 2 * WIN_PAD);
@@ -1233,7 +1402,9 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     const unsigned int *queries = nullptr;
     int s = RSM_OK;
     const size_t mark = A->off;
-    bool prepassed = false;
+    bool prepassed = false, wave_done = false;
+    const float4 *lat_all = nullptr;
+    int64_t lat_cells = 0;
     if (pre && mean_k <= 128 && nv > 0) { // the pixel-window pass: what it cannot decide becomes the ladder's first query list
         float4 *lat = A->get<float4>(cloud_lattice_bytes(pre->XL, pre->XR, pre->YL, pre->YR) / sizeof(float4));
         unsigned int *cell_of = A->get<unsigned int>((size_t)n);
@@ -1295,7 +1466,10 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
             int last = radius;
             for (int pass = 0; pass < 2 && nq > 0; pass++) {
                 if (radii[pass] <= last || !((pre->list_pass >> pass) & 1)) continue;
-                launch_sor_window_list(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, radii[pass], cur, nq, d_dist, d_flag, st);
+                if ((pre->list_pass >> (3 + pass)) & 1) // (A/B: the wave form at this radius instead of the thread form)
+                    launch_sor_window_wave(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, radii[pass], cur, nq, d_dist, d_flag, st);
+                else
+                    launch_sor_window_list(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, radii[pass], cur, nq, d_dist, d_flag, st);
                 if (rocprim::exclusive_scan(tp, tb, d_flag, d_pos, 0u, (size_t)nq, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
                 hipLaunchKernelGGL(k_compact_list, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, cur, d_flag, d_pos, nq, oth, d_cnt);
                 if (hipMemcpyAsync(h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
@@ -1304,12 +1478,34 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
                 last = radii[pass]; // (the ladder keeps its start: what is left now is few, and a level whose 27 cells hold tens of
                                     // thousands of candidates costs a wave-per-query search milliseconds however few the queries)
             }
+            // What the list passes leave (C2: 564 of 5.5 M -- mask corners, hole rims, outliers): a wave each over windows of 80, 160,
+            // 320 ... pixels of the lattice copy, while there are few enough for that to be cheaper than a grid level (a level is a
+            // sort of the whole cloud plus, for these queries, 27 cells of tens of thousands of candidates each: 4 ms a level on C2).
+            if ((pre->list_pass & 4) && last >= 24) {
+                const int span = std::max(pre->XR - pre->XL, pre->YR - pre->YL) + 1;
+                for (int wr = std::max(80, 2 * last); nq > 0 && nq <= 65536; wr *= 2) {
+                    launch_sor_window_wave(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, wr, cur, nq, d_dist, d_flag, st);
+                    if (rocprim::exclusive_scan(tp, tb, d_flag, d_pos, 0u, (size_t)nq, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
+                    hipLaunchKernelGGL(k_compact_list, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, cur, d_flag, d_pos, nq, oth, d_cnt);
+                    if (hipMemcpyAsync(h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;
+                    nq = h_cnt[0];
+                    std::swap(cur, oth);
+                    if (wr >= span) break; // the window already covers the whole box: what is left has fewer than k + 1 points within its bound
+                }
+                wave_done = true;
+            }
             queries = cur;
             if (pre->undecided_out) *pre->undecided_out = nq;
+            lat_all = lat;
+            lat_cells = (int64_t)(pre->XR - pre->XL + 1 + 2 * WIN_PAD) * (int64_t)(pre->YR - pre->YL + 1 + 2 * WIN_PAD);
         }
     }
     FilterGridDev G;
-    for (int level = 0; level < KNN_LEVELS && nq > 0; level++, h *= 2.0f) {
+    G.sxyz = nullptr;
+    // after the wave passes a handful is left at most (isolated points): straight to the whole-chip search, over the lattice copy
+    // as the point array (its empty pixels are NaN: never below any threshold) -- no grid level, no sort
+    const bool skip_ladder = wave_done && nq <= 48 && lat_all != nullptr;
+    for (int level = 0; level < KNN_LEVELS && nq > 0 && !skip_ladder; level++, h *= 2.0f) {
         A->off = mark; // the previous level's grid is done (its kernels are ordered before this level's on the stream)
         s = build_grid(A, d_xyz, n, nv, h, glo, ghi, st, G);
         if (s != RSM_OK) return s;
@@ -1340,16 +1536,19 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
         if (!d_xq || !d_hist) return RSM_E_NOMEM;
         if (hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)XQ_BATCH * 2048, st) != hipSuccess) return RSM_E_HIP;
         const int shifts[3] = {20, 9, 0}, widths[3] = {11, 11, 9};
+        const float4 *arr = skip_ladder ? lat_all : G.sxyz; // any array holding every finite point once
+        const int arr_n = skip_ladder ? (int)lat_cells : (int)nv;
+        if (!arr || lat_cells >= (1ll << 31)) return RSM_E_INVALID;
         for (int q0 = 0; q0 < nq; q0 += XQ_BATCH) {
             const int cnt = std::min(XQ_BATCH, nq - q0), qy = std::min(cnt, 1024);
             const unsigned int *list = queries + q0;
             hipLaunchKernelGGL(k_xq_init, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_xq, cnt, mean_k, (int)nv);
             for (int pass = 0; pass < 3; pass++) {
-                hipLaunchKernelGGL(k_xq_hist, dim3(XQ_SLICES, (unsigned)qy), dim3(256), 0, st, d_xyz, G.sxyz, (int)nv, list, cnt, d_xq, shifts[pass],
+                hipLaunchKernelGGL(k_xq_hist, dim3(XQ_SLICES, (unsigned)qy), dim3(256), 0, st, d_xyz, arr, arr_n, list, cnt, d_xq, shifts[pass],
                                    widths[pass], d_hist);
                 hipLaunchKernelGGL(k_xq_pick, dim3((unsigned)cnt), dim3(64), 0, st, d_xq, cnt, shifts[pass], widths[pass], d_hist);
             }
-            hipLaunchKernelGGL(k_xq_sum, dim3(XQ_SLICES, (unsigned)qy), dim3(256), 0, st, d_xyz, G.sxyz, (int)nv, list, cnt, d_xq);
+            hipLaunchKernelGGL(k_xq_sum, dim3(XQ_SLICES, (unsigned)qy), dim3(256), 0, st, d_xyz, arr, arr_n, list, cnt, d_xq);
             hipLaunchKernelGGL(k_xq_finish, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_xq, list, cnt, mean_k, (int)nv, d_dist);
         }
     }

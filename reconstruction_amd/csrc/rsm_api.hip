@@ -116,7 +116,7 @@ struct rsm_ctx {
     rsm_point16 *pack16 = nullptr; // the cloud as 16-byte records / the filter's output, staged for a host download (on first use)
     float *pack_nrm = nullptr;     // ... and the filter's normals
     FilterArena *filt_arena = nullptr; // the cloud filter's scratch (created on first use, grows with the cloud)
-    int opt_filter_list = 3;           // ... and the 24-pixel window a thread each for what the tile pass leaves over
+    int opt_filter_list = 31;          // ... and the 24-pixel window a thread each for what the tile pass leaves over
     int opt_filter_window = 1;         // rsm_filter_last_cloud: the pixel-window k-nearest pass in front of the grid ladder (1: radius from a sparse probe; 0: off; else the radius)
     int64_t filt_tile_left = 0;        // ... queries the tile pass alone left over
     int64_t filt_info[4]{};            // last rsm_filter_last_cloud: window pass used, queries it left to the ladder, points in, points kept
@@ -536,7 +536,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
             return set_err(c, RSM_E_INVALID, "refine_skew_variant %lld: the instantiated variants are 0, 1, 2, 3, 4, 12, 28, 64", value);
         c->opt_refine_skew_variant = (int)value;
     } else if (!strcmp(name, "shared_gpu")) c->opt_shared_gpu = value != 0;
-    else if (!strcmp(name, "filter_list")) c->opt_filter_list = (int)std::max(0LL, std::min(value, 3LL)); // bit 0: the 24-pixel list pass, bit 1: the 40-pixel one
+    else if (!strcmp(name, "filter_list")) c->opt_filter_list = (int)std::max(0LL, std::min(value, 31LL)); // bit 0: the 24-pixel list pass, bit 1: the 40-pixel one, bit 2: the wave passes (80, 160, ... pixels) for what they leave, bits 3 / 4: the 24- / 40-pixel pass in the wave form too
     else if (!strcmp(name, "filter_window")) c->opt_filter_window = (int)std::max(0LL, std::min(value, 24LL)); // 0 off, 1 default, else the radius
     else if (!strcmp(name, "refine_skew1_strips")) c->opt_refine_skew1_strips = (int)std::max(1LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
@@ -1589,6 +1589,24 @@ extern "C" int rsm_stage_div_unscaled(rsm_ctx *c, const double *a_in, const doub
     t.down(q_fast, df, (size_t)n);
     t.down(q_ieee, di, (size_t)n);
     return finish(c, t);
+}
+
+// the cloud filter's trimmed sqrtf (k_filter.hip: sqrtf_rn) against the compiler's on the floats with bit patterns first .. first + n - 1
+extern "C" int rsm_stage_sqrt_check(rsm_ctx *c, uint32_t first_bits, int64_t n, int64_t *mismatches) {
+    if (!c || !mismatches || n < 0 || (uint64_t)first_bits + (uint64_t)n > (1ull << 32)) return RSM_E_INVALID;
+    *mismatches = 0;
+    if (n == 0) return RSM_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return set_err(c, RSM_E_HIP, "hipSetDevice");
+    Tmp t(c);
+    unsigned long long *d = t.alloc<unsigned long long>(1);
+    if (!t.ok) return finish(c, t);
+    if (hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream) != hipSuccess) return set_err(c, RSM_E_HIP, "hipMemsetAsync");
+    launch_sqrt_check(first_bits, (long long)n, d, c->stream);
+    unsigned long long h = 0;
+    t.down(&h, d, 1);
+    const int rc = finish(c, t);
+    *mismatches = (int64_t)h;
+    return rc;
 }
 
 extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_t *img_own, const uint8_t *img_oth,

@@ -121,6 +121,7 @@ void launch_median(const StageArgs &a, hipStream_t st);        // d16_in -> d16_
 void launch_exp_neg(const double *t, double *out, long long n, hipStream_t st, int small_form); // the specified exp(-t) (tests)
 // k_refine_skew's division without operand scaling beside the compiler's a / b (tests)
 void launch_refine_xi(const uint32_t *A, const uint32_t *B, int W, int H, int form, double *out, hipStream_t st); // the data term's matching costs (tests)
+void launch_sqrt_check(unsigned int first, long long n, unsigned long long *mismatches, hipStream_t st); // k_filter.hip
 void launch_div_unscaled(const double *a, const double *b, double *q_fast, double *q_ieee, long long n, hipStream_t st);
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel

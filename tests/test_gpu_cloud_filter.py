@@ -115,7 +115,8 @@ def test_pixel_window_pass_gives_the_generic_searchs_results(ctx, case, k):
     below the distance to every ray outside the window -- decided per point, a query per lane; the rest goes to the grid
     ladder) against the same call with the pass switched off (every query through the generic grid search): the same
     surviving points, the same normals, the same statistics, to the bit -- for the probed radius and for every instantiated
-    one (7, 12, 16, 20, 24), on rectangular and elliptic masks, holes, occlusions (depth edges), both disparity signs,
+    one (7, 12, 16, 20, 24), with every combination of the passes behind the tile pass (`filter_list`: the 49 x 49 and 81 x 81
+    list passes a thread per query, the wave passes over 80 ... pixels, the whole-chip search over the lattice copy), on rectangular and elliptic masks, holes, occlusions (depth edges), both disparity signs,
     rotated rigs (R_final != I for pair > 0), thick sheets (small disparities: depth noise of many pixel spacings) and a thin
     one (large disparities), k = 100 and 30."""
     cfg = synth.config_small(**PAIRS_W[case])
@@ -128,8 +129,15 @@ def test_pixel_window_pass_gives_the_generic_searchs_results(ctx, case, k):
     try:
         got, info = _filter_sig(ctx, k, cam, 12)
     finally:
-        ctx.set_option("filter_list", 3)
+        ctx.set_option("filter_list", 31)
     assert got == want and info["radius"] == 12
+    for fl in (1, 2, 3, 5, 7, 15, 23):   # the passes behind the tile pass one by one, thread form and wave form, with and without the wave passes at 80 ... pixels (31 = the default, below)
+        ctx.set_option("filter_list", fl)
+        try:
+            got, info = _filter_sig(ctx, k, cam, 16)
+        finally:
+            ctx.set_option("filter_list", 31)
+        assert got == want, (case, k, "filter_list", fl)
     for window in (1, 7, 12, 16, 20, 24):   # (default: what the tile pass leaves over gets the 24-pixel window a thread each)
         got, info = _filter_sig(ctx, k, cam, window)
         print("case %d k %d window %d: %d points, radius %d, %d (%.1f %%) left to the ladder" % (case, k, window, res.n_points, info["radius"], info["undecided"],

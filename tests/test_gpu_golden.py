@@ -159,3 +159,16 @@ def test_hip_unscaled_division_is_the_ieee_division_inside_its_guard(ctx):
         assert np.array_equal(qi.view(np.int64), want.view(np.int64))            # the device's a / b is IEEE
         bad = qf.view(np.int64) != want.view(np.int64)
         assert not bad.any(), (int(bad.sum()), a[bad][:4], b[bad][:4], qf[bad][:4], want[bad][:4])
+
+
+def test_the_cloud_filters_trimmed_sqrt_is_sqrtf_on_every_float(ctx):
+    """k_filter.hip: sqrtf_rn -- the correctly rounded float32 square root the k-nearest sums take (PCL: sqrt of the float32 squared
+    distances, pcl::StatisticalOutlierRemoval behind CCloudOptimization.cpp:25-61) as the compiler's sequence without its denormal
+    scaling and zero / infinity test -- against the device's sqrtf on EVERY non-negative float: the 1.88 G patterns from 2^-96 to
+    FLT_MAX that take the trimmed sequence, zero, and the patterns below 2^-96, infinity and the NaNs that take sqrtf itself."""
+    lo = 0x0f800000                       # 2^-96
+    assert ctx.sqrt_check(lo, 0x7f800000 - lo) == 0
+    assert ctx.sqrt_check(0, lo) == 0     # zero, the denormals, the small normals
+    assert ctx.sqrt_check(0x7f800000, 1 << 16) == 0   # +inf and NaNs (bit-for-bit the same NaN)
+    assert ctx.sqrt_check(0x80000000, 1 << 20) == 0   # -0 and negative denormals
+
