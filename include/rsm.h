@@ -250,8 +250,8 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          the 49 x 49 pass, bit 1 the 81 x 81 pass on what that leaves, bit 2 (needs bit 0 or a 24-pixel tile pass)
  *                          a wave per query over windows of 80, 160, 320 ... pixels for the few hundred those leave, then the
  *                          whole-chip search for the handful beyond -- no grid level at all; bits 3 / 4: the 49 x 49 / 81 x 81 pass in
- *                          that wave form too (coalesced reads of the lattice rows: 4.0 against 6.8 ms and 1.4 against 3.9 ms on
- *                          C2's cloud) instead of a thread per query; default 31, 0 = tile pass + grid ladder only
+ *                          that wave form too instead of a thread per query (coalesced reads of the lattice rows; on C2's cloud the
+ *                          81 x 81 pass gains, 1.4 against 3.9 ms, the 49 x 49 pass does not); default 23, 0 = tile pass + grid ladder only
  *   "filter_window"        rsm_filter_last_cloud's pixel-window pass: 1 (default) radius from a sparse probe, 0 off (the generic grid
  *                          search decides every query), 7 / 12 / 16 / 20 / 24 that radius
  *   "shared_gpu" = 1       the caller's hint that other contexts use this context's GPU (pairs in flight): the lone-pair split

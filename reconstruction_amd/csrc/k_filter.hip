@@ -59,14 +59,17 @@ __device__ __forceinline__ float fdist2(float ax, float ay, float az, float bx, 
 // denormals and its zero / infinity test (8 of 17 instructions): the same bits for every x in [2^-96, FLT_MAX] and for 0
 // (rsm_stage_sqrt_check holds it against sqrtf on ALL of them); anything else takes sqrtf.  The pixel-window search spends its
 // second pass in this function with a tenth of its lanes active.
-__device__ __forceinline__ float sqrtf_rn(float x) {
-    if (__builtin_expect(!(x >= 0x1p-96f || x == 0.0f), 0)) return sqrtf(x); // denormal-range inputs (and NaN / negative): the general sequence
+__device__ __forceinline__ float sqrtf_rn_core(float x) { // x in [2^-96, FLT_MAX] or 0
     float s = __builtin_amdgcn_sqrtf(x);
     const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
     const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
     s = (r_dn <= 0.0f) ? s_dn : s;
     s = (r_up > 0.0f) ? s_up : s;
     return s;
+}
+__device__ __forceinline__ float sqrtf_rn(float x) {
+    if (__builtin_expect(!(x >= 0x1p-96f || x == 0.0f), 0)) return sqrtf(x); // denormal-range inputs (and NaN / negative): the general sequence
+    return sqrtf_rn_core(x);
 }
 // test entry (rsm_stage_sqrt_check): sqrtf_rn against sqrtf on the floats with bit patterns first .. first + n - 1
 __global__ void k_sqrt_check(unsigned int first, long long n, unsigned long long *mismatches) {
@@ -532,18 +535,31 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
     const int want = mean_k + 1;
     const float inv_w = (range > 0.0f) ? (float)WIN_NB / range : 0.0f;
     if (!(range > 0.0f && inv_w > 0.0f && isfinite(inv_w))) return false;
-    auto bin_of = [&](float d2) { return min((int)(d2 * inv_w), WIN_NB - 1); }; // monotone in d2
+    // bin of a squared distance: 0 .. WIN_NB - 1 below the bound, WIN_NB (the sink row) at or beyond it and for NaN (a pixel without a
+    // point: fminf returns the other operand) -- monotone in d2; one multiply, one minimum, one conversion
+    auto bin_of = [&](float d2) { return (int)fminf(d2 * inv_w, (float)WIN_NB); };
     // A chunk of a window row at a time: all its reads first (16-byte reads, in flight together), then the arithmetic -- a read,
     // its wait and a data-dependent branch per candidate would expose the read latency (2 x 1089 times per query at WR = 16).
+    // the squared distance of fdist2 -- (dx dx + dy dy) + dz dz, the same operations on the same operands -- with x and y as one
+    // packed pair (v_pk_add_f32 / v_pk_mul_f32: the lattice entry's x and y arrive in adjacent registers)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f Pxy = {P.x, P.y};
+    auto d2_of = [&](const float4 &o) {
+        const v2f oxy = {o.x, o.y};
+        const v2f dxy = Pxy - oxy;
+        const v2f sq = dxy * dxy;
+        const float dz = P.z - o.z;
+        return (sq.x + sq.y) + dz * dz;
+    };
     auto chunk_d2 = [&](int r, int c0, float (&d2)[CH]) {
         float4 o[CH];
 #pragma unroll
-        for (int i = 0; i < CH; i++) {
-            o[i] = ld(r, c0 + i);
-            asm volatile("" : "+v"(o[i].w)); // (keeps the read a 16-byte one: twice the LDS rate of the 12-byte form)
-        }
+        for (int i = 0; i < CH; i++) o[i] = ld(r, c0 + i);
 #pragma unroll
-        for (int i = 0; i < CH; i++) d2[i] = fdist2(P.x, P.y, P.z, o[i].x, o[i].y, o[i].z); // NaN for a pixel without a point: every test below fails
+        for (int i = 0; i < CH; i++) asm volatile("" : "+v"(o[i].w)); // (keeps the reads 16-byte ones: twice the LDS rate of the 12-byte form -- AFTER all of them
+                                                                      // have been issued: a use right behind each read puts a wait for it there)
+#pragma unroll
+        for (int i = 0; i < CH; i++) d2[i] = d2_of(o[i]); // NaN for a pixel without a point: every test below fails
     };
     // pass 1: histogram of the window's squared distances (the point itself included: d2 = 0, as nearestKSearch(k + 1)); branch-free:
     // what lies beyond the bound goes to the sink row
@@ -555,7 +571,7 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
             chunk_d2(r, c0, d2);
 #pragma unroll
             for (int i = 0; i < CH; i++) {
-                const int b = (d2[i] < range) ? bin_of(d2[i]) : WIN_NB;
+                const int b = bin_of(d2[i]);
 #if defined(WIN_EXP) && (WIN_EXP & 1) // timing experiment (results invalid): no histogram updates
                 asm volatile("" ::"v"(b));
 #else
@@ -581,14 +597,15 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
     float *lst = (float *)col;
     double sum = 0.0;
     int nl = 0;
-    auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB - 1
+    bool odd = false;
+    auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB
         float t = (float)b / inv_w;
         while (t > 0.0f && bin_of(__uint_as_float(__float_as_uint(t) - 1u)) >= b) t = __uint_as_float(__float_as_uint(t) - 1u);
         while (bin_of(t) < b) t = __uint_as_float(__float_as_uint(t) + 1u);
         return t;
     };
     const float t_lo = bstar > 0 ? first_in(bstar) : 0.0f;
-    const float t_hi = bstar < WIN_NB - 1 ? fminf(first_in(bstar + 1), range) : range;
+    const float t_hi = fminf(first_in(bstar + 1), range); // (a value at the bound's edge can round into the last bin: it is not listed, the count then disagrees and the query is left undecided)
 #pragma unroll 1
     for (int r = 0; r < NC; r++) {
 #if defined(WIN_EXP) && (WIN_EXP & 2) // timing experiment (results invalid): no second pass
@@ -598,6 +615,7 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
         for (int c0 = 0; c0 < NC; c0 += CH) {
             float d2[CH];
             chunk_d2(r, c0, d2);
+#if !defined(WIN_BRANCHFREE_PASS2) // (default; the branch-free form below measured 5 % SLOWER on C2: 8.6 against 8.2 ms)
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 if (d2[i] < t_lo) sum += (double)sqrtf_rn(d2[i]);
@@ -606,6 +624,22 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
                     nl++;
                 }
             }
+#else
+            // Branch-free: nearly every candidate index has SOME lane of the wave below t_lo (a tenth of the lanes each) and some lane
+            // inside the rank's bin, so a branch per case is entered almost always and only adds its exec-mask bookkeeping.  The
+            // square root runs on every lane (of 0 for the lanes that do not count: adds nothing); the listed value goes to the
+            // list's next slot or to the sink row.  sqrtf_rn's trimmed sequence needs d2 >= 2^-96 or 0: a lane that meets anything
+            // else gives its query up (`odd`; never seen -- float32 coordinates do not produce such differences).
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const bool below = d2[i] < t_lo, listed = !below && d2[i] < t_hi; // (NaN: neither)
+                const float v = below ? d2[i] : 0.0f;
+                odd |= v < 0x1p-96f && v != 0.0f;
+                sum += (double)sqrtf_rn_core(v);
+                lst[min(listed ? nl : WIN_NB, WIN_NB) * 256] = d2[i]; // (nl <= in_bin <= WIN_LCAP by the histogram; the clamp keeps a disagreement inside the column)
+                nl += listed;
+            }
+#endif
         }
     }
     // tau = the (want - below)-th smallest of the listed values (by value: ties are equal distances)
@@ -632,7 +666,7 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
         const float v = lst[i * 256];
         if (v < tau) sum += (double)sqrtf_rn(v);
     }
-    if (!(nl == in_bin && tau < range)) return false;
+    if (!(nl == in_bin && tau < range) || odd) return false;
     // every point outside the window is farther than sqrt(tau): the k + 1 smallest are all here
     *out = (float)((sum + (double)(want - (below + less)) * (double)sqrtf(tau)) / mean_k);
     return true;

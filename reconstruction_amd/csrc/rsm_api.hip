@@ -116,7 +116,7 @@ struct rsm_ctx {
     rsm_point16 *pack16 = nullptr; // the cloud as 16-byte records / the filter's output, staged for a host download (on first use)
     float *pack_nrm = nullptr;     // ... and the filter's normals
     FilterArena *filt_arena = nullptr; // the cloud filter's scratch (created on first use, grows with the cloud)
-    int opt_filter_list = 31;          // ... and the 24-pixel window a thread each for what the tile pass leaves over
+    int opt_filter_list = 23;          // ... and the 24-pixel window a thread each for what the tile pass leaves over
     int opt_filter_window = 1;         // rsm_filter_last_cloud: the pixel-window k-nearest pass in front of the grid ladder (1: radius from a sparse probe; 0: off; else the radius)
     int64_t filt_tile_left = 0;        // ... queries the tile pass alone left over
     int64_t filt_info[4]{};            // last rsm_filter_last_cloud: window pass used, queries it left to the ladder, points in, points kept

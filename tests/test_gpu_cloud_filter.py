@@ -129,14 +129,14 @@ def test_pixel_window_pass_gives_the_generic_searchs_results(ctx, case, k):
     try:
         got, info = _filter_sig(ctx, k, cam, 12)
     finally:
-        ctx.set_option("filter_list", 31)
+        ctx.set_option("filter_list", 23)
     assert got == want and info["radius"] == 12
-    for fl in (1, 2, 3, 5, 7, 15, 23):   # the passes behind the tile pass one by one, thread form and wave form, with and without the wave passes at 80 ... pixels (31 = the default, below)
+    for fl in (1, 2, 3, 5, 7, 15, 31):   # the passes behind the tile pass one by one, thread form and wave form, with and without the wave passes at 80 ... pixels (23 = the default, below)
         ctx.set_option("filter_list", fl)
         try:
             got, info = _filter_sig(ctx, k, cam, 16)
         finally:
-            ctx.set_option("filter_list", 31)
+            ctx.set_option("filter_list", 23)
         assert got == want, (case, k, "filter_list", fl)
     for window in (1, 7, 12, 16, 20, 24):   # (default: what the tile pass leaves over gets the 24-pixel window a thread each)
         got, info = _filter_sig(ctx, k, cam, window)

@@ -6,7 +6,7 @@ with Context(0) as ctx:
     ctx.match_pair(cfg, want_cloud=False)
     n = ctx.n_points
     rec = torch.empty((n, 16), dtype=torch.uint8, device="cuda:0"); nrm = torch.empty((n, 4), dtype=torch.float32, device="cuda:0")
-    for fl in (7, 15, 31, 23, 3):
+    for fl in (23, 7, 23):
         ctx.set_option("filter_list", fl)
         for rep in range(2):
             torch.cuda.synchronize(); t0 = time.time()
