@@ -519,10 +519,23 @@ __global__ __launch_bounds__(256) void k_cloud_lattice(const uint8_t *__restrict
 // (0 .. 2 WR), col = the thread's private LDS column (stride 256 words: WIN_NB + 1 words of counters, later the list), CH = the
 // candidates whose reads are in flight together (a divisor of 2 WR + 1).  Returns whether the query is decided; *out = its mean
 // neighbour distance, *lim_out = the bound.
+// The pixels a window of "radius" WR has to look at: the bound holds for every ray at a pixel distance rho >= WR + 1, so the DISC
+// a^2 + b^2 <= (WR + 1)^2 - 1 suffices -- the corners of the square are farther than the rays the bound already covers.  The rows
+// of the window fall into four classes by |b| (<= WR/2, <= 3WR/4, <= 7WR/8, <= WR), each as wide as its widest row needs: 14 %
+// fewer candidates than the square at WR = 16 (937 of 1089), the code of a row four times.
+constexpr int win_isqrt(int v) {
+    int r = 0;
+    while ((r + 1) * (r + 1) <= v) r++;
+    return r;
+}
+constexpr int win_halfwidth(int WR, int b) { // widest |a| of the disc's row b, at most WR
+    const int a = win_isqrt((WR + 1) * (WR + 1) - 1 - b * b);
+    return a < WR ? a : WR;
+}
 template <int WR, int CH, class Loader>
 __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, const WinGeom &g, int mean_k, unsigned int *col, float *out, double *lim_out) {
     constexpr int NC = 2 * WR + 1;
-    static_assert(NC % CH == 0, "whole chunks");
+    (void)NC;
     // the bound and its rounding margin, in double (once per query)
     const double dx = (double)P.x - g.T[0], dy = (double)P.y - g.T[1], dz = (double)P.z - g.T[2];
     const double F2 = fabs(g.rz[0] * dx + g.rz[1] * dy + g.rz[2] * dz), nP = sqrt(dx * dx + dy * dy + dz * dz);
@@ -551,35 +564,57 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
         const float dz = P.z - o.z;
         return (sq.x + sq.y) + dz * dz;
     };
-    auto chunk_d2 = [&](int r, int c0, float (&d2)[CH]) {
-        float4 o[CH];
+    // n candidates of window row r from column c0 on: all reads first (in flight together), then the arithmetic
+    auto chunk_d2 = [&](int r, int c0, auto n_, float *d2) {
+        constexpr int n = decltype(n_)::value;
+        float4 o[n];
 #pragma unroll
-        for (int i = 0; i < CH; i++) o[i] = ld(r, c0 + i);
+        for (int i = 0; i < n; i++) o[i] = ld(r, c0 + i);
 #pragma unroll
-        for (int i = 0; i < CH; i++) asm volatile("" : "+v"(o[i].w)); // (keeps the reads 16-byte ones: twice the LDS rate of the 12-byte form -- AFTER all of them
-                                                                      // have been issued: a use right behind each read puts a wait for it there)
+        for (int i = 0; i < n; i++) asm volatile("" : "+v"(o[i].w)); // (keeps the reads 16-byte ones: twice the LDS rate of the 12-byte form -- AFTER all of them
+                                                                     // have been issued: a use right behind each read puts a wait for it there)
 #pragma unroll
-        for (int i = 0; i < CH; i++) d2[i] = d2_of(o[i]); // NaN for a pixel without a point: every test below fails
+        for (int i = 0; i < n; i++) d2[i] = d2_of(o[i]); // NaN for a pixel without a point: every test below fails
+    };
+    // the disc, a row class at a time (rolled loops over the rows of a class, the columns in chunks of at most CH)
+    auto for_disc = [&](auto &&body) {
+        auto rows = [&](int lo, int hi, auto hw_) { // the rows with |b| in [lo, hi] (lo = 0: one run of rows, else one above and one below), half width hw
+            constexpr int hw = decltype(hw_)::value, wd = 2 * hw + 1, full = wd / CH, tail = wd % CH;
+#pragma unroll 1
+            for (int run = 0; run < (lo == 0 ? 1 : 2); run++) {
+                const int r0 = lo == 0 ? WR - hi : (run ? WR + lo : WR - hi), r1 = lo == 0 ? WR + hi : (run ? WR + hi : WR - lo);
+#pragma unroll 1
+                for (int r = r0; r <= r1; r++) {
+                    if (full > 0) {
+#pragma unroll 1
+                        for (int c = 0; c < full; c++) body(r, WR - hw + c * CH, std::integral_constant<int, (full > 0 ? CH : 1)>());
+                    }
+                    if (tail > 0) body(r, WR - hw + full * CH, std::integral_constant<int, (tail > 0 ? tail : 1)>());
+                }
+            }
+        };
+        constexpr int g1 = WR / 2, g2 = 3 * WR / 4, g3 = 7 * WR / 8;
+        rows(0, g1, std::integral_constant<int, win_halfwidth(WR, 0)>());
+        if (g2 > g1) rows(g1 + 1, g2, std::integral_constant<int, win_halfwidth(WR, g1 + 1)>());
+        if (g3 > g2) rows(g2 + 1, g3, std::integral_constant<int, win_halfwidth(WR, g2 + 1)>());
+        if (WR > g3) rows(g3 + 1, WR, std::integral_constant<int, win_halfwidth(WR, g3 + 1)>());
     };
     // pass 1: histogram of the window's squared distances (the point itself included: d2 = 0, as nearestKSearch(k + 1)); branch-free:
     // what lies beyond the bound goes to the sink row
-#pragma unroll 1
-    for (int r = 0; r < NC; r++) {
-#pragma unroll 1
-        for (int c0 = 0; c0 < NC; c0 += CH) {
-            float d2[CH];
-            chunk_d2(r, c0, d2);
+    for_disc([&](int r, int c0, auto n_) {
+        constexpr int n = decltype(n_)::value;
+        float d2[n];
+        chunk_d2(r, c0, n_, d2);
 #pragma unroll
-            for (int i = 0; i < CH; i++) {
-                const int b = bin_of(d2[i]);
+        for (int i = 0; i < n; i++) {
+            const int b = bin_of(d2[i]);
 #if defined(WIN_EXP) && (WIN_EXP & 1) // timing experiment (results invalid): no histogram updates
-                asm volatile("" ::"v"(b));
+            asm volatile("" ::"v"(b));
 #else
-                atomicAdd(col + 256 * b, 1u); // (no return value: a fire-and-forget ds_add)
+            atomicAdd(col + 256 * b, 1u); // (no return value: a fire-and-forget ds_add)
 #endif
-            }
         }
-    }
+    });
     // the bin holding rank `want`
     int below = 0, bstar = -1, in_bin = 0;
 #pragma unroll 1
@@ -597,7 +632,6 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
     float *lst = (float *)col;
     double sum = 0.0;
     int nl = 0;
-    bool odd = false;
     auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB
         float t = (float)b / inv_w;
         while (t > 0.0f && bin_of(__uint_as_float(__float_as_uint(t) - 1u)) >= b) t = __uint_as_float(__float_as_uint(t) - 1u);
@@ -606,42 +640,21 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
     };
     const float t_lo = bstar > 0 ? first_in(bstar) : 0.0f;
     const float t_hi = fminf(first_in(bstar + 1), range); // (a value at the bound's edge can round into the last bin: it is not listed, the count then disagrees and the query is left undecided)
-#pragma unroll 1
-    for (int r = 0; r < NC; r++) {
-#if defined(WIN_EXP) && (WIN_EXP & 2) // timing experiment (results invalid): no second pass
-        break;
-#endif
-#pragma unroll 1
-        for (int c0 = 0; c0 < NC; c0 += CH) {
-            float d2[CH];
-            chunk_d2(r, c0, d2);
-#if !defined(WIN_BRANCHFREE_PASS2) // (default; the branch-free form below measured 5 % SLOWER on C2: 8.6 against 8.2 ms)
+#if !(defined(WIN_EXP) && (WIN_EXP & 2)) // (timing experiment, results invalid: no second pass)
+    for_disc([&](int r, int c0, auto n_) {
+        constexpr int n = decltype(n_)::value;
+        float d2[n];
+        chunk_d2(r, c0, n_, d2);
 #pragma unroll
-            for (int i = 0; i < CH; i++) {
-                if (d2[i] < t_lo) sum += (double)sqrtf_rn(d2[i]);
-                else if (d2[i] < t_hi) {
-                    lst[nl * 256] = d2[i];
-                    nl++;
-                }
+        for (int i = 0; i < n; i++) {
+            if (d2[i] < t_lo) sum += (double)sqrtf_rn(d2[i]);
+            else if (d2[i] < t_hi) {
+                lst[min(nl, WIN_NB) * 256] = d2[i]; // (nl <= in_bin <= WIN_LCAP by the histogram; the clamp keeps a disagreement inside the column)
+                nl++;
             }
-#else
-            // Branch-free: nearly every candidate index has SOME lane of the wave below t_lo (a tenth of the lanes each) and some lane
-            // inside the rank's bin, so a branch per case is entered almost always and only adds its exec-mask bookkeeping.  The
-            // square root runs on every lane (of 0 for the lanes that do not count: adds nothing); the listed value goes to the
-            // list's next slot or to the sink row.  sqrtf_rn's trimmed sequence needs d2 >= 2^-96 or 0: a lane that meets anything
-            // else gives its query up (`odd`; never seen -- float32 coordinates do not produce such differences).
-#pragma unroll
-            for (int i = 0; i < CH; i++) {
-                const bool below = d2[i] < t_lo, listed = !below && d2[i] < t_hi; // (NaN: neither)
-                const float v = below ? d2[i] : 0.0f;
-                odd |= v < 0x1p-96f && v != 0.0f;
-                sum += (double)sqrtf_rn_core(v);
-                lst[min(listed ? nl : WIN_NB, WIN_NB) * 256] = d2[i]; // (nl <= in_bin <= WIN_LCAP by the histogram; the clamp keeps a disagreement inside the column)
-                nl += listed;
-            }
-#endif
         }
-    }
+    });
+#endif
     // tau = the (want - below)-th smallest of the listed values (by value: ties are equal distances)
     const int rank = want - below; // 1 .. in_bin
     float tau = 0.0f;
@@ -666,7 +679,7 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
         const float v = lst[i * 256];
         if (v < tau) sum += (double)sqrtf_rn(v);
     }
-    if (!(nl == in_bin && tau < range) || odd) return false;
+    if (!(nl == in_bin && tau < range)) return false;
     // every point outside the window is farther than sqrt(tau): the k + 1 smallest are all here
     *out = (float)((sum + (double)(want - (below + less)) * (double)sqrtf(tau)) / mean_k);
     return true;
