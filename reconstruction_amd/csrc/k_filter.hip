@@ -294,8 +294,10 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
         for (int i = 0; i < KNN_C; i++) {
             d2[i] = inf;
             if (i < nreg && lane + 64 * i < K) d2[i] = mine[lane + 64 * i];
-            asm volatile("" : "+v"(d2[i])); // materialise: the value lives in a register from here on
         }
+#pragma unroll
+        for (int i = 0; i < KNN_C; i++) asm volatile("" : "+v"(d2[i])); // materialise: the values live in registers from here on (the fences AFTER
+                                                                        // the last read: one right behind each read makes it a round trip of its own)
         auto count4 = [&](float t, int i0) {
             int cnt = 0;
 #pragma unroll
