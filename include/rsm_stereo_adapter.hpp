@@ -96,6 +96,7 @@ public:
             rsm_destroy(s.ctx);
         }
         delete[] slots_;
+        delete[] gates_;
     }
     bool Ok() const { return create_status_ == RSM_OK; }
     int LastStatus() const { return create_status_ != RSM_OK ? create_status_ : status_; }
@@ -110,6 +111,9 @@ public:
     bool want_disparity;              // download the fp64 disparity maps too (into `disparity`)
     std::vector<double> disparity[2]; // the LAST replayed pair's maps when want_disparity (the reference's local, .cpp:22)
     bool fp64_points;                 // download fp64 xyz + BGR (27 B per point) instead of the 16-byte records
+    int max_running;                  // slots of one GPU inside rsm_run_pair at once (0 = no limit, the default): measured on C2 with 4 ... 7 slots
+                                      // and a limit of 3 -- 272-280 Mdisp/s with and without it (profiles/r05_gate.log): the loop is not
+                                      // bound by too many pairs matching at once; kept for rigs whose pairs are smaller
     bool stage_inputs;                // (default) a slot's worker copies the pair's images / masks into page-locked staging of its own before
                                       // the upload: the reference's cv::Mats are pageable, and the runtime's own staging of pageable uploads is
                                       // serialised across threads -- five workers copying in parallel keep the DMA at the link's rate
@@ -143,9 +147,32 @@ public:
 
 private:
     enum State { IDLE, SUBMITTED, DONE, QUIT };
+    // At most `limit` slots of a device inside rsm_run_pair at once (0 = no limit; option max_running): lets the loop have more
+    // slots than pairs worth matching side by side, the extra ones overlapping their upload, staging copy and download.
+    struct RunGate {
+        std::mutex mu;
+        std::condition_variable cv;
+        int running, limit;
+        RunGate() : running(0), limit(0) {}
+        struct Pass {
+            RunGate *g;
+            explicit Pass(RunGate *gate) : g(gate) {
+                if (!g || g->limit <= 0) { g = 0; return; }
+                std::unique_lock<std::mutex> l(g->mu);
+                while (g->running >= g->limit) g->cv.wait(l);
+                g->running++;
+            }
+            ~Pass() {
+                if (!g) return;
+                { std::lock_guard<std::mutex> l(g->mu); g->running--; }
+                g->cv.notify_one();
+            }
+        };
+    };
     struct Slot {
         rsm_ctx *ctx;
         int device;
+        RunGate *gate;
         std::thread worker;
         std::mutex mu;
         std::condition_variable cv;
@@ -165,7 +192,7 @@ private:
         double *xyz, *disp[2];
         unsigned char *bgr;
         std::string err;
-        Slot() : ctx(0), device(0), state(IDLE), pair(-1), run_status(RSM_OK), dump(false), filtered(false), busy(false), n_kept(0), cap_px(0),
+        Slot() : ctx(0), device(0), gate(0), state(IDLE), pair(-1), run_status(RSM_OK), dump(false), filtered(false), busy(false), n_kept(0), cap_px(0),
                  have_disp(false), have_fp64(false), have_nrm(false), pts(0), nrm(0), stage(0), staged(false), xyz(0), bgr(0) {
             disp[0] = disp[1] = 0;
             memset(&in, 0, sizeof in);
@@ -193,7 +220,12 @@ private:
         const int per = per_device < 1 ? 1 : per_device;
         nslots_ = per * (int)devices_.size();
         slots_ = new Slot[(size_t)nslots_];
-        for (int i = 0; i < nslots_; i++) slots_[i].device = devices_[(size_t)i % devices_.size()];
+        max_running = 0;
+        gates_ = new RunGate[devices_.size()];
+        for (int i = 0; i < nslots_; i++) {
+            slots_[i].device = devices_[(size_t)i % devices_.size()];
+            slots_[i].gate = &gates_[(size_t)i % devices_.size()];
+        }
         create_status_ = rsm_create(&slots_[0].ctx, slots_[0].device); // the first context now: "is there a GPU" is answered here
     }
     static void free_buffers(Slot &s) {
@@ -259,11 +291,20 @@ private:
                 d += px;
             }
         }
-        if (!s.filtered) {
-            s.run_status = rsm_match_pair(s.ctx, &s.in, &s.out);
+        if (!s.filtered) { // rsm_match_pair's three steps, the middle one behind the device's gate (max_running)
+            int st = rsm_upload_pair(s.ctx, &s.in);
+            if (st == RSM_OK) {
+                typename RunGate::Pass pass(s.gate);
+                st = rsm_run_pair(s.ctx);
+            }
+            if (st == RSM_OK) st = rsm_download_pair(s.ctx, &s.out);
+            s.run_status = st;
         } else { // ... with the per-pair cloud filter in between: only what survives it (and its normals) comes down
             int st = rsm_upload_pair(s.ctx, &s.in);
-            if (st == RSM_OK) st = rsm_run_pair(s.ctx);
+            if (st == RSM_OK) {
+                typename RunGate::Pass pass(s.gate);
+                st = rsm_run_pair(s.ctx);
+            }
             if (st == RSM_OK) st = rsm_download_pair(s.ctx, &s.out); // margins, counts, the optional maps / raw records
             s.n_kept = 0;
             if (st == RSM_OK) st = rsm_filter_last_cloud_host(s.ctx, &s.fprm, s.pts, s.nrm, (int64_t)s.cap_px, &s.n_kept, 0);
@@ -328,6 +369,10 @@ private:
             s.have_nrm = keep_nrm;
         }
         s.staged = stage_inputs && s.stage != 0;
+        if (s.gate) {
+            std::lock_guard<std::mutex> l(s.gate->mu);
+            s.gate->limit = max_running;
+        }
         memset(&s.out, 0, sizeof s.out);
         for (int v = 0; v < 2; v++) s.out.disparity[v] = want_disparity ? s.disp[v] : 0;
         if (filtered) { // the raw cloud stays on the GPU; only counts and margins come down before the filter
@@ -481,6 +526,7 @@ private:
     double t_submit_, t_wait_, t_replay_;
     int nslots_;
     Slot *slots_;
+    RunGate *gates_;
     RsmStereoAdapter(const RsmStereoAdapter &);
     RsmStereoAdapter &operator=(const RsmStereoAdapter &);
 };

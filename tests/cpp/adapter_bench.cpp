@@ -116,6 +116,7 @@ int main(int argc, char **argv) {
     gpu.want_disparity = want_disp;
     gpu.fp64_points = (flags & 1) != 0;
     gpu.stage_inputs = (flags & 4) == 0; // 4: the plain pageable upload (A/B)
+    if (const char *mr = getenv("RSM_ADAPTER_MAX_RUNNING")) gpu.max_running = atoi(mr); // (A/B of the run gate; default 3)
     const bool filtered = (flags & 2) != 0;
     s.cloud.assign(px * 3, 0.0f); // a cloud can hold a point per pixel
     s.fill = 0;
