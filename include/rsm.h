@@ -240,6 +240,9 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          strip advances all four sweeps itself, the state rings in registers, neighbours by lane shifts, no
  *                          barrier, the four rows' updates interleaved -- bit-identical, measured 24 % SLOWER alone (0.37 against
  *                          0.30 ms per launch; DESIGN.md 4 says why), kept for A/B
+ *   "refine_skew_waves_alone"  the workgroups a time-skewed launch aims at while no other context of the device is inside
+ *                          rsm_run_pair (default 2560: half as tall chunks, a second round of workgroups shortens the launch's
+ *                          tail -- one C2 pair 22.4 -> 21.7 ms; with pairs in flight `refine_skew_waves` applies); 0 = the same
  *   "refine_skew1_strips"  strip-chunks a launch of that kernel aims at (default 2048 = the 8 strips of 18 KB of LDS a CU holds)
  *   "cu_share" = n         n > 1: the context's streams are confined to one of n equal shares of the compute units (the
  *                          context's creation ordinal on its device picks the share; measured slower than sharing the whole

@@ -148,6 +148,7 @@ struct rsm_ctx {
     int opt_refine_skew_T = 4;     // sweeps per time-skewed launch (2..4)
     int opt_refine_skew_min_px = 1000000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
     int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
+    int opt_refine_skew_waves_alone = 2560; // ... when no other context of the device is inside rsm_run_pair (0: the same)
     int opt_refine_skew1_strips = 2048;  // strip-chunks a launch of the one-wave-per-strip kernel (refine_skew_variant 64) aims at
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
     int opt_refine_skew_variant = 28;    // T = 4 kernel (k_refine.hip), a bit set: 4 rows without a live pixel skip the update math, 8 the row's predicates as lane masks, 16 only the selected cache way is read (all three default); bits 0 / 1 = two bit-identical restatements measured slower
@@ -538,6 +539,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     } else if (!strcmp(name, "shared_gpu")) c->opt_shared_gpu = value != 0;
     else if (!strcmp(name, "filter_list")) c->opt_filter_list = (int)std::max(0LL, std::min(value, 31LL)); // bit 0: the 24-pixel list pass, bit 1: the 40-pixel one, bit 2: the wave passes (80, 160, ... pixels) for what they leave, bits 3 / 4: the 24- / 40-pixel pass in the wave form too
     else if (!strcmp(name, "filter_window")) c->opt_filter_window = (int)std::max(0LL, std::min(value, 24LL)); // 0 off, 1 default, else the radius
+    else if (!strcmp(name, "refine_skew_waves_alone")) c->opt_refine_skew_waves_alone = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_skew1_strips")) c->opt_refine_skew1_strips = (int)std::max(1LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "cu_share")) {
@@ -768,8 +770,13 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
             }
             // (variant 64, one wave per strip: 8 strips of 18 KB of LDS are resident per CU, two per workgroup -- the launch's grid is
             // ceil(widest direction's strips / 2) x chunks x directions workgroups and must not exceed the resident 4 per CU by a few)
+            // A pair that has the GPU to itself takes twice as many, half as tall chunks: its launches end in a tail of one or two
+            // waves per SIMD that nothing else fills, and a second round of workgroups shortens it (one C2 pair 22.4 -> 21.7 ms);
+            // with pairs in flight the other pairs' kernels fill the tail and the extra pipeline fill only costs (332 -> 326).
+            const bool lone = c->device < RSM_MAX_DEVICES && !c->opt_shared_gpu && g_running[c->device].load() == 1 && c->opt_refine_skew_waves_alone > 0;
+            const int waves = lone ? c->opt_refine_skew_waves_alone : c->opt_refine_skew_waves;
             const int chunks = (c->opt_refine_skew_variant & 64) ? std::max(1, (c->opt_refine_skew1_strips / 2) / std::max(1, a.ndir * ((strips_max + 1) / 2)))
-                                                                 : std::max(1, c->opt_refine_skew_waves / std::max(1, strips));
+                                                                 : std::max(1, waves / std::max(1, strips));
             a.skew_variant = c->opt_refine_skew_variant;
             a.skew_rows = c->opt_refine_skew_rows > 0 ? c->opt_refine_skew_rows : std::max(4 * skewT, (rows + chunks - 1) / chunks);
         }
