@@ -255,7 +255,9 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          whole-chip search for the handful beyond -- no grid level at all; bits 3 / 4: the 49 x 49 / 81 x 81 pass in
  *                          that wave form too instead of a thread per query (coalesced reads of the lattice rows; on C2's cloud the
  *                          81 x 81 pass gains, 1.4 against 3.9 ms, the 49 x 49 pass does not); default 23, 0 = tile pass + grid ladder only
- *   "filter_window"        rsm_filter_last_cloud's pixel-window pass: 1 (default) radius from a sparse probe, 0 off (the generic grid
+ *   "filter_window"        rsm_filter_last_cloud's pixel-window pass: 1 (default) radius from a sparse probe (remembered by the context:
+ *                          probed again on every 8th call, for another k or image size, when it stops deciding 70 % of the queries and
+ *                          after any rsm_set_option), 0 off (the generic grid
  *                          search decides every query), 7 / 12 / 16 / 20 / 24 that radius
  *   "shared_gpu" = 1       the caller's hint that other contexts use this context's GPU (pairs in flight): the lone-pair split
  *                          below is never used, whatever the library's own count says at the moment a level is enqueued;

@@ -145,6 +145,12 @@ def test_pixel_window_pass_gives_the_generic_searchs_results(ctx, case, k):
         assert got == want, (case, k, window)
         if window > 1:
             assert info["radius"] == window
+    # the probed radius is remembered by the context (no probe launches on the following calls, a fresh probe every 8th and after
+    # any set_option): ten calls in a row, the same bits every time
+    ctx.set_option("filter_window", 1)
+    for rep in range(10):
+        rec, nrm, st = ctx.filter_last_cloud_host(k, 1.0, 2.5, cam)
+        assert (rec.tobytes(), nrm.tobytes(), (st["mean"], st["stddev"], st["threshold"]), len(rec)) == want, (case, k, "repeat", rep)
     thin = "d0_l0" in PAIRS_W[case]
     if thin and k == 100:   # the thin sheet: the probe settles for the small window, which decides nearly everything
         got, info = _filter_sig(ctx, k, cam, 1)
