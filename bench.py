@@ -683,6 +683,11 @@ def valu_counters(kernel, args):
     return {"insts_valu": int(r["SQ_INSTS_VALU"][0]), "insts_salu": int(r["SQ_INSTS_SALU"][0]),
             "salu_per_valu": round(r["SQ_INSTS_SALU"][0] / max(1.0, r["SQ_INSTS_VALU"][0]), 3),
             "active_frac": round(frac, 4) if frac is not None else None,
+            # the rate dependent fp64 fma chains saturate at on this chip whatever the occupancy or the chains per wave:
+            # 0.72-0.75 of 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (tests/micro/ilp_probe.hip, profiles/r05_ilp_probe.log) --
+            # the ceiling a VALU-bound fp64 kernel is priced against
+            "fp64_issue_ceiling_of_nominal": 0.735,
+            "active_frac_of_ceiling": round(frac / 0.735, 4) if frac is not None else None,
             "launch_ms_in_this_pass": round(dur, 5) if dur else None,
             "fp64_issue_floor_ms": round(dur * frac, 5) if dur and frac is not None else None,
             "shader_clock_GHz": round(clocks / (dur * 1e6), 3) if dur else None,
