@@ -634,6 +634,7 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
     float *lst = (float *)col;
     double sum = 0.0;
     int nl = 0;
+    unsigned int odd_min = 0xffffffffu; // tracks whether an input outside the trimmed square root's range (0 < d2 < 2^-96) was met
     auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB
         float t = (float)b / inv_w;
         while (t > 0.0f && bin_of(__uint_as_float(__float_as_uint(t) - 1u)) >= b) t = __uint_as_float(__float_as_uint(t) - 1u);
@@ -649,8 +650,12 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
         chunk_d2(r, c0, n_, d2);
 #pragma unroll
         for (int i = 0; i < n; i++) {
-            if (d2[i] < t_lo) sum += (double)sqrtf_rn(d2[i]);
-            else if (d2[i] < t_hi) {
+            if (d2[i] < t_lo) {
+                // (the trimmed square root itself; an input it is not made for -- positive and below 2^-96: float32 coordinates do not
+                // produce such differences -- marks the query `odd`, and it is left to the later passes, which take sqrtf)
+                odd_min = min(odd_min, __float_as_uint(d2[i]) - 1u); // (the smallest positive pattern met, minus one; 0 wraps to the top)
+                sum += (double)sqrtf_rn_core(d2[i]);
+            } else if (d2[i] < t_hi) {
                 lst[min(nl, WIN_NB) * 256] = d2[i]; // (nl <= in_bin <= WIN_LCAP by the histogram; the clamp keeps a disagreement inside the column)
                 nl++;
             }
@@ -681,7 +686,7 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
         const float v = lst[i * 256];
         if (v < tau) sum += (double)sqrtf_rn(v);
     }
-    if (!(nl == in_bin && tau < range)) return false;
+    if (!(nl == in_bin && tau < range) || odd_min < 0x0f7fffffu) return false;
     // every point outside the window is farther than sqrt(tau): the k + 1 smallest are all here
     *out = (float)((sum + (double)(want - (below + less)) * (double)sqrtf(tau)) / mean_k);
     return true;
