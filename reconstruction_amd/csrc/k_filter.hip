@@ -634,6 +634,8 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
     float *lst = (float *)col;
     double sum = 0.0;
     int nl = 0;
+    float pend = 0.0f;               // (WIN_PENDING_SQRT) the lane's value waiting for its square root
+    unsigned long long m_full = 0ull; // ... the lanes whose slot is taken
     unsigned int odd_min = 0xffffffffu; // tracks whether an input outside the trimmed square root's range (0 < d2 < 2^-96) was met
     auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB
         float t = (float)b / inv_w;
@@ -650,18 +652,40 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
         chunk_d2(r, c0, n_, d2);
 #pragma unroll
         for (int i = 0; i < n; i++) {
+#ifdef WIN_PENDING_SQRT
+            // A value below t_lo waits in the lane's one-entry slot (0 = empty: its square root adds nothing); the square roots are
+            // taken for the whole wave only when some lane's slot is taken AND it has another value -- every second or third candidate
+            // instead of every one (a tenth of the lanes has a value per candidate, so some lane nearly always does).
+            const unsigned long long mq = __builtin_amdgcn_fcmpf(d2[i], t_lo, 4); // ordered <
+            if (mq & m_full) {
+                odd_min = min(odd_min, __float_as_uint(pend) - 1u);
+                sum += (double)sqrtf_rn_core(pend);
+                pend = 0.0f;
+                m_full = 0ull;
+            }
+            pend = __builtin_amdgcn_inverse_ballot_w64(mq) ? d2[i] : pend;
+            m_full |= mq;
+            if (!(d2[i] < t_lo) && d2[i] < t_hi) {
+#else
             if (d2[i] < t_lo) {
                 // (the trimmed square root itself; an input it is not made for -- positive and below 2^-96: float32 coordinates do not
                 // produce such differences -- marks the query `odd`, and it is left to the later passes, which take sqrtf)
                 odd_min = min(odd_min, __float_as_uint(d2[i]) - 1u); // (the smallest positive pattern met, minus one; 0 wraps to the top)
                 sum += (double)sqrtf_rn_core(d2[i]);
             } else if (d2[i] < t_hi) {
+#endif
                 lst[min(nl, WIN_NB) * 256] = d2[i]; // (nl <= in_bin <= WIN_LCAP by the histogram; the clamp keeps a disagreement inside the column)
                 nl++;
             }
         }
     });
 #endif
+#ifdef WIN_PENDING_SQRT
+    odd_min = min(odd_min, __float_as_uint(pend) - 1u);
+    sum += (double)sqrtf_rn_core(pend);
+#endif
+    (void)pend;
+    (void)m_full;
     // tau = the (want - below)-th smallest of the listed values (by value: ties are equal distances)
     const int rank = want - below; // 1 .. in_bin
     float tau = 0.0f;
