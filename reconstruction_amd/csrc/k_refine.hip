@@ -13,6 +13,9 @@
 // Right-window reads have no bounds check in the reference (.cpp:628): emulated on the flat
 // row-major buffer, bytes outside the whole image read 0 (same rule as oracle/stereo_oracle.c).
 #include "rsm_dev.h"
+#ifndef RF_TU
+#define RF_TU 0 // which part of this file a translation unit compiles: 0 everything but the two time-skewed kernels, 1 k_refine_skew1, 2 k_refine_skew
+#endif
 
 #include <limits.h>
 #include <type_traits>
@@ -124,7 +127,7 @@ __device__ __forceinline__ void exp_neg2(double t1, double t2, double &w1, doubl
     w2 = exp_neg(t2, tab);
 }
 
-#ifndef RF_SKEW1_TU // (k_refine_skew1.hip includes this file for the device functions only)
+#if RF_TU == 0 // (the translation units k_refine_skew.hip / k_refine_skew1.hip include this file for the device functions and ONE kernel each)
 // test entry: the specified exp on an array (rsm_stage_exp_neg); flag = 1: the t < 512 form on every argument below 512
 __global__ void k_exp_neg(const double *t, double *out, long long n, int small_form) {
     __shared__ double2 s_exp[128];
@@ -158,7 +161,7 @@ void launch_refine_init(const StageArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_refine_init, dim3((unsigned)blocks, 1, a.ndir), dim3(256), 0, st, a);
 }
 
-#endif // !RF_SKEW1_TU
+#endif // RF_TU == 0
 // The update of .cpp:652-672 given the data term (pwp, delta = pdp - dCenter).
 __device__ __forceinline__ double refine_update(int mode, double dC, double dE, double dW, double dN, double dS,
                                                 double pwp, double delta, double ws, ExpTab tab) {
@@ -192,7 +195,7 @@ __device__ __forceinline__ double div_unscaled(double a, double b) {
     return __builtin_fma(rem, y, q);
 }
 
-#ifndef RF_SKEW1_TU // (k_refine_skew1.hip includes this file for the device functions only)
+#if RF_TU == 0 // (the translation units k_refine_skew.hip / k_refine_skew1.hip include this file for the device functions and ONE kernel each)
 // test entry (rsm_stage_div_unscaled): the trimmed division beside the compiler's on arrays
 __global__ void k_div_unscaled(const double *a, const double *b, double *q_fast, double *q_ieee, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,7 +208,7 @@ void launch_div_unscaled(const double *a, const double *b, double *q_fast, doubl
     if (n > 0) hipLaunchKernelGGL(k_div_unscaled, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, q_fast, q_ieee, n);
 }
 
-#endif // !RF_SKEW1_TU
+#endif // RF_TU == 0
 // Lane masks straight from the compare (one v_cmp into a scalar pair), combined with scalar logic; rf_sel turns a mask back into
 // a select / branch condition at no cost.  A ballot of a COMBINED bool costs two vector instructions (v_cndmask 0 / 1 + v_cmp).
 #define RF_FNE(x, y) __builtin_amdgcn_fcmp((x), (y), 14) // unordered or not equal: C's !=
@@ -523,7 +526,7 @@ __device__ __forceinline__ void refine_data_term_quad(const uint32_t *__restrict
     refine_entry(x0, x1, x2, pwp, delta);
 }
 
-#ifndef RF_SKEW1_TU // (k_refine_skew1.hip includes this file for the device functions only)
+#if RF_TU == 0 // (the translation units k_refine_skew.hip / k_refine_skew1.hip include this file for the device functions and ONE kernel each)
 // test entry (rsm_stage_refine_xi): the matching costs xi (.cpp:624-629) as each of the three device restatements of the data
 // term computes them, for every row y in [1, H-1), own column x in [1, W-1) and other-view window left edge col in [0, W-3]:
 // out[c][entry] = xi(x, y, col + c), c = 0..2, entry = ((y-1) (W-2) + (x-1)) (W-2) + col.  form 0: refine_left + refine_cost_left
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(256) void k_refine_apply(StageArgs a) {
     }
 }
 
-#endif // !RF_SKEW1_TU
+#endif // RF_TU == 0
 // k_refine_skew's miss path, entered by the whole wave when any of its lanes misses.  A handful of misses per row is the
 // usual case once the iteration has settled: they are listed in LDS and computed four lanes per entry, 16 entries per
 // round (a third of the instructions of a lane computing its own).  The new entries are
@@ -1012,7 +1015,7 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
     }
 }
 
-#ifndef RF_SKEW1_TU // (k_refine_skew1.hip includes this file for the device functions only)
+#if RF_TU == 2 // k_refine_skew.hip: the time-skewed kernel as a translation unit of its own (its scheduling strategy: Makefile)
 // ---------------------------------------------------------------------------------------------------------------
 // T Jacobi sweeps per launch, time-skewed down the rows (option refine_skew_from).
 // A workgroup of T waves owns a strip of 64 columns and a chunk of rows and streams down it: in step s it stages row
@@ -1281,8 +1284,8 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 #endif
 }
 
-#endif // !RF_SKEW1_TU
-#ifdef RF_SKEW1_TU
+#endif // RF_TU == 2
+#if RF_TU == 1 // k_refine_skew1.hip
 // ---------------------------------------------------------------------------------------------------------------
 // The same four time-skewed sweeps with ONE wave per strip (option refine_skew_variant = 64; round 5).
 // What bounds k_refine_skew is not the vector unit (busy half of the launch) but the time its waves spend outside the
@@ -1697,9 +1700,9 @@ void launch_refine_skew1(const StageArgs &a, dim3 grid, hipStream_t st) {
     if (a.flag) hipLaunchKernelGGL(k_refine_skew1<1>, grid, dim3(128), 0, st, a);
     else hipLaunchKernelGGL(k_refine_skew1<0>, grid, dim3(128), 0, st, a);
 }
-#endif // RF_SKEW1_TU
+#endif // RF_TU == 1
 
-#ifndef RF_SKEW1_TU
+#if RF_TU == 2
 // T sweeps f64_a -> f64_b in one launch (a.flag3 = launch index, a.skew_rows = rows per chunk) + the launch that applies
 // its cache updates.  T in {2, 3, 4}.
 void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1715,7 +1718,7 @@ void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev
     if (T == 4 && (a.skew_variant & 64)) { // one wave per strip, two strips per workgroup
         launch_refine_skew1(a, dim3((grid.x + 1) / 2, grid.y, grid.z), st);
         if (ev1) (void)hipEventRecord(ev1, st);
-        hipLaunchKernelGGL(k_refine_apply, dim3(8, RF_UPD_SHARDS), dim3(256), 0, st, a);
+        launch_refine_apply(a, st);
         return;
     }
 #define RF_LAUNCH_V(TT, VV)                                                                                   \
@@ -1738,8 +1741,13 @@ void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev
 #undef RF_LAUNCH_V
 #undef RF_LAUNCH
     if (ev1) (void)hipEventRecord(ev1, st);
-    hipLaunchKernelGGL(k_refine_apply, dim3(8, RF_UPD_SHARDS), dim3(256), 0, st, a);
+    launch_refine_apply(a, st);
 }
+#endif // RF_TU == 2
+
+#if RF_TU == 0
+// scatters a launch's update list into the cache (after k_refine_skew / k_refine_skew1 / k_refine_multi)
+void launch_refine_apply(const StageArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_refine_apply, dim3(8, RF_UPD_SHARDS), dim3(256), 0, st, a); }
 
 void launch_refine_multi(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int rows = 0, cols = 0;
@@ -1787,4 +1795,4 @@ void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0, hip
     if (ev1) (void)hipEventRecord(ev1, st);
 }
 
-#endif // !RF_SKEW1_TU
+#endif

@@ -4,5 +4,5 @@
 // the miss service).  What differs is the compiler's scheduling strategy (Makefile: -mllvm -amdgpu-sched-strategy=max-ilp): the
 // kernel advances four independent rows per step and wants their fp64 chains side by side; the default strategy finishes one
 // row's chain before it starts the next (lowest register pressure), and fencing the stages by hand costs registers.
-#define RF_SKEW1_TU
+#define RF_TU 1
 #include "k_refine.hip"

@@ -131,6 +131,7 @@ void launch_refine_fixup(const StageArgs &a, hipStream_t st);
 // TWO sweeps f64_a -> f64_b in one launch (a.flag3 = launch index) + the launch that applies its cache updates
 void launch_refine_multi(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // T (2..4) sweeps f64_a -> f64_b in one time-skewed launch (a.flag3 = launch index, a.skew_rows) + the cache-update launch
+void launch_refine_apply(const StageArgs &a, hipStream_t st); // k_refine.hip
 void launch_refine_skew1(const StageArgs &a, dim3 grid, hipStream_t st); // k_refine_skew1.hip
 void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
