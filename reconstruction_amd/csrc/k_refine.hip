@@ -1051,7 +1051,10 @@ __device__ __forceinline__ void skew_miss(const StageArgs &a, const DirArgs &d, 
 //   V & 2: the row's predicates as lane masks and the mode-3 update with unscaled divisions (refine_update3m): 8 % fewer
 //          vector instructions per launch (95.8 M against 104.1 M), 12 % more scalar ones, 0.328 ms per launch against 0.310.
 template <int T, int TOP, int V>
-__global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_refine_skew(StageArgs a) {
+#ifndef RF_SKEW_WPE
+#define RF_SKEW_WPE 5 // waves per SIMD the register budget is set for (5: 96 VGPRs, what the 30 KB of LDS per workgroup allow; 4: 128 -- A/B)
+#endif
+__global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(RF_SKEW_WPE, RF_SKEW_WPE))) void k_refine_skew(StageArgs a) {
     constexpr int NE = 2 * T + 1;  // rows of cache entries resident: row r is staged in step r - 1 and last used in step r + 2T - 1
     constexpr int UW = 64 - 2 * T; // columns a strip owns
     __shared__ double s_d[T][4][66];       // [level][row & 3][lane + 1]
