@@ -506,10 +506,15 @@ def main():
                 ab = adapter_bench(cfgs, args.adapter_pairs, args.adapter_inflight if args.adapter_inflight > 0 else F + 2, int(res.v_top))
                 out["adapter"] = ab["records16"]
                 out["value_adapter_pcie_inclusive"] = ab["records16"]["value"]
+                # ... and once the loop's pipeline runs (from the first pair's replay to the last one's: the job's fill left out)
+                if "value_steady" in ab["records16"]:
+                    out["value_adapter_steady"] = ab["records16"]["value_steady"]
                 # the same loop with CCloudOptimization::filter's first half (CCloudOptimization.cpp:82-121, once per pair inside
                 # MatchAllLayer, CStereoMatching.cpp:31) on the pair's GPU, inside the loop: MatchAllFiltered
                 out["adapter_with_filter"] = ab["gpu_filter"]
                 out["value_with_filter"] = ab["gpu_filter"]["value"]
+                if "value_steady" in ab["gpu_filter"]:
+                    out["value_with_filter_steady"] = ab["gpu_filter"]["value_steady"]
                 out["adapter_fp64_points"] = ab["fp64"]
             except Exception as e:  # noqa: BLE001
                 out["adapter"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
@@ -741,6 +746,8 @@ def adapter_bench(cfgs, n_pairs, inflight, v_top):
             d = json.loads(r.stdout.strip().splitlines()[-1])
             d["value"] = round(n * v_top / d["seconds"] / 1e6, 3)
             d["ms_per_pair"] = round(d["seconds"] / n * 1e3, 3)
+            if d.get("steady_s_per_pair", 0) > 0:  # from the first pair's replay to the last one's: the loop once its pipeline runs
+                d["value_steady"] = round(v_top / d["steady_s_per_pair"] / 1e6, 3)
             d["what"] = what[key] % (n, inflight) if "%d" in what[key] else what[key]
             res[key] = d
         return res

@@ -32,6 +32,8 @@ struct BStereo {
     std::vector<float> cloud; // what InsertPoint keeps: float xyz (CCloudOptimization.cpp:61); sized once, filled through `fill`
     size_t fill;
     int64_t points, filters, kept;
+    std::vector<double> done_at; // when each pair's replay finished (seconds on the steady clock): the loop's steady-state rate
+    void stamp() { done_at.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
 };
 struct BTraits {
     typedef BStereo Stereo;
@@ -63,6 +65,7 @@ struct BTraits {
     static void filter(Stereo &s, int) {
         s.filters++;
         s.fill = 0; // (the reference's filter() consumes cloud_in and clears it, CCloudOptimization.cpp:84-121)
+        s.stamp();
     }
     static void cam_center(Stereo &, int, float c[3]) { c[0] = c[1] = c[2] = 0.0f; }
     static void filtered_cloud(Stereo &s, int, const rsm_point16 *pts, const float *nrm, int64_t n_kept, int64_t n_raw) {
@@ -78,6 +81,7 @@ struct BTraits {
         s.points += n_raw;
         s.kept += n_kept;
         s.filters++;
+        s.stamp();
     }
 };
 
@@ -131,9 +135,14 @@ int main(int argc, char **argv) {
     const int ok = filtered ? gpu.MatchAllFiltered(s, n_total, status.data()) : gpu.MatchAll(s, n_total, status.data());
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (ok != n_total) { fprintf(stderr, "MatchAll: %d of %d pairs, %s\n", ok, n_total, gpu.LastError()); return 5; }
+    // steady state: from the first pair's replay to the last one's (the job's fill -- the first pair's upload, match and download with
+    // nothing to overlap -- left out): seconds per pair once the pipeline runs
+    double steady = 0.0;
+    if (s.done_at.size() >= 2) steady = (s.done_at.back() - s.done_at.front()) / (double)(s.done_at.size() - 1);
     printf("{\"pairs\": %d, \"pairs_in_flight\": %d, \"devices\": %d, \"seconds\": %.6f, \"points\": %lld, \"kept\": %lld, \"filters\": %lld, \"v_top_last\": %lld, "
-           "\"want_disparity\": %d, \"fp64_points\": %d, \"gpu_filter\": %d, \"caller_submit_s\": %.4f, \"caller_wait_s\": %.4f, \"caller_replay_s\": %.4f}\n",
+           "\"want_disparity\": %d, \"fp64_points\": %d, \"gpu_filter\": %d, \"caller_submit_s\": %.4f, \"caller_wait_s\": %.4f, \"caller_replay_s\": %.4f, "
+           "\"steady_s_per_pair\": %.6f}\n",
            n_total, inflight, n_dev, dt, (long long)s.points, (long long)s.kept, (long long)s.filters, (long long)gpu.LastVTop(), want_disp ? 1 : 0, (flags & 1) ? 1 : 0,
-           filtered ? 1 : 0, gpu.LastSubmitSeconds(), gpu.LastWaitSeconds(), gpu.LastReplaySeconds());
+           filtered ? 1 : 0, gpu.LastSubmitSeconds(), gpu.LastWaitSeconds(), gpu.LastReplaySeconds(), steady);
     return 0;
 }
