@@ -364,24 +364,13 @@ def main():
         # ---- roofline of the dominant kernel: the top level's Jacobi sweep (k_refine_sweep<1>, one launch per sweep)
         # (hipEvents recorded by the library right around every 8th k_refine_sweep<1> launch, on its own stream)
         # which kernel carries the top level's sweeps: k_refine_skew<T,1> (T time-skewed sweeps per launch, the default
-        # once the iteration has settled), k_refine_multi<1> (option) or the single-sweep k_refine_sweep<1>
+        # once the iteration has settled) or the single-sweep k_refine_sweep<1>
         light_b = prof_acc["refine_light_top"]["bytes"] / max(1, prof_acc["refine_light_top"]["launches"])
-        dom = "refine_light_top"
-        for k in ("refine_multi_top", "refine_skew_top"):
-            if prof_acc.get(k, {"launches": 0})["launches"] > 0:
-                dom = k
+        dom = "refine_skew_top" if prof_acc.get("refine_skew_top", {"launches": 0})["launches"] > 0 else "refine_light_top"
         top = prof_acc[dom]
         spl = int(round(top["bytes"] / max(1, top["launches"]) / light_b)) if light_b > 0 else 1  # sweeps per launch
-        variant = 28   # the library's default (rsm.h: refine_skew_variant), unless an --opt overrides it
-        for o in args.opt:
-            if o.startswith("refine_skew_variant="):
-                variant = int(o.split("=")[1])
-        skew_name = ("k_refine_skew<%d,1,%d> (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level; template arguments: sweeps per launch, top level, variant = option refine_skew_variant)" % (spl, variant if spl == 4 else 0, spl)
-                     if not (variant & 64 and spl == 4) else
-                     "k_refine_skew1<1> (DisparityRefine, 4 time-skewed Jacobi sweeps per launch by one wave per strip, top level; option refine_skew_variant = 64)")
-        kname = {"refine_skew_top": skew_name,
-                 "refine_multi_top": "k_refine_multi<1> (DisparityRefine, two Jacobi sweeps per launch, top level)",
-                 "refine_light_top": "k_refine_sweep<1,0> (DisparityRefine Jacobi sweep, top level)"}[dom]
+        kname = {"refine_skew_top": "k_refine_skew<%d,1> (DisparityRefine, %d time-skewed Jacobi sweeps per launch, top level; template arguments: sweeps per launch, top level)" % (spl, spl),
+                 "refine_light_top": "k_refine_sweep<1> (DisparityRefine Jacobi sweep, top level)"}[dom]
         multi = dom != "refine_light_top"
         launches = max(1, top["launches"])
         avg_ms = top["ms"] / launches
@@ -417,7 +406,7 @@ def main():
         alone = stage_prof[dom]
         alone_ms = alone["ms"] / max(1, alone["launches"])
         alone_gbs = (alone["bytes"] / max(1, alone["launches"])) / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else 0.0
-        total_alg_bytes = sum(v["bytes"] for k, v in stage_prof.items() if k not in ("refine_light_top", "refine_multi_top", "refine_skew_top"))
+        total_alg_bytes = sum(v["bytes"] for k, v in stage_prof.items() if k not in ("refine_light_top", "refine_skew_top"))
         out = {
             "metric": "Mdisparities/s per GPU (11x11 NCC, 128 disp)" if args.config == "c2" else "Mdisparities/s",
             "value": round(value, 3), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
@@ -455,23 +444,46 @@ def main():
         }
         out["roofline"]["traffic_source"] = traffic_source  # measured = this run's own --pmc passes; quoted = profiles/pmc_traffic.json
         valu = traffic_detail.pop("valu", None) if isinstance(traffic_detail, dict) else None
+        scalar = traffic_detail.pop("scalar", None) if isinstance(traffic_detail, dict) else None
         out["roofline"]["traffic_detail"] = traffic_detail
         out["roofline"]["valu"] = valu
-        # what bounds the kernel, from the data: the share of the launch its VALU is busy against the share of the HBM rate a
-        # streaming kernel can reach on this part (6.3 TB/s, MI355X_MICROARCH.md) that its MEASURED traffic takes (alone, as the
-        # PMC passes run it).  `achieved` / `peak` / `frac` stay the contract's: algorithmic bytes against the 8 TB/s HBM peak.
-        if valu and valu.get("active_frac") is not None and traffic and valu.get("launch_ms_in_this_pass"):
-            hbm_util = traffic / (valu["launch_ms_in_this_pass"] * 1e-3) / 1e9 / 6300.0
-            out["roofline"]["bound"] = "hbm" if hbm_util >= valu["active_frac"] else "valu"
+        out["roofline"]["scalar"] = scalar
+        # What bounds the kernel, from the data: every unit's busy share of the launch, first-class fields beside `frac`
+        # (`achieved` / `peak` / `frac` stay the contract's: algorithmic bytes against the 8 TB/s HBM peak = frac_hbm).
+        #   frac_hbm_traffic: the MEASURED HBM bytes of a launch against the rate a streaming kernel reaches on this part (6.3 TB/s,
+        #                     MI355X_MICROARCH.md), alone as the PMC passes run it
+        #   frac_fp64_issue:  the share of the launch a SIMD's VALU is busy (the fp64 issue floor / launch time)
+        #   frac_scalar:      scalar instructions per CU and clock (a CU has ONE scalar unit for its four SIMDs)
+        #   frac_lds:         the share of the launch a CU's waves are inside LDS instructions
+        # `bound` names the largest.  `frac` itself uses roofline.avg_launch_ms (hipEvents around every 8th launch of the timed region,
+        # `launches_timed` of them, pairs in flight); profiles/r06_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same
+        # command) carries the same kernel's average over all its calls.
+        rl = out["roofline"]
+        rl["frac_hbm"] = rl["frac"]
+        rl["launches_timed"] = launches
+        rl["frac_source"] = "algorithmic_bytes_per_launch / avg_launch_ms (hipEvents around %d launches of the timed region, %d pairs in flight) / 8 TB/s" % (launches, F)
+        if valu and valu.get("active_frac") is not None and valu.get("launch_ms_in_this_pass"):
+            fr = {"fp64_issue": valu["active_frac"]}
+            if traffic:
+                fr["hbm_traffic"] = round(traffic / (valu["launch_ms_in_this_pass"] * 1e-3) / 1e9 / 6300.0, 4)
+            if scalar and scalar.get("scalar_issue_frac") is not None:
+                fr["scalar"] = scalar["scalar_issue_frac"]
+                fr["lds"] = scalar.get("active_inst_lds_frac_per_cu")
+            rl["frac_fp64_issue"] = fr["fp64_issue"]
+            rl["frac_hbm_traffic"] = fr.get("hbm_traffic")
+            rl["frac_scalar"] = fr.get("scalar")
+            rl["frac_lds"] = fr.get("lds")
+            best = max((v, k) for k, v in fr.items() if v is not None)
+            rl["bound"] = {"fp64_issue": "valu", "hbm_traffic": "hbm", "scalar": "scalar", "lds": "lds"}[best[1]]
             parked = (valu.get("wave_cycles_split") or {}).get("parked_waitcnt_or_barrier")
-            out["roofline"]["bound_note"] = ("VALU busy %.0f %% of the launch (fp64), measured HBM traffic at %.0f %% of the achievable 6.3 TB/s, a wave parked "
-                                             "(s_waitcnt / barrier) %s of its cycles: %s" % (
-                                                 100 * valu["active_frac"], 100 * hbm_util, ("%.0f %%" % (100 * parked)) if parked is not None else "?",
-                                                 "the fp64 VALU is the busiest unit and neither it nor the memory system is saturated -- the waves' dependent fp64 chains "
-                                                 "(5 waves per SIMD), its issue rate while all workgroups are resident and the launch's low-occupancy tail bound the kernel: "
-                                                 "vector instructions removed early in a row's chain pay (option refine_skew_variant bits 8 / 16), the same removed behind "
-                                                 "a late guard (bit 2) or traded for a shorter chain cost time (DESIGN.md 4)"
-                                                 if hbm_util < valu["active_frac"] else "the memory system is the busiest unit"))
+            rl["bound_note"] = ("busiest unit of the launch (one pair alone, PMC passes): %s at %.0f %%; fp64 VALU %.0f %%, measured HBM traffic %s of the achievable "
+                                "6.3 TB/s, scalar unit %s, LDS %s; a wave parked (s_waitcnt / barrier) %s of its cycles -- no unit is saturated: the kernel is bound "
+                                "by its waves' dependent chains at five waves per SIMD (LDS and registers allow no more) and by the launch's low-occupancy tail"
+                                % (best[1], 100 * best[0], 100 * fr["fp64_issue"],
+                                   ("%.0f %%" % (100 * fr["hbm_traffic"])) if fr.get("hbm_traffic") is not None else "?",
+                                   ("%.0f %%" % (100 * fr["scalar"])) if fr.get("scalar") is not None else "?",
+                                   ("%.0f %%" % (100 * fr["lds"])) if fr.get("lds") is not None else "?",
+                                   ("%.0f %%" % (100 * parked)) if parked is not None else "?"))
         if rig:
             # BASELINE configs[3]: the SAME ten pairs at every N (strong scaling): pair p on rank p % N; a step
             # = all ten pairs matched once + (N > 1) the RCCL fan-in of the ten clouds to rank 0; 10 pairs on 8 GPUs cap at 5x
@@ -667,7 +679,36 @@ def measure_traffic(kernel, args):
         out["valu"] = valu_counters(kernel, args)
     except Exception as e:  # noqa: BLE001
         out["valu"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    try:
+        out["scalar"] = scalar_counters(kernel, args)
+    except Exception as e:  # noqa: BLE001
+        out["scalar"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     return out
+
+
+def scalar_counters(kernel, args):
+    """The scalar and LDS side of the dominant kernel (one more --pmc pass): a CU has ONE scalar unit for its four SIMDs, so
+    scalar wave-instructions are priced per CU, not per SIMD.  SQ_ACTIVE_INST_SCA / SQ_INST_CYCLES_SALU / SQ_ACTIVE_INST_LDS /
+    SQ_WAIT_INST_LDS count quad-cycles summed over the chip's waves; the busy share of a unit is that sum x 4 / (units x the
+    launch's shader clocks)."""
+    ctrs = ["SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_ACTIVE_INST_SCA", "SQ_INST_CYCLES_SALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS",
+            "GRBM_GUI_ACTIVE"]
+    r, dur = pmc_pass(ctrs, kernel, args)
+    n_cu = 256
+    clocks = r["GRBM_GUI_ACTIVE"][0] / max(1.0, r["GRBM_GUI_ACTIVE"][1])
+    if dur and clocks / (dur * 1e6) > 3.0:
+        clocks /= 8.0
+    sca = r["SQ_ACTIVE_INST_SCA"][0] * 4.0 / n_cu       # clocks in which a CU's waves are inside a scalar instruction
+    salu = r["SQ_INST_CYCLES_SALU"][0] * 4.0 / n_cu
+    lds = r["SQ_ACTIVE_INST_LDS"][0] * 4.0 / n_cu
+    return {"insts_salu": int(r["SQ_INSTS_SALU"][0]), "insts_smem": int(r["SQ_INSTS_SMEM"][0]), "insts_branch": int(r["SQ_INSTS_BRANCH"][0]),
+            # lower bound of the scalar unit's busy share: one scalar instruction per clock and CU
+            "scalar_issue_frac": round((r["SQ_INSTS_SALU"][0] + r["SQ_INSTS_SMEM"][0]) / n_cu / clocks, 4) if clocks > 0 else None,
+            "active_inst_sca_frac_per_cu": round(sca / clocks, 4) if clocks > 0 else None,
+            "inst_cycles_salu_frac_per_cu": round(salu / clocks, 4) if clocks > 0 else None,
+            "active_inst_lds_frac_per_cu": round(lds / clocks, 4) if clocks > 0 else None,
+            "wait_inst_lds_quad_cycles": int(r["SQ_WAIT_INST_LDS"][0]),
+            "launch_ms_in_this_pass": round(dur, 5) if dur else None}
 
 
 def valu_counters(kernel, args):

@@ -65,7 +65,11 @@ typedef struct rsm_pair_in {
     int verbose;             /* Verbose (.cpp:12)                                         */
 } rsm_pair_in;
 
-/* Outputs of one pair. Buffers are caller-allocated; NULL skips that output. */
+/* Outputs of one pair. Buffers are caller-allocated; NULL skips that output.
+ * ZERO-INITIALISE the struct (memset / = {0}) before filling it in: the library reads EVERY pointer member, and members are
+ * appended as the ABI grows -- `points16` came with ABI 2 (RSM_ABI_VERSION / rsm_abi_version(); a caller compiled against
+ * the ABI 1 header, whose struct ends at v_top, must be rebuilt: an ABI 2 library reads 8 bytes beyond its struct). */
+#define RSM_ABI_VERSION 2
 typedef struct rsm_pair_out {
     double *disparity[2];   /* width*height fp64 each: disparity[0|1] after the last level  */
     rsm_boundary margin[2]; /* margin[0|1] at the top level (-> cam[pair][v].bound)         */
@@ -87,6 +91,8 @@ int rsm_create(rsm_ctx **ctx, int hip_device);
 void rsm_destroy(rsm_ctx *ctx);
 const char *rsm_last_error(const rsm_ctx *ctx);
 const char *rsm_version(void);
+/* the ABI the library was built with (struct layouts of this header): compare with RSM_ABI_VERSION after loading it */
+int rsm_abi_version(void);
 /* GPUs visible to this process (hipGetDeviceCount; 0 when there is none or no HIP runtime) */
 int rsm_device_count(void);
 
@@ -225,25 +231,16 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          candidates; 0 = by window size from the measured crossover) and which of them take the sliding sums
  *                          (widest interval <= ncc_slide_max, default 512) rather than the int8 row GEMM
  *   "no_exact" = 1         (timing A/B only) skip the reference-order re-evaluation of near-tie pixels
- *   "refine_band_mb" / "refine_band_rows"   time-skewed band schedule of the refine sweeps (0 = whole-frame, default)
  *   "refine_skew_from" / "refine_skew_T" / "refine_skew_min_px" / "refine_skew_waves" / "refine_skew_rows"   time-skewed refine
  *                          sweeps (k_refine_skew): T (2..4, default 4) sweeps per launch from that sweep of a level on (default
  *                          22; 0 = never) at levels with at least min_px margin pixels per direction (default 1 M: the two
- *                          largest levels of a 12 MP pair), aiming at `waves` workgroups (default 1280) or `rows` rows per chunk
- *   "refine_skew_variant"  the T = 4 time-skewed kernel, a bit set (default 28 = 4 + 8 + 16): 4 rows of a strip without a live
- *                          pixel (outside an elliptic mask, a hole) skip the update math (C3 +5 %, C2 unchanged); 8 the row's
- *                          wave-level predicates as lane masks straight from the compares (5.6 % fewer vector instructions,
- *                          +2 %); 16 only the cache way the state selects is read from LDS (+1.5 %); 1 / 2 = two bit-identical
- *                          restatements measured SLOWER (a row's staging shared by two waves / lane masks + unscaled divisions
- *                          behind a late guard), kept for A/B; 0 = round 3's kernel.  Only the instantiated sets are accepted:
- *                          0, 1, 2, 3, 4, 12, 28, 64 (anything else: RSM_E_INVALID).  64 = k_refine_skew1 (round 5): one wave per
- *                          strip advances all four sweeps itself, the state rings in registers, neighbours by lane shifts, no
- *                          barrier, the four rows' updates interleaved -- bit-identical, measured 24 % SLOWER alone (0.37 against
- *                          0.30 ms per launch; DESIGN.md 4 says why), kept for A/B
+ *                          largest levels of a 12 MP pair; a level narrower than 80 columns never), aiming at `waves` workgroups
+ *                          (default 1280) or `rows` rows per chunk
+ *   "refine_skew_uw"       columns a strip of that kernel owns: 0 (default) = 66 - 2T, all that its last sweep can compute from 64
+ *                          lanes; an even number below that (e.g. 56: every strip starts on a 128-byte line of the cache ways) for A/B
  *   "refine_skew_waves_alone"  the workgroups a time-skewed launch aims at while no other context of the device is inside
  *                          rsm_run_pair (default 2560: half as tall chunks, a second round of workgroups shortens the launch's
- *                          tail -- one C2 pair 22.4 -> 21.7 ms; with pairs in flight `refine_skew_waves` applies); 0 = the same
- *   "refine_skew1_strips"  strip-chunks a launch of that kernel aims at (default 2048 = the 8 strips of 18 KB of LDS a CU holds)
+ *                          tail; with pairs in flight `refine_skew_waves` applies); 0 = the same
  *   "cu_share" = n         n > 1: the context's streams are confined to one of n equal shares of the compute units (the
  *                          context's creation ordinal on its device picks the share; measured slower than sharing the whole
  *                          chip in turns); 0 / 1 = the whole chip.  The masked streams are BLOCKING streams
@@ -257,20 +254,18 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          81 x 81 pass gains, 1.4 against 3.9 ms, the 49 x 49 pass does not); default 23, 0 = tile pass + grid ladder only
  *   "filter_window"        rsm_filter_last_cloud's pixel-window pass: 1 (default) radius from a sparse probe (remembered by the context:
  *                          probed again on every 8th call, for another k or image size, when it stops deciding 70 % of the queries and
- *                          after any rsm_set_option), 0 off (the generic grid
+ *                          after any "filter_*" option), 0 off (the generic grid
  *                          search decides every query), 7 / 12 / 16 / 20 / 24 that radius
  *   "shared_gpu" = 1       the caller's hint that other contexts use this context's GPU (pairs in flight): the lone-pair split
  *                          below is never used, whatever the library's own count says at the moment a level is enqueued;
- *                          rsm_run_pairs / rsm_match_pairs set it themselves, RsmStereoAdapter sets it for its slots
+ *                          rsm_run_pairs / rsm_match_pairs derive the same per call from their pool (the option stays as the caller
+ *                          set it), RsmStereoAdapter sets it for its slots when it creates them
  *   "refine_prefill"       1 (default): the first sweep of a level also fills the second cache way (0: A/B)
  *   "refine_split"         1 (default): a pair that has the GPU to itself (no other context of the device inside rsm_run_pair,
  *                          no per-launch timing) runs the two directions of its time-skewed sections as separate launch chains
  *                          on its two streams (one's low-occupancy tail beside the other's head: one C2 pair 24.1 -> 23.0 ms);
  *                          not used with pairs in flight (measured slower there): the library counts the contexts of the device
  *                          that are inside rsm_run_pair when a level is enqueued, and "shared_gpu" rules it out altogether
- *   "refine_multi_from" / "refine_multi_min_px"   two sweeps per launch from that sweep on (0 = never, default)
- *   "refine_defer_from" / "refine_defer_to" / "refine_defer_min_px"   sweeps whose data-term cache misses are listed and served
- *                          by a second kernel, a lane per miss, instead of inside the sweep (to = 0 = never, default)
  *   "heavy_exclusive" = 0 | 1 | 2   contexts sharing a GPU: no turns / the top level's refine sweeps take turns (default) /
  *                          every large level's; "heavy_min_px", "heavy_from_sweep" bound the sections that take turns;
  *                          "heavy_lanes" = 2 (default): a level's single-sweep part (fabric-bound) and its time-skewed part

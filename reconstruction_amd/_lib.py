@@ -72,7 +72,7 @@ class RectifyOut(C.Structure):
 
 # every symbol include/rsm.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
-    "rsm_create", "rsm_destroy", "rsm_last_error", "rsm_version", "rsm_device_count", "rsm_filter_last_cloud_host", "rsm_filter_last_info", "rsm_match_pair", "rsm_upload_pair",
+    "rsm_create", "rsm_destroy", "rsm_last_error", "rsm_version", "rsm_abi_version", "rsm_device_count", "rsm_filter_last_cloud_host", "rsm_filter_last_info", "rsm_match_pair", "rsm_upload_pair",
     "rsm_upload_pair_device", "rsm_run_pair", "rsm_download_pair", "rsm_result_device", "rsm_export_cloud_device",
     "rsm_set_option", "rsm_profile_enable", "rsm_profile_stage_count", "rsm_profile_stage_name", "rsm_profile_get",
     "rsm_stage_find_margin", "rsm_stage_pyr_down", "rsm_stage_erode_ellipse", "rsm_stage_initial_match",
@@ -100,6 +100,9 @@ def load():
     lib.rsm_last_error.restype = C.c_char_p
     lib.rsm_last_error.argtypes = [C.c_void_p]
     lib.rsm_version.restype = C.c_char_p
+    abi = lib.rsm_abi_version() if hasattr(lib, "rsm_abi_version") else 1   # include/rsm.h: RSM_ABI_VERSION (PairOut below carries points16)
+    if abi != 2 and os.environ.get("RSM_AB_OLD_LIBRARY") != "1":          # (the A/B scripts load round 5's library: same layouts, no version symbol)
+        raise RsmError(RSM_E_STATE, "librsm_mi355.so has ABI %d, this binding ABI 2: rebuild the library" % abi)
     lib.rsm_profile_stage_name.restype = C.c_char_p
     lib.rsm_destroy.restype = None
     lib.rsm_host_alloc.restype = C.c_void_p

@@ -38,7 +38,6 @@ enum Stage {
     ST_REFINE_SWEEP,     // all levels below the top
     ST_REFINE_SWEEP_TOP, // the top level's sweeps (light + worklist kernels)
     ST_REFINE_LIGHT_TOP, // only the k_refine_sweep<1> launches of the top level
-    ST_REFINE_MULTI_TOP, // only the k_refine_multi<1> launches of the top level (two sweeps each)
     ST_REFINE_SKEW_TOP,  // only the k_refine_skew<T,1> launches of the top level (T sweeps each; the dominant kernel)
     ST_UNIQ64,
     ST_CLOUD,
@@ -46,7 +45,7 @@ enum Stage {
 };
 static const char *kStageNames[ST_COUNT] = {"pyramid", "margin", "boxsum", "initial_match", "smooth", "order",
                                             "uniqueness_s16", "rematch", "median", "refine_init",
-                                            "refine_sweep", "refine_sweep_top", "refine_light_top", "refine_multi_top", "refine_skew_top", "uniqueness_f64", "cloud"};
+                                            "refine_sweep", "refine_sweep_top", "refine_light_top", "refine_skew_top", "uniqueness_f64", "cloud"};
 
 struct EvPair {
     hipEvent_t a, b;
@@ -79,16 +78,14 @@ struct rsm_ctx {
     int16_t *d16i[RSM_MAX_LEVELS][2]{}, *d16s[RSM_MAX_LEVELS][2]{}, *d16m[RSM_MAX_LEVELS][2]{}; // per level: initial-match / constraint-stage / median maps, pre-filled NOMATCH
     double *f64[3][2]{};
     int32_t *nv[2]{};
-    int16_t *rf_key[2]{};
+    uint32_t *rf_key[2]{};
     int32_t *rf_cnt = nullptr; // NCC wide-pixel counter
     int32_t *wrow = nullptr;   // NCC: wide pixels per (direction, row) of the level at hand
     uint32_t *rf_list = nullptr;
     uint32_t *tie_list = nullptr; // NCC tie pixels (k_ncc_exact)
     int32_t *tie_cnt = nullptr;   // [2 * level + (Rematch ? 1 : 0)]
-    double *rf_pwp[2]{}, *rf_delta[2]{};
-    RfMiss *miss_list = nullptr; // deferred refine misses (k_refine_fixup)
-    int miss_cap = 0;
-    RfUpd *upd_list = nullptr; // k_refine_multi's cache updates
+    double2 *rf_ent[2]{};
+    RfUpd *upd_list = nullptr; // k_refine_skew's cache updates
     int32_t *upd_cnt = nullptr;
     int upd_cap = 0;
     int32_t *prefix = nullptr;
@@ -105,6 +102,8 @@ struct rsm_ctx {
     int32_t *upd_cnt2 = nullptr;
     int opt_refine_split = 1;       // a pair that has the GPU to itself runs the two directions of its time-skewed sections on two streams
     int opt_shared_gpu = 0;         // the caller's hint that other contexts use this GPU (a pool of pairs in flight): never split, whatever g_running says at the moment
+    int pool_shared = 0;            // the same, derived per call by rsm_run_pairs / rsm_match_pairs from their pool (the caller's option stays as set)
+    bool shared_now() const { return opt_shared_gpu || pool_shared; }
     std::atomic<int> in_run{0};     // inside rsm_run_pair (options that replace the streams refuse to act then)
     int32_t *row_count = nullptr;
     int64_t *row_offset = nullptr;
@@ -138,21 +137,14 @@ struct rsm_ctx {
     int opt_heavy_min_px = 400000; // ... from this many margin pixels on (smaller levels are launch-bound themselves)
     int opt_heavy_lanes = 2;     // 2: the single-sweep part and the time-skewed part of a level's refine take turns separately (lanes 0 / 1)
     int opt_heavy_exclusive = 1; // refine sections of contexts sharing a GPU take turns (heavy_begin): 1 = the top level's, 2 = every large level's, 0 = none
-    int opt_refine_defer_from = 4, opt_refine_defer_to = 0;  // sweeps whose cache misses go to k_refine_fixup (to = 0: never -- the default: measured slower)
-    double opt_refine_defer_min_px = 1.0e6;                  // ... on levels with at least this many margin pixels per direction
-    int opt_refine_band_mb = 0;  // working set of one refine band (refine_sweeps); 0 = whole-frame sweeps (default: measured faster)
-    int opt_refine_multi_from = 0;  // first sweep of a level that may run in the two-sweeps-per-launch kernel (0: never = default: measured slower, k_refine.hip)
-    int opt_refine_multi_min_px = 400000; // ... at levels with at least this many margin pixels
-    int opt_refine_band_rows = 0; // > 0: band height in rows, overrides refine_band_mb (tests)
     int opt_refine_skew_from = 22; // first sweep of a level that may run in the time-skewed kernel (k_refine_skew; 0: never): before that too many pixels still miss the data-term cache for its lane-serial miss service
     int opt_refine_prefill = 1;    // k_refine_first also fills the second cache way with the neighbour iMatch its update points to
     int opt_refine_skew_T = 4;     // sweeps per time-skewed launch (2..4)
     int opt_refine_skew_min_px = 1000000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
     int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
     int opt_refine_skew_waves_alone = 2560; // ... when no other context of the device is inside rsm_run_pair (0: the same)
-    int opt_refine_skew1_strips = 2048;  // strip-chunks a launch of the one-wave-per-strip kernel (refine_skew_variant 64) aims at
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
-    int opt_refine_skew_variant = 28;    // T = 4 kernel (k_refine.hip), a bit set: 4 rows without a live pixel skip the update math, 8 the row's predicates as lane masks, 16 only the selected cache way is read (all three default); bits 0 / 1 = two bit-identical restatements measured slower
+    int opt_refine_skew_uw = 0;          // columns a strip owns; 0: 66 - 2T, all its last level can compute (an even number <= that: A/B)
 
     // profiling
     bool profile = false;
@@ -264,7 +256,8 @@ static void ellipse_spans(int k, std::vector<int> &j1, std::vector<int> &j2) {
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" const char *rsm_version(void) { return "rsm-mi355 0.2 (gfx950)"; }
+extern "C" const char *rsm_version(void) { return "rsm-mi355 0.3 (gfx950)"; }
+extern "C" int rsm_abi_version(void) { return RSM_ABI_VERSION; }
 extern "C" int rsm_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
@@ -402,9 +395,8 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
         DALLOC(c, c->BR[v], px);
         for (int i = 0; i < 3; i++) DALLOC(c, c->f64[i][v], px);
         DALLOC(c, c->nv[v], px / 4 + 16);
-        DALLOC(c, c->rf_key[v], 2 * px);
-        DALLOC(c, c->rf_pwp[v], 2 * px);
-        DALLOC(c, c->rf_delta[v], 2 * px);
+        DALLOC(c, c->rf_key[v], px);     // both ways' keys of a pixel in one dword
+        DALLOC(c, c->rf_ent[v], 2 * px); // a (pwp, delta) record per way
     }
     DALLOC(c, c->rf_cnt, 32 + 2 * (size_t)in->height); // level k uses rf_cnt + k: [0] wide-pixel count, [16 + dir * H + y] Rematch pixels of a row
     DALLOC(c, c->rf_list, std::max(2 * px + 64, 2 * SETB_SCRATCH(in->width)));
@@ -415,9 +407,6 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->upd_list2, (size_t)RF_UPD_SHARDS * c->upd_cap);
     DALLOC(c, c->upd_cnt2, 2 * RF_UPD_SHARDS);
     DALLOC(c, c->upd_cnt, 2 * RF_UPD_SHARDS);
-    // every pixel of the sweep workgroups (256 x RF_PPT pixels each, both directions) that can hash to one shard
-    c->miss_cap = (int)((((size_t)(in->width / 256 + 2) * (size_t)(in->height / RF_PPT + 2) * 2) / RF_UPD_SHARDS + 2) * 256 * RF_PPT);
-    c->miss_list = nullptr; // 227 MB at C2 for a path that is off by default: allocated by rsm_run_pair when refine_defer_to > 0
     DALLOC(c, c->tie_cnt, 2 * RSM_MAX_LEVELS);
     DALLOC(c, c->prefix, (size_t)(in->width + 1) * in->height);
     DALLOC(c, c->blk, CLOUD_BLOCKS(in->width, in->height));
@@ -512,37 +501,30 @@ static void prof_end(rsm_ctx *c, int slot, int stage, int launches, double bytes
 
 extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     if (!c || !name) return RSM_E_INVALID;
-    c->filt_memo_radius = 0; // (any option change: the cloud filter probes its window radius afresh)
+    if (!strncmp(name, "filter_", 7)) c->filt_memo_radius = 0; // (the cloud filter's own options: it probes its window radius afresh)
     if (!strcmp(name, "ncc_bytes")) c->opt_ncc_bytes = value != 0;
     else if (!strcmp(name, "heavy_from_sweep")) c->opt_heavy_from_sweep = (int)std::max(1LL, std::min(value, 100000LL));
     else if (!strcmp(name, "heavy_min_px")) c->opt_heavy_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "heavy_lanes")) c->opt_heavy_lanes = (int)std::max(1LL, std::min(value, 2LL));
     else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = (int)std::max(0LL, std::min(value, 2LL));
     else if (!strcmp(name, "no_rowgemm")) c->opt_no_rowgemm = value != 0 ? 1 : 0;
-    else if (!strcmp(name, "refine_defer_from")) c->opt_refine_defer_from = (int)value;
-    else if (!strcmp(name, "refine_defer_to")) c->opt_refine_defer_to = (int)value;
-    else if (!strcmp(name, "refine_defer_min_px")) c->opt_refine_defer_min_px = (double)value;
     else if (!strcmp(name, "wide_rows")) c->opt_no_rowgemm = (value >= 0 && value <= 3) ? (int)value : 0;
     else if (!strcmp(name, "ncc_mid")) c->opt_ncc_mid = value <= 0 ? 0 : (int)std::max(8LL, std::min(value, 160LL));
     else if (!strcmp(name, "ncc_slide_max")) c->opt_ncc_slide_max = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "no_exact")) c->opt_no_exact = value != 0;
-    else if (!strcmp(name, "refine_multi_from")) c->opt_refine_multi_from = (int)std::max(0LL, std::min(value, 100000LL));
-    else if (!strcmp(name, "refine_multi_min_px")) c->opt_refine_multi_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_from")) c->opt_refine_skew_from = (int)std::max(0LL, std::min(value, 100000LL));
     else if (!strcmp(name, "refine_prefill")) c->opt_refine_prefill = value != 0;
     else if (!strcmp(name, "refine_split")) c->opt_refine_split = (int)std::max(0LL, std::min(value, 2LL)); // 2: also with pairs in flight (A/B)
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
-    else if (!strcmp(name, "refine_skew_variant")) { // only these instantiations of k_refine_skew<4, TOP, V> exist
-        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 12 && value != 28 && value != 64)
-            return set_err(c, RSM_E_INVALID, "refine_skew_variant %lld: the instantiated variants are 0, 1, 2, 3, 4, 12, 28, 64", value);
-        c->opt_refine_skew_variant = (int)value;
+    else if (!strcmp(name, "refine_skew_uw")) { // an even number of columns (the state row's 16-byte pieces start on even columns)
+        if (value < 0 || value > 62 || (value & 1)) return set_err(c, RSM_E_INVALID, "refine_skew_uw %lld: 0 (= 66 - 2T) or an even number <= 66 - 2T", value);
+        c->opt_refine_skew_uw = (int)value;
     } else if (!strcmp(name, "shared_gpu")) c->opt_shared_gpu = value != 0;
     else if (!strcmp(name, "filter_list")) c->opt_filter_list = (int)std::max(0LL, std::min(value, 31LL)); // bit 0: the 24-pixel list pass, bit 1: the 40-pixel one, bit 2: the wave passes (80, 160, ... pixels) for what they leave, bits 3 / 4: the 24- / 40-pixel pass in the wave form too
     else if (!strcmp(name, "filter_window")) c->opt_filter_window = (int)std::max(0LL, std::min(value, 24LL)); // 0 off, 1 default, else the radius
     else if (!strcmp(name, "refine_skew_waves_alone")) c->opt_refine_skew_waves_alone = (int)std::max(0LL, std::min(value, 1000000LL));
-    else if (!strcmp(name, "refine_skew1_strips")) c->opt_refine_skew1_strips = (int)std::max(1LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "refine_skew_rows")) c->opt_refine_skew_rows = (int)std::max(0LL, std::min(value, 1000000LL));
     else if (!strcmp(name, "cu_share")) {
         // Contexts that share a GPU each on their own share of the compute units (the `ordinal % n`-th of n equal ranges of the
@@ -577,9 +559,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
         c->stream = s1;
         c->stream2 = s2;
         c->opt_cu_share = n;
-    } else if (!strcmp(name, "refine_band_mb")) c->opt_refine_band_mb = (int)std::max(0LL, std::min(value, 4096LL));
-    else if (!strcmp(name, "refine_band_rows")) c->opt_refine_band_rows = (int)std::max(0LL, std::min(value, 1000000LL));
-    else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
+    } else return set_err(c, RSM_E_INVALID, "unknown option %s", name);
     return RSM_OK;
 }
 
@@ -628,11 +608,7 @@ static StageArgs level_args(rsm_ctx *c, int k) {
     a.upd_list = c->upd_list;
     a.upd_cnt = c->upd_cnt;
     a.upd_cap = c->upd_cap;
-    a.miss_list = c->miss_list;
-    a.miss_cap = c->miss_cap;
     a.rf_stride = c->cap_px;
-    a.row_lo = 0;
-    a.row_hi = INT_MAX;
     a.opt_ncc_bytes = c->opt_ncc_bytes;
     a.opt_no_exact = c->opt_no_exact;
     for (int v = 0; v < 2; v++) {
@@ -654,8 +630,7 @@ static StageArgs level_args(rsm_ctx *c, int k) {
         d.BR = c->BR[v];
         d.parent_nv = c->nv[v];
         d.rf_key = c->rf_key[v];
-        d.rf_pwp = c->rf_pwp[v];
-        d.rf_delta = c->rf_delta[v];
+        d.rf_ent = c->rf_ent[v];
     }
     return a;
 }
@@ -663,23 +638,10 @@ static StageArgs level_args(rsm_ctx *c, int k) {
 static bool degenerate(const Mg &m) { return m.YL >= m.YR || m.XL >= m.XR; } // .cpp:827
 
 // DisparityRefine's Jacobi sweeps (.cpp:590-678): sweep t reads A (t even) or B (t odd) and writes the other.
-//
-// Band schedule (options refine_band_mb / refine_band_rows; off by default).  A sweep streams 52 B per pixel (state
-// in and out + the data-term cache entries) and a level's sweeps re-stream the same arrays 30..150 times, 0.3-0.6 GB
-// per sweep at the large levels.  The sweeps can be time-skewed over bands of rows: band j performs ALL sweeps
-// 1..iters-1 on itself before band j+1 starts, its row window sliding up one row per sweep, rows
-// [Y0 + j*B - u, Y0 + (j+1)*B - u) at step u.  A Jacobi update of row y in sweep t needs rows y-1..y+1 of sweep
-// t-1: row y+1 lies in the same band's previous window, row y-1 at the window's upper edge in band j-1, which has
-// finished; and nothing a later launch still needs is overwritten (the two ping-pong buffers hold sweep t-1 / t
-// of exactly the rows the sliding window covers).  So the values are those of whole-frame sweeps, bit for bit
-// (tests/test_gpu_parity.py::test_refine_band_schedule_is_bit_identical) while a band's working set stays in the
-// 256 MB Infinity Cache.  MEASURED (C2, round 2): no gain -- 48 / 96 / 144 / 192 MB bands run the level in 30.2 /
-// 23.1 / 20.2 / 19.4 ms against 19.1 ms whole-frame.  tests/micro/wsbw.hip shows why: a working set that fits the
-// Infinity Cache streams at 6.0-6.5 TB/s (read) against 5.3 TB/s from HBM -- the fabric between the XCD L2s and
-// the memory side is the limit either way -- and the shorter launches lose more than that 15 percent.
-// Returns the number of sweeps launched; *final_in_B tells which buffer holds the result.
-// Large levels run their settled sweeps two per launch (k_refine_multi, from sweep `refine_multi_from` on: before
-// that too many pixels still miss the data-term cache for its in-wave miss service).
+// Sweep 0 is k_refine_first (every pixel computes its data term); then one launch per sweep (k_refine_sweep) while the
+// data-term cache fills, and from sweep `refine_skew_from` on the large levels run T sweeps per launch, time-skewed
+// (k_refine_skew.hip), with the leftover sweeps single again.  Returns the number of sweeps launched; *final_in_B tells
+// which buffer holds the result.
 static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double *const bufB[2], int iters,
                          hipStream_t st, bool top, bool *final_in_B, double heavy_px = 0.0) {
     int launches = 0;
@@ -691,31 +653,27 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
         }
         a.flag2 = t;
     };
-    auto window_bytes = [&](int lo, int hi) { // 16 B per interior pixel of the rows [lo, hi) (fp64 in + out)
+    auto level_bytes = [&]() { // 16 B per interior pixel (fp64 in + out)
         double bytes = 0;
         for (int v = 0; v < a.ndir; v++) {
-            const int r0 = std::max(a.d[v].own.YL + 1, lo), r1 = std::min(a.d[v].own.YR, hi);
+            const int r0 = a.d[v].own.YL + 1, r1 = a.d[v].own.YR;
             if (r1 > r0) bytes += 16.0 * (r1 - r0) * (a.d[v].own.XR - a.d[v].own.XL + 1);
         }
         return bytes;
     };
     int nlaunch = 0;
     bool split_now = false; // inside a time-skewed section whose two directions run on two streams (below)
-    auto launch = [&](int t, int lo, int hi, int multi) { // sweeps t .. t + (multi ? multi : 1) - 1 over the rows [lo, hi); multi = 2: k_refine_multi, < 0: k_refine_skew with T = -multi
-        const int skewT = multi < 0 ? -multi : 0;
-        if (skewT) multi = skewT;
+    auto launch = [&](int t, int skewT) { // sweeps t .. t + max(skewT, 1) - 1; skewT > 0: one k_refine_skew launch
         bind(t);
-        a.row_lo = lo;
-        a.row_hi = hi;
         const bool timed = c && c->profile && top && (nlaunch++ & 7) == 4;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (timed) { // every 8th sweep of the dominant kernel
-            const int stg = skewT ? ST_REFINE_SKEW_TOP : multi ? ST_REFINE_MULTI_TOP : ST_REFINE_LIGHT_TOP;
+        if (timed) { // every 8th sweep launch of the top level
+            const int stg = skewT ? ST_REFINE_SKEW_TOP : ST_REFINE_LIGHT_TOP;
             const int es = prof_slot(c, stg);
             e0 = c->evpool[es].a;
             e1 = c->evpool[es].b;
             c->prof_launches[stg] += 1;
-            c->prof_bytes[stg] += (multi ? (double)multi : 1.0) * window_bytes(lo, hi);
+            c->prof_bytes[stg] += (skewT ? (double)skewT : 1.0) * level_bytes();
         }
         if (skewT && split_now) { // the two directions as two launch chains: one's tail runs beside the other's head
             StageArgs a0 = a, a1 = a;
@@ -726,134 +684,84 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
             launch_refine_skew(a0, skewT, st, e0, e1); // (e0 / e1: only under refine_split = 2, an A/B mode)
             launch_refine_skew(a1, skewT, c->stream2, nullptr, nullptr);
         } else if (skewT) launch_refine_skew(a, skewT, st, e0, e1);
-        else if (multi) launch_refine_multi(a, st, e0, e1);
         else launch_refine_sweep(a, st, e0, e1);
-        launches += multi ? multi : 1;
+        launches += skewT ? skewT : 1;
         curB = !curB;
     };
     *final_in_B = false;
     if (iters <= 0) return 0;
-    int Y0 = INT_MAX, Y1 = INT_MIN; // interior rows [Y0, Y1) over the directions
-    double row_bytes = 0, px = 0;
-    for (int v = 0; v < a.ndir; v++) {
-        Y0 = std::min(Y0, a.d[v].own.YL + 1);
-        Y1 = std::max(Y1, a.d[v].own.YR);
-        row_bytes += 52.0 * (a.d[v].own.XR - a.d[v].own.XL + 1);
-        px += (double)(a.d[v].own.XR - a.d[v].own.XL + 1) * (a.d[v].own.YR - a.d[v].own.YL + 1);
-    }
+    double px = 0;
+    for (int v = 0; v < a.ndir; v++) px += (double)(a.d[v].own.XR - a.d[v].own.XL + 1) * (a.d[v].own.YR - a.d[v].own.YL + 1);
     bind(0);
-    a.row_lo = 0;
-    a.row_hi = INT_MAX;
     a.flag3 = (c && !c->opt_refine_prefill) ? 2 : 0;
     launch_refine_sweep(a, st); // k_refine_first: whole interior
     a.flag3 = 0;
     launches++;
     curB = true;
-    const int nsw = iters - 1;
-    int B = 0;
-    if (c && c->opt_refine_band_rows > 0) B = c->opt_refine_band_rows;
-    else if (c && c->opt_refine_band_mb > 0) B = std::max(4 * RF_PPT, (int)((double)c->opt_refine_band_mb * 1048576.0 / row_bytes) & ~(RF_PPT - 1));
-    if (B <= 0 || B >= Y1 - Y0 || nsw < 2) { // whole-frame sweeps
-        const bool multi = c && c->opt_refine_multi_from > 0 && a.upd_list && px / a.ndir >= c->opt_refine_multi_min_px;
-        if (multi) (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
-        int nmulti = 0;
-        // sweeps whose cache misses are deferred to k_refine_fixup (a lane per miss) instead of being served inside the sweep
-        // settled sweeps of the large levels T per launch, time-skewed (k_refine_skew)
-        const bool skew = c && c->opt_refine_skew_from > 0 && a.upd_list && !multi && px / a.ndir >= c->opt_refine_skew_min_px;
-        const int skewT = skew ? c->opt_refine_skew_T : 0;
-        if (skew) {
-            (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
-            int rows = 1, strips = 0, strips_max = 0;
-            for (int v = 0; v < a.ndir; v++) {
-                rows = std::max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
-                const int sv = (std::max(1, a.d[v].own.XR - a.d[v].own.XL - 1) + (64 - 2 * skewT) - 1) / (64 - 2 * skewT);
-                strips += sv;
-                strips_max = std::max(strips_max, sv);
-            }
-            // (variant 64, one wave per strip: 8 strips of 18 KB of LDS are resident per CU, two per workgroup -- the launch's grid is
-            // ceil(widest direction's strips / 2) x chunks x directions workgroups and must not exceed the resident 4 per CU by a few)
-            // A pair that has the GPU to itself takes twice as many, half as tall chunks: its launches end in a tail of one or two
-            // waves per SIMD that nothing else fills, and a second round of workgroups shortens it (one C2 pair 22.4 -> 21.7 ms);
-            // with pairs in flight the other pairs' kernels fill the tail and the extra pipeline fill only costs (332 -> 326).
-            const bool lone = c->device < RSM_MAX_DEVICES && !c->opt_shared_gpu && g_running[c->device].load() == 1 && c->opt_refine_skew_waves_alone > 0;
-            const int waves = lone ? c->opt_refine_skew_waves_alone : c->opt_refine_skew_waves;
-            const int chunks = (c->opt_refine_skew_variant & 64) ? std::max(1, (c->opt_refine_skew1_strips / 2) / std::max(1, a.ndir * ((strips_max + 1) / 2)))
-                                                                 : std::max(1, waves / std::max(1, strips));
-            a.skew_variant = c->opt_refine_skew_variant;
-            a.skew_rows = c->opt_refine_skew_rows > 0 ? c->opt_refine_skew_rows : std::max(4 * skewT, (rows + chunks - 1) / chunks);
+    // settled sweeps of the large levels T per launch, time-skewed (k_refine_skew)
+    const bool skew = c && c->opt_refine_skew_from > 0 && a.upd_list && px / a.ndir >= c->opt_refine_skew_min_px && refine_skew_fits(a);
+    const int skewT = skew ? c->opt_refine_skew_T : 0;
+    if (skew) {
+        (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
+        a.skew_uw = (c->opt_refine_skew_uw > 0 && c->opt_refine_skew_uw <= 66 - 2 * skewT) ? c->opt_refine_skew_uw : 66 - 2 * skewT;
+        int rows = 1, strips = 0;
+        for (int v = 0; v < a.ndir; v++) {
+            rows = std::max(rows, a.d[v].own.YR - a.d[v].own.YL - 1);
+            strips += refine_skew_strips(a.d[v].own, skewT, a.skew_uw);
         }
-        int nskew = 0;
-        const bool may_defer = c && c->opt_refine_defer_to > 0 && a.miss_list && !multi && !skew && px / a.ndir >= c->opt_refine_defer_min_px;
-        if (may_defer) (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
-        int ndefer = 0;
-        // the section that takes turns with the other contexts of this GPU starts once the sweeps have settled into pure
-        // streaming: the first ones are busy computing data terms (VALU) and run well beside another pair's streaming sweeps
-        bool held = false;
-        int lane = 0;
-        const int turn_from = (c && heavy_px > 0.0) ? std::min(std::max(c->opt_heavy_from_sweep, 1), iters) : iters + 1;
-        // A pair that has the GPU to itself (no other context inside rsm_run_pair on this device, no per-launch timing) runs the
-        // two directions of a time-skewed section as separate launch chains on its two streams: every skewed launch ends in a
-        // tail of one or two waves per SIMD, and the other direction's launch fills it.  With pairs in flight the
-        // other pairs' kernels do that already, and the split costs throughput (measured): not used there.
-        const bool may_split = skew && a.ndir == 2 && c->opt_refine_split && (!c->profile || c->opt_refine_split == 2) && c->stream2 != st && c->upd_list2 &&
-                               c->device < RSM_MAX_DEVICES && (c->opt_refine_split == 2 || (!c->opt_shared_gpu && g_running[c->device].load() == 1));
-        auto join = [&]() {
-            if (!split_now) return;
-            (void)hipEventRecord(c->ev_join, c->stream2);
-            (void)hipStreamWaitEvent(st, c->ev_join, 0);
-            split_now = false;
-        };
-        for (int t = 1; t < iters;) {
-            const bool skew_now = skew && t >= c->opt_refine_skew_from && t + skewT <= iters;
-            if (!skew_now) join(); // (before the lane is handed on: the section's end event must cover the second stream's launches)
-            if (c && c->opt_heavy_lanes == 2 && (int)skew_now != lane && t >= turn_from) { // the section changes kind: hand its lane on
-                heavy_end(c, held, lane);
-                held = false;
-                lane = (int)skew_now;
-            }
-            if (t >= turn_from && !held) held = heavy_begin(c, heavy_px, top, lane);
-            if (skew_now && may_split && !split_now) { // fork: the second stream continues from here -- AFTER heavy_begin's wait has
-                                                       // been enqueued on `st`, so the second direction takes turns like the first
-                (void)hipMemsetAsync(c->upd_cnt2, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
-                (void)hipEventRecord(c->ev_fork, st);
-                (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-                split_now = true;
-            }
-            if (multi && t >= c->opt_refine_multi_from && t + 1 < iters) {
-                a.flag3 = nmulti++;
-                launch(t, 0, INT_MAX, 2);
-                t += 2;
-            } else if (skew_now) {
-                a.flag3 = nskew++;
-                launch(t, 0, INT_MAX, -skewT);
-                t += skewT;
-            } else {
-                const bool defer = may_defer && t >= c->opt_refine_defer_from && t <= c->opt_refine_defer_to;
-                a.defer = defer;
-                if (defer) a.flag3 = ndefer++;
-                launch(t, 0, INT_MAX, 0);
-                if (defer) { // a.f64_a / f64_b are still bound as for the sweep
-                    launch_refine_fixup(a, st);
-                    launches++;
-                }
-                a.defer = 0;
-                t += 1;
-            }
-        }
-        join();
-        heavy_end(c, held, lane);
-    } else { // time-skewed bands: sweep u + 1 of band j reads what sweep u wrote, buffers alternate with u
-        for (int j = 0; Y0 + j * B - (nsw - 1) < Y1; j++)
-            for (int u = 0; u < nsw; u++) {
-                const int lo = std::max(Y0 + j * B - u, Y0), hi = std::min(Y0 + (j + 1) * B - u, Y1);
-                if (lo >= hi) continue;
-                curB = (u & 1) == 0; // sweep u + 1 reads B for even u
-                launch(u + 1, lo, hi, 0);
-            }
-        curB = (iters & 1) != 0;
+        // A pair that has the GPU to itself takes twice as many, half as tall chunks: its launches end in a tail of one or two
+        // waves per SIMD that nothing else fills, and a second round of workgroups shortens it; with pairs in flight the other
+        // pairs' kernels fill the tail and the extra pipeline fill only costs.
+        const bool lone = c->device < RSM_MAX_DEVICES && !c->shared_now() && g_running[c->device].load() == 1 && c->opt_refine_skew_waves_alone > 0;
+        const int waves = lone ? c->opt_refine_skew_waves_alone : c->opt_refine_skew_waves;
+        const int chunks = std::max(1, waves / std::max(1, strips));
+        a.skew_rows = c->opt_refine_skew_rows > 0 ? c->opt_refine_skew_rows : std::max(4 * skewT, (rows + chunks - 1) / chunks);
     }
-    a.row_lo = 0;
-    a.row_hi = INT_MAX;
+    int nskew = 0;
+    // the section that takes turns with the other contexts of this GPU starts once the sweeps have settled into pure
+    // streaming: the first ones are busy computing data terms (VALU) and run well beside another pair's streaming sweeps
+    bool held = false;
+    int lane = 0;
+    const int turn_from = (c && heavy_px > 0.0) ? std::min(std::max(c->opt_heavy_from_sweep, 1), iters) : iters + 1;
+    // A pair that has the GPU to itself (no other context inside rsm_run_pair on this device, no per-launch timing) runs the
+    // two directions of a time-skewed section as separate launch chains on its two streams: every skewed launch ends in a
+    // tail of one or two waves per SIMD, and the other direction's launch fills it.  With pairs in flight the other pairs'
+    // kernels do that already, and the split costs throughput (measured): not used there.
+    const bool may_split = skew && a.ndir == 2 && c->opt_refine_split && (!c->profile || c->opt_refine_split == 2) && c->stream2 != st && c->upd_list2 &&
+                           c->device < RSM_MAX_DEVICES && (c->opt_refine_split == 2 || (!c->shared_now() && g_running[c->device].load() == 1));
+    auto join = [&]() {
+        if (!split_now) return;
+        (void)hipEventRecord(c->ev_join, c->stream2);
+        (void)hipStreamWaitEvent(st, c->ev_join, 0);
+        split_now = false;
+    };
+    for (int t = 1; t < iters;) {
+        const bool skew_now = skew && t >= c->opt_refine_skew_from && t + skewT <= iters;
+        if (!skew_now) join(); // (before the lane is handed on: the section's end event must cover the second stream's launches)
+        if (c && c->opt_heavy_lanes == 2 && (int)skew_now != lane && t >= turn_from) { // the section changes kind: hand its lane on
+            heavy_end(c, held, lane);
+            held = false;
+            lane = (int)skew_now;
+        }
+        if (t >= turn_from && !held) held = heavy_begin(c, heavy_px, top, lane);
+        if (skew_now && may_split && !split_now) { // fork: the second stream continues from here -- AFTER heavy_begin's wait has
+                                                   // been enqueued on `st`, so the second direction takes turns like the first
+            (void)hipMemsetAsync(c->upd_cnt2, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
+            (void)hipEventRecord(c->ev_fork, st);
+            (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+            split_now = true;
+        }
+        if (skew_now) {
+            a.flag3 = nskew++;
+            launch(t, skewT);
+            t += skewT;
+        } else {
+            launch(t, 0);
+            t += 1;
+        }
+    }
+    join();
+    heavy_end(c, held, lane);
     *final_in_B = curB;
     return launches;
 }
@@ -868,7 +776,6 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
     c->have_result = false;
     c->ev_used = 0;
     const double P_top_full = (double)c->Wk[N - 1] * c->Hk[N - 1];
-    if (c->opt_refine_defer_to > 0 && !c->miss_list) DALLOC(c, c->miss_list, (size_t)RF_UPD_SHARDS * c->miss_cap); // deferred miss service (option)
 
     // ConstructPyrm, .cpp:1040-1053 (top level = uploaded images).  The main stream needs the masks (margins) first;
     // everything that depends on the images or the top mask only goes to the side stream and is made while the small
@@ -1186,7 +1093,7 @@ extern "C" int rsm_run_pairs_repeat(rsm_ctx *const *ctxs, int n, int repeats) {
     for (int i = 0; i < n; i++) { // contexts that share a device with another one of the pool: pairs in flight, never the lone-pair split
         bool shared = false;
         for (int j = 0; j < n; j++) shared |= j != i && ctxs[j]->device == ctxs[i]->device;
-        ctxs[i]->opt_shared_gpu = shared;
+        ctxs[i]->pool_shared = shared;
     }
     std::vector<int> st((size_t)n, RSM_OK);
     auto loop = [&](int i) { // every context runs its resident pair `repeats` times, free of the others
@@ -1197,6 +1104,7 @@ extern "C" int rsm_run_pairs_repeat(rsm_ctx *const *ctxs, int n, int repeats) {
     for (int i = 1; i < n; i++) th.emplace_back(loop, i);
     loop(0);
     for (auto &t : th) t.join();
+    for (int i = 0; i < n; i++) ctxs[i]->pool_shared = 0;
     for (int i = 0; i < n; i++)
         if (st[(size_t)i] != RSM_OK) return st[(size_t)i];
     return RSM_OK;
@@ -1213,7 +1121,7 @@ extern "C" int rsm_match_pairs(rsm_ctx *const *ctxs, int n_ctx, const rsm_pair_i
     for (int i = 0; i < n_ctx; i++) { // (see rsm_run_pairs_repeat)
         bool shared = false;
         for (int j = 0; j < n_ctx; j++) shared |= j != i && ctxs[j]->device == ctxs[i]->device;
-        ctxs[i]->opt_shared_gpu = shared;
+        ctxs[i]->pool_shared = shared;
     }
     std::atomic<int> next(0);
     std::vector<int> st((size_t)n_pairs, RSM_OK);
@@ -1228,6 +1136,7 @@ extern "C" int rsm_match_pairs(rsm_ctx *const *ctxs, int n_ctx, const rsm_pair_i
     for (int i = 1; i < nt; i++) th.emplace_back(worker, ctxs[i]);
     worker(ctxs[0]);
     for (auto &t : th) t.join();
+    for (int i = 0; i < n_ctx; i++) ctxs[i]->pool_shared = 0;
     int first = RSM_OK;
     for (int p = 0; p < n_pairs; p++) {
         if (status) status[p] = st[(size_t)p];
@@ -1392,8 +1301,6 @@ StageArgs one_dir(rsm_ctx *c, int W, int H, int r, const rsm_boundary *own, cons
     a.opt_no_rowgemm = c->opt_no_rowgemm;
     a.ncc_mid = c->opt_ncc_mid;
     a.ncc_slide_max = c->opt_ncc_slide_max;
-    a.row_lo = 0;
-    a.row_hi = INT_MAX;
     a.ndir = 1;
     a.W = W;
     a.H = H;
@@ -1631,13 +1538,10 @@ extern "C" int rsm_stage_refine(rsm_ctx *c, const int16_t *disp_in, const uint8_
     d.img_oth = t.up(img_oth, px * 3);
     uint32_t *i4o = t.alloc<uint32_t>(px), *i4t = t.alloc<uint32_t>(px);
     double *A = t.alloc<double>(px), *B = t.alloc<double>(px);
-    d.rf_key = t.alloc<int16_t>(2 * px);
-    d.rf_pwp = t.alloc<double>(2 * px);
-    d.rf_delta = t.alloc<double>(2 * px);
+    d.rf_key = t.alloc<uint32_t>(px);
+    d.rf_ent = t.alloc<double2>(2 * px);
     a.rf_stride = px;
     a.upd_cap = 4096;
-    a.miss_cap = (int)((((size_t)(W / 256 + 2) * (size_t)(H / RF_PPT + 2)) / RF_UPD_SHARDS + 2) * 256 * RF_PPT);
-    a.miss_list = c->opt_refine_defer_to > 0 ? t.alloc<RfMiss>((size_t)RF_UPD_SHARDS * a.miss_cap) : nullptr;
     a.upd_list = t.alloc<RfUpd>((size_t)RF_UPD_SHARDS * a.upd_cap);
     a.upd_cnt = t.alloc<int32_t>(2 * RF_UPD_SHARDS);
     if (!t.ok) return finish(c, t);

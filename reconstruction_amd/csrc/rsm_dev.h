@@ -9,6 +9,7 @@
 #define WAVE 64
 #define RF_MAX_SWEEPS 1024
 #define RF_NOKEY ((int16_t)-32768)
+#define RF_NOKEY2 0x80008000u // both ways of DirArgs::rf_key empty
 #define RF_PPT 4      // pixels per thread of the refine sweep kernel
 #define SBV_S 32 // SetBoundary: row segments per column of the vertical sweeps
 // int32 scratch of launch_set_boundary (in rf_list), per direction
@@ -33,20 +34,15 @@ struct DirArgs {
     const double *parent;      // fp64 disparity of level k-1 (this direction)
     const int32_t *parent_nv;  // next-valid-column table of `parent`
     double *f64_a, *f64_b;     // fp64 disparity ping-pong / uniqueness maps
-    int16_t *rf_key;           // refine cache (2 ways): iMatch - x = int(d - 1.5) of the cached entry, RF_NOKEY = empty
-    double *rf_pwp, *rf_delta; // refine cache: data-term weight and offset
+    uint32_t *rf_key;          // refine cache, per pixel: iMatch - x = int(d - 1.5) of the entry in way 0 (low half) | way 1 (high half), RF_NOKEY = empty
+    double2 *rf_ent;           // refine cache, [way * rf_stride + pixel]: the data term (pwp, delta = pdp - dCenter) of that iMatch
 };
 
-// A data-term cache entry computed by k_refine_multi, applied to the cache by k_refine_apply after the launch.
+// A data-term cache entry computed inside a k_refine_skew launch, applied to the cache by k_refine_apply after it.
 struct RfUpd {
     uint32_t pix; // pixel index | direction << 31
     int32_t rel;  // iMatch - x of the entry (its parity selects the way)
     double pwp, delta;
-};
-// A pixel a deferring refine sweep (StageArgs::defer) leaves to k_refine_fixup.
-struct RfMiss {
-    uint32_t pix; // pixel index | direction << 31
-    int32_t rel;  // iMatch - x the pixel needs
 };
 #define RF_UPD_SHARDS 32 // append counters (one counter serialises at ~88 appends per microsecond)
 
@@ -68,17 +64,13 @@ struct StageArgs {
     double ws;   // m_ws
     int flag;    // stage-specific
     int flag2;   // refine: sweep index
-    int row_lo, row_hi; // refine sweep: only rows [row_lo, row_hi) of the interior are updated (band schedule, k_refine.hip)
     size_t rf_stride;  // refine: elements between the two cache ways (>= W*H)
-    RfUpd *upd_list;   // refine (k_refine_multi): RF_UPD_SHARDS regions of upd_cap records
+    RfUpd *upd_list;   // refine (k_refine_skew): RF_UPD_SHARDS regions of upd_cap records
     int32_t *upd_cnt;  // [2][RF_UPD_SHARDS]: append counters, the set in use alternates per launch (flag3 & 1)
     int upd_cap;
-    int flag3;         // refine multi / deferred misses: launch index (counter set)
-    int defer;         // refine sweep: 1 = cache misses go to miss_list for k_refine_fixup instead of being served in the sweep
-    RfMiss *miss_list; // RF_UPD_SHARDS regions of miss_cap records (counters: upd_cnt); nullptr = never defer
-    int miss_cap;      // >= 1024 x the workgroups a shard can receive: a deferring sweep never overflows
+    int flag3;         // refine: k_refine_first: bit 1 = no prefill of the second way; k_refine_skew: launch index (counter set)
     int skew_rows;     // refine (k_refine_skew): rows per chunk
-    int skew_variant;  // refine (k_refine_skew, T = 4): bit set, 28 = the shipped kernel (k_refine.hip)
+    int skew_uw;       // refine (k_refine_skew): columns a strip owns (<= 66 - 2T)
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int opt_no_exact;               // skip k_ncc_exact (timing A/B only: ties then follow the integer form)
     uint32_t *rf_list; // NCC: worklist of wide pixels (dir << 31 | pixel index); SetBoundary: segment-map scratch
@@ -126,14 +118,11 @@ void launch_div_unscaled(const double *a, const double *b, double *q_fast, doubl
 void launch_refine_init(const StageArgs &a, hipStream_t st);   // d16_in -> f64_a, f64_b, cache reset
 // f64_a -> f64_b; ev0/ev1 (optional) are recorded right around the light sweep kernel
 void launch_refine_sweep(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-// serves the misses a deferring sweep (a.defer) listed: data term, cache entry, the pixel's update f64_a -> f64_b
-void launch_refine_fixup(const StageArgs &a, hipStream_t st);
-// TWO sweeps f64_a -> f64_b in one launch (a.flag3 = launch index) + the launch that applies its cache updates
-void launch_refine_multi(const StageArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-// T (2..4) sweeps f64_a -> f64_b in one time-skewed launch (a.flag3 = launch index, a.skew_rows) + the cache-update launch
+// T (2..4) sweeps f64_a -> f64_b in one time-skewed launch (a.flag3 = launch index, a.skew_rows, a.skew_uw) + the cache-update launch
 void launch_refine_apply(const StageArgs &a, hipStream_t st); // k_refine.hip
-void launch_refine_skew1(const StageArgs &a, dim3 grid, hipStream_t st); // k_refine_skew1.hip
-void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr); // k_refine_skew.hip
+int refine_skew_strips(const Mg &m, int T, int uw); // strips of 64 lanes a direction's interior takes (k_refine_skew.hip)
+bool refine_skew_fits(const StageArgs &a);          // the kernel's flat over-reads stay inside the level
 
 // cloud: returns nothing; *d_npoints (device int64) receives the point count; `flags` = W*H bytes of scratch,
 // `blk` = launch_bad_blocks' map (CLOUD_BLOCKS(W,H) bytes)

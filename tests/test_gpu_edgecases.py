@@ -129,13 +129,14 @@ def test_refine_block_edges(ctx, rows, cols, iters):
         assert np.array_equal(a, b), (rows, cols, sign, float(np.abs(a - b).max()))
 
 
-@pytest.mark.parametrize("skew", [0, 28, 64])
+@pytest.mark.parametrize("skew", [0, 4, 2])
 def test_refine_with_weights_across_the_exps_whole_range(ctx, skew):
     """DisparityRefine's smoothness weights exp(-(|dE - dC| - |dW - dC|)^2) (CStereoMatching.cpp:665-666) over the whole range of
     the specified exp INSIDE the sweep kernels: disparity steps of 0 ... 45 pixels between neighbours give arguments from 0 to
     ~2000 -- the table path (t < 512: the time-skewed kernel's common form), glibc's special case for t in [512, 1024) (subnormal
     weights beyond 708), exact zeros beyond 1024 and with them `wx + wy == 0` -> the plain average of :667-668 -- in the single-sweep
-    kernels and (skew = its variant, 64 = one wave per strip) in the time-skewed ones from the first cached sweep on.  Bit for bit against the oracle."""
+    kernels and (skew = T sweeps per launch) in the time-skewed one from the first cached sweep on, where every such pixel fails the
+    common row's guards and is redone by the general update.  Bit for bit against the oracle."""
     H, W, iters = 46, 300, 24
     rng = np.random.default_rng(77)
     base = rng.integers(0, 256, size=(H, W + 8, 3)).astype(np.uint8)
@@ -149,14 +150,14 @@ def test_refine_with_weights_across_the_exps_whole_range(ctx, skew):
     d[rng.random((H, W)) < 0.05] = NOMATCH
     own = (3, H - 4, 4, W - 5, W - 8, H - 6)
     if skew:
-        ctx.set_option("refine_skew_variant", skew)
+        ctx.set_option("refine_skew_T", skew)
         ctx.set_option("refine_skew_from", 1)
         ctx.set_option("refine_skew_min_px", 0)
         ctx.set_option("refine_skew_rows", 16)
     try:
         a = ctx.disparity_refine(d, img0, img1, iters, 0.03, own)
     finally:
-        ctx.set_option("refine_skew_variant", 28)
+        ctx.set_option("refine_skew_T", 4)
         ctx.set_option("refine_skew_from", 22)
         ctx.set_option("refine_skew_min_px", 1000000)
         ctx.set_option("refine_skew_rows", 0)

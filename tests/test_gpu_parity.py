@@ -354,28 +354,6 @@ def test_libm_exp_sensitivity(ctx):
         assert (np.abs(g[ok] - o_libm[ok]) / np.maximum(1.0, np.abs(o_libm[ok]))).max() < 1e-3
 
 
-@pytest.mark.parametrize("rows", [5, 16, 23, 64])
-def test_refine_band_schedule_is_bit_identical(ctx, rows):
-    """DisparityRefine's sweeps run time-skewed over bands of rows so that a band stays in the Infinity Cache
-    (rsm_api.hip: refine_sweeps).  Whatever the band height -- including heights that are no multiple of the
-    4-row thread tile and bands shorter than the number of sweeps -- the result is the whole-frame Jacobi
-    iteration of CStereoMatching.cpp:590-678, bit for bit."""
-    cfg, rec, fin = stages("s512x384_5levels")
-    ctx.set_option("refine_band_rows", rows)
-    try:
-        for q in rec:
-            if q["stage"] != "refine" or q["level"] < 2:
-                continue
-            k, v = q["level"], q["v"]
-            g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], q["iters"], cfg.ws, q["mg"][v])
-            assert np.array_equal(g, q["out"]), diff_report("banded refine rows=%d L%d v%d" % (rows, k, v), g, q["out"])
-        res = ctx.match_pair(cfg)
-        for v in range(2):
-            assert np.array_equal(res.disparity[v], fin["disparity"][v])
-    finally:
-        ctx.set_option("refine_band_rows", 0)
-
-
 def test_whole_pair_against_the_libm_exp_oracle(ctx):
     """The honest statement of DisparityRefine parity.  Against the oracle with the SPECIFIED exp the HIP path is
     bit-identical (every other test).  The reference itself calls its C runtime's exp (.cpp:665-666); run the oracle
@@ -401,77 +379,20 @@ def test_whole_pair_against_the_libm_exp_oracle(ctx):
         assert np.array_equal(res.xyz, ref["xyz"], equal_nan=True)
 
 
-@pytest.mark.parametrize("span", [(1, 1000), (2, 5), (4, 48), (30, 31)])
-def test_refine_deferred_miss_service_is_bit_identical(ctx, span):
-    """Sweeps `from..to` hand their cache misses to k_refine_fixup (a lane per listed pixel computes the data term, the
-    cache entry and the pixel's update) instead of serving them inside the sweep: the same values, bit for bit --
-    from the first cached sweep (nearly every pixel listed) to the settled regime, odd and even sweep counts."""
-    ctx.set_option("refine_defer_from", span[0])
-    ctx.set_option("refine_defer_to", span[1])
-    ctx.set_option("refine_defer_min_px", 0)
-    try:
-        for name in ("s512x384_5levels", "s192x128_ellipse", "s320x160_occluded_neg_r4"):
-            cfg, rec, fin = stages(name)
-            for q in rec:
-                if q["stage"] != "refine":
-                    continue
-                k, v = q["level"], q["v"]
-                for iters in (q["iters"], q["iters"] - 1):
-                    want = q["out"] if iters == q["iters"] else orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
-                    g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
-                    assert np.array_equal(g, want), diff_report("defer %s %s L%d v%d iters %d" % (span, name, k, v, iters), g, want)
-            res = ctx.match_pair(cfg)
-            for v in range(2):
-                assert np.array_equal(res.disparity[v], fin["disparity"][v])
-    finally:
-        ctx.set_option("refine_defer_from", 4)
-        ctx.set_option("refine_defer_to", 0)
-        ctx.set_option("refine_defer_min_px", 1000000)
-
-
-@pytest.mark.parametrize("first", [1, 2, 7, 32])
-def test_refine_two_sweeps_per_launch_is_bit_identical(ctx, first):
-    """k_refine_multi (two Jacobi sweeps per launch on an LDS-resident tile, deferred cache updates) from sweep
-    `first` on -- from the very first cached sweep, where nearly every pixel misses, to the settled regime -- gives
-    the single-sweep result, i.e. the oracle's, bit for bit; odd and even numbers of remaining sweeps."""
-    ctx.set_option("refine_multi_from", first)
-    ctx.set_option("refine_multi_min_px", 0)
-    try:
-        for name in ("s512x384_5levels", "s192x128_ellipse", "s320x160_occluded_neg_r4"):
-            cfg, rec, fin = stages(name)
-            for q in rec:
-                if q["stage"] != "refine":
-                    continue
-                k, v = q["level"], q["v"]
-                for iters in (q["iters"], q["iters"] - 1):
-                    want = q["out"] if iters == q["iters"] else orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
-                    g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
-                    assert np.array_equal(g, want), diff_report("multi from %d %s L%d v%d iters %d" % (first, name, k, v, iters), g, want)
-            res = ctx.match_pair(cfg)
-            for v in range(2):
-                assert np.array_equal(res.disparity[v], fin["disparity"][v])
-    finally:
-        ctx.set_option("refine_multi_from", 0)
-        ctx.set_option("refine_multi_min_px", 400000)
-
-
-@pytest.mark.parametrize("T,first,rows,variant", [(2, 1, 0, 0), (3, 1, 7, 0), (4, 1, 16, 0), (3, 5, 0, 0), (4, 9, 33, 0), (2, 30, 12, 0), (3, 2, 1000, 0),
-                                                 (4, 1, 16, 1), (4, 9, 33, 2), (4, 1, 0, 3), (4, 22, 0, 2), (4, 1, 16, 4), (4, 9, 0, 4), (4, 1, 16, 12), (4, 9, 33, 12), (4, 1, 16, 28), (4, 9, 33, 28), (4, 22, 0, 28),
-                                                 (4, 1, 16, 64), (4, 9, 33, 64), (4, 22, 0, 64), (4, 1, 0, 64), (4, 2, 5, 64), (4, 3, 1000, 64)])
-def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows, variant):
-    """k_refine_skew (T Jacobi sweeps per launch: a wave streams down a 64-column strip with sweep t on row y - t, the
-    state rings and both cache ways in its LDS slice, cache updates deferred to the update list) from sweep `first` on
-    -- from the first cached sweep, where nearly every pixel misses, to the settled regime -- gives the single-sweep
-    result, i.e. the oracle's, bit for bit; chunk heights from 4T rows to the whole level, sweep counts that leave 0..T-1
-    single sweeps at the end.  variant != 0: round 4's restatements of the T = 4 kernel (a row's staging shared by two waves;
-    lane-mask predicates and divisions without the hardware sequence's scaling steps; 64: k_refine_skew1, one wave per strip with
-    the state rings in registers and the four levels' updates four wide; 4: rows without a live
-    pixel skip the update math; 8: the predicates as lane masks, early in the chain; 16: only the selected cache way is read; 28 is the default) -- the same bits."""
-    ctx.set_option("refine_skew_variant", variant)
+@pytest.mark.parametrize("T,first,rows,uw", [(2, 1, 0, 0), (3, 1, 7, 0), (4, 1, 16, 0), (3, 5, 0, 0), (4, 9, 33, 0), (2, 30, 12, 0), (3, 2, 1000, 0),
+                                             (4, 22, 0, 0), (4, 1, 0, 56), (4, 2, 5, 56), (4, 3, 1000, 40), (4, 9, 33, 2), (2, 3, 9, 62), (3, 4, 11, 30)])
+def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows, uw):
+    """k_refine_skew (T Jacobi sweeps per launch: wave t of a workgroup streams down a strip of 64 lanes with sweep t on row
+    s - 2t + 1, the state rings and both cache ways' rows in LDS, one 16-byte load and LDS write per wave and step, the common
+    row straight-line with unscaled divisions and its guards looked at afterwards, cache updates deferred to the update list)
+    from sweep `first` on -- from the first cached sweep, where nearly every pixel misses and every row takes the rare path, to
+    the settled regime -- gives the single-sweep result, i.e. the oracle's, bit for bit; chunk heights from 4T rows to the whole
+    level, sweep counts that leave 0..T-1 single sweeps at the end, strips of 66 - 2T columns (the default) and narrower."""
     ctx.set_option("refine_skew_from", first)
     ctx.set_option("refine_skew_T", T)
     ctx.set_option("refine_skew_min_px", 0)
     ctx.set_option("refine_skew_rows", rows)
+    ctx.set_option("refine_skew_uw", uw)
     try:
         for name in ("s512x384_5levels", "s192x128_ellipse", "s320x160_occluded_neg_r4"):
             cfg, rec, fin = stages(name)
@@ -482,13 +403,13 @@ def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows, varian
                 for iters in (q["iters"], q["iters"] - 1):
                     want = q["out"] if iters == q["iters"] else orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
                     g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
-                    assert np.array_equal(g, want), diff_report("skew T %d from %d rows %d %s L%d v%d iters %d" % (T, first, rows, name, k, v, iters), g, want)
+                    assert np.array_equal(g, want), diff_report("skew T %d from %d rows %d uw %d %s L%d v%d iters %d" % (T, first, rows, uw, name, k, v, iters), g, want)
             res = ctx.match_pair(cfg)
             for v in range(2):
                 assert np.array_equal(res.disparity[v], fin["disparity"][v])
     finally:
-        ctx.set_option("refine_skew_variant", 28)  # the defaults
-        ctx.set_option("refine_skew_from", 22)
+        ctx.set_option("refine_skew_from", 22)  # the defaults
         ctx.set_option("refine_skew_T", 4)
         ctx.set_option("refine_skew_min_px", 1000000)
         ctx.set_option("refine_skew_rows", 0)
+        ctx.set_option("refine_skew_uw", 0)

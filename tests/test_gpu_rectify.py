@@ -48,7 +48,31 @@ def test_grey_erosion_bit_exact(ctx, ksize):
     assert np.array_equal(ctx.erode_ellipse_gray(m, ksize), orc.erode_ellipse(m, ksize))
 
 
+def test_rectify_pair_plan_satisfies_the_geometry(ctx, raw):
+    """What rsm_rectify_pair leaves behind (Q, R_final, T_final, cam[j].P: CStereoMatching.cpp:132-145) held to the geometry
+    itself, not to the oracle's copy of the same transcription (tests/test_rectify_properties.py does it for random poses on
+    the host routine): world points projected with cam[0].P / cam[1].P land on one row, and DisparityToCloud's formula with
+    the reference's disparity convention followed by R_final X + T_final returns them to 1e-9."""
+    g = ctx.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"], want_images=False)
+    scale = float(raw["lowest"][0]) / raw["origin"][0] * (1 << (raw["pyr_levels"] - 1))
+    q = np.array(g["Q"], np.float64)
+    q[:, 3] *= scale                                        # :697-699
+    assert np.abs(g["R_final"] @ g["R_final"].T - np.eye(3)).max() < 1e-13
+    rng = np.random.default_rng(5)
+    R0, t0 = raw["E"][0][:, :3], raw["E"][0][:, 3]
+    for _ in range(50):
+        Xw = R0.T @ (np.array([rng.uniform(-0.25, 0.25), rng.uniform(-0.2, 0.2), 1.0]) * rng.uniform(400, 4000) - t0)
+        p0, p1 = g["P"][0] @ np.append(Xw, 1.0), g["P"][1] @ np.append(Xw, 1.0)
+        x0, y0, x1, y1 = p0[0] / p0[2], p0[1] / p0[2], p1[0] / p1[2], p1[1] / p1[2]
+        assert abs(y0 - y1) < 1e-9
+        iW = 1.0 / (q[3, 3] + q[3, 2] * (x1 - x0))          # :744, disparity = x_other - x
+        F = np.array([(q[0, 3] + x0) * iW, (y0 + q[1, 3]) * iW, q[2, 3] * iW])
+        assert np.abs(g["R_final"] @ F + g["T_final"] - Xw).max() < 1e-9 * np.abs(Xw).max()
+
+
 def test_rectify_pair_matches_oracle(ctx, raw):
+    """(A regression guard: the oracle's Rectify is the same transcription of OpenCV's routines as the product's -- equality
+    says the two dialects have not drifted apart, the property tests say what they compute is a rectification.)"""
     g = ctx.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"])
     o = orc.rectify_pair(raw["K"], raw["E"], raw["origin"], raw["lowest"], raw["pyr_levels"], raw["image"], raw["mask"])
     for v in range(2):

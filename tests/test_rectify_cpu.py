@@ -48,6 +48,9 @@ def test_rectified_views_are_row_aligned():
 
 
 def test_product_host_routine_equals_the_oracle_bit_for_bit():
+    """A REGRESSION GUARD, not a check of correctness: csrc/rectify_host.cpp and oracle/rectify_oracle.c are one transcription of
+    cv::stereoRectify in two dialects (OpenCV's source and binaries are absent from the reference tree), so their equality only
+    says neither has drifted.  What holds both to the geometry is tests/test_rectify_properties.py."""
     raw = synth.make_raw_pair()
     K, E = raw["K"], raw["E"]
     R = E[1][:, :3] @ E[0][:, :3].T
