@@ -235,12 +235,15 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          sweeps (k_refine_skew): T (2..4, default 4) sweeps per launch from that sweep of a level on (default
  *                          22; 0 = never) at levels with at least min_px margin pixels per direction (default 1 M: the two
  *                          largest levels of a 12 MP pair; a level narrower than 80 columns never), aiming at `waves` workgroups
- *                          (default 1280) or `rows` rows per chunk
+ *                          (default 2560: two rounds of the 1280 a chip holds) or `rows` rows per chunk
  *   "refine_skew_uw"       columns a strip of that kernel owns: 0 (default) = 66 - 2T, all that its last sweep can compute from 64
  *                          lanes; an even number below that (e.g. 56: every strip starts on a 128-byte line of the cache ways) for A/B
  *   "refine_skew_waves_alone"  the workgroups a time-skewed launch aims at while no other context of the device is inside
- *                          rsm_run_pair (default 2560: half as tall chunks, a second round of workgroups shortens the launch's
- *                          tail; with pairs in flight `refine_skew_waves` applies); 0 = the same
+ *                          rsm_run_pair (default 3840; with pairs in flight `refine_skew_waves` applies); 0 = the same
+ *   "refine_skew_prio"     p > 0: the time-skewed kernel's waves rotate their issue priority (s_setprio) every 2^p shader clocks, in step
+ *                          over the whole chip, so that the workgroups of a CU -- which the hardware serves oldest first -- advance
+ *                          alike; 0 (default) = off: it equalises them as designed and gains 7 % on a single round of workgroups,
+ *                          nothing on the default two rounds
  *   "cu_share" = n         n > 1: the context's streams are confined to one of n equal shares of the compute units (the
  *                          context's creation ordinal on its device picks the share; measured slower than sharing the whole
  *                          chip in turns); 0 / 1 = the whole chip.  The masked streams are BLOCKING streams

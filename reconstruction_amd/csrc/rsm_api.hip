@@ -141,9 +141,12 @@ struct rsm_ctx {
     int opt_refine_prefill = 1;    // k_refine_first also fills the second cache way with the neighbour iMatch its update points to
     int opt_refine_skew_T = 4;     // sweeps per time-skewed launch (2..4)
     int opt_refine_skew_min_px = 1000000; // ... at levels with at least this many margin pixels per direction (smaller levels: the 4T-step pipeline fill of a chunk eats the gain)
-    int opt_refine_skew_waves = 1280;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident
-    int opt_refine_skew_waves_alone = 2560; // ... when no other context of the device is inside rsm_run_pair (0: the same)
+    int opt_refine_skew_waves = 2560;    // workgroups a time-skewed launch aims at (sets the rows per chunk): 5 per CU are resident, so two rounds --
+                                         // workgroups at different points of their chunks share a CU better than 1 280 in lockstep (measured: 0.28 against 0.34 ms)
+    int opt_refine_skew_waves_alone = 3840; // ... when no other context of the device is inside rsm_run_pair (0: the same)
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
+    int opt_refine_skew_rps = 1;         // rows a wave of the time-skewed kernel advances per step (T = 4): 1 or 2
+    int opt_refine_skew_prio = 0;        // the time-skewed kernel's waves rotate their issue priority every 2^this shader clocks (0: never)
     int opt_refine_skew_uw = 0;          // columns a strip owns; 0: 66 - 2T, all its last level can compute (an even number <= that: A/B)
 
     // profiling
@@ -518,6 +521,8 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
+    else if (!strcmp(name, "refine_skew_rps")) c->opt_refine_skew_rps = value == 2 ? 2 : 1;
+    else if (!strcmp(name, "refine_skew_prio")) c->opt_refine_skew_prio = (int)std::max(0LL, std::min(value, 40LL));
     else if (!strcmp(name, "refine_skew_uw")) { // an even number of columns (the state row's 16-byte pieces start on even columns)
         if (value < 0 || value > 62 || (value & 1)) return set_err(c, RSM_E_INVALID, "refine_skew_uw %lld: 0 (= 66 - 2T) or an even number <= 66 - 2T", value);
         c->opt_refine_skew_uw = (int)value;
@@ -703,6 +708,8 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
     const int skewT = skew ? c->opt_refine_skew_T : 0;
     if (skew) {
         (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
+        a.skew_prio = c->opt_refine_skew_prio;
+        a.skew_rps = skewT == 4 ? c->opt_refine_skew_rps : 1;
         a.skew_uw = (c->opt_refine_skew_uw > 0 && c->opt_refine_skew_uw <= 66 - 2 * skewT) ? c->opt_refine_skew_uw : 66 - 2 * skewT;
         int rows = 1, strips = 0;
         for (int v = 0; v < a.ndir; v++) {
