@@ -800,7 +800,7 @@ def kernel_src_sha():
     """Identity of the dominant kernel's source (the GPU box has no git checkout to ask)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("k_refine.hip", "rsm_dev.h"):
+    for f in ("k_refine_skew.hip", "k_refine.hip", "refine_common.h", "rsm_dev.h"):
         with open(os.path.join(ROOT, "reconstruction_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

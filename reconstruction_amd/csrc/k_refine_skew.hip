@@ -146,6 +146,38 @@ __device__ __forceinline__ void skew_rare_row(SkewRare q, u64 m_redo, u64 m_own)
     }
 }
 
+// .cpp:652-672 for a row whose live pixels all have four neighbours, straight-line on all lanes (the common row of the kernels
+// in this file): the update `u`, the lanes whose `u` is the reference's as far as the masks known early in the chain say
+// (`m_early`), and the lanes the rare path has to redo (`m_redo`).
+__device__ __forceinline__ void skew_common_row(double dC, double dE, double dW, double dN, double dS, double2 pd, int crel, int rel, double ws, u64 m_try,
+                                                ExpTab tab, double &u, u64 &m_early, u64 &m_redo) {
+    const double ex = fabs(dE - dC) - fabs(dW - dC);
+    const double ey = fabs(dS - dC) - fabs(dN - dC);
+    const double tx = ex * ex, ty = ey * ey;
+    double wx, wy;
+    exp_neg2_small(tx, ty, wx, wy, tab); // .cpp:665-666 (the bits of exp_neg for t < 512)
+    const double b2 = pd.x + ws;         // the second division's reciprocal needs pwp only: two Newton steps beside the exps
+    double y2 = __builtin_amdgcn_rcp(b2);
+    double e2 = __builtin_fma(-b2, y2, 1.0);
+    y2 = __builtin_fma(y2, e2, y2);
+    e2 = __builtin_fma(-b2, y2, 1.0);
+    y2 = __builtin_fma(y2, e2, y2);
+    const double b1 = 2 * (wx + wy);
+    double y1r = __builtin_amdgcn_rcp(b1);
+    double e1 = __builtin_fma(-b1, y1r, 1.0);
+    y1r = __builtin_fma(y1r, e1, y1r);
+    e1 = __builtin_fma(-b1, y1r, 1.0);
+    y1r = __builtin_fma(y1r, e1, y1r);
+    const double a1 = wx * (dE + dW) + wy * (dN + dS);
+    const double q1 = a1 * y1r;
+    const double ds = __builtin_fma(__builtin_fma(-b1, q1, a1), y1r, q1); // a1 / (2 (wx + wy)): div_unscaled's operations
+    const double a2 = (dC + pd.y) * pd.x + ws * ds;
+    const double q2 = a2 * y2;
+    u = __builtin_fma(__builtin_fma(-b2, q2, a2), y2, q2); // .cpp:671
+    m_early = m_try & RF_IEQ(crel, rel) & RF_FLE(fmax(tx, ty), 200.0) & RF_FGT(pd.x, 0.0);
+    m_redo = m_try & ~(m_early & RF_FGT(fabs(a1), 0x1p-300) & RF_FGT(fabs(a2), 0x1p-300));
+}
+
 // which of a row's four streams (0 state, 1 keys, 2 / 3 the ways' entries; -1 none) wave w carries in slot j
 template <int T>
 __device__ __forceinline__ int skew_stream(int w, int j) {
@@ -337,41 +369,12 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                         // the way the state selects, as ONE 16-byte read (two 8-byte reads at a 16-byte lane stride conflict two ways)
                         const double2 pd = *(const double2 *)__builtin_assume_aligned(s_mem + LY::OFF_ENT + ek * 8u + (unsigned)way * 1024u + lane16, 16);
                         const int crel = (int)(int16_t)(kk >> (way << 4));
-                        // .cpp:652-672 for mode 3, straight-line on all lanes
-                        const double ex = fabs(dE - dC) - fabs(dW - dC);
-                        const double ey = fabs(dS - dC) - fabs(dN - dC);
-                        const double tx = ex * ex, ty = ey * ey;
-                        double wx, wy;
-                        exp_neg2_small(tx, ty, wx, wy, (ExpTab)(s_mem + LY::OFF_EXP)); // .cpp:665-666 (the bits of exp_neg for t < 512)
-                        // the second division's reciprocal needs pwp only: two Newton steps beside the exps
-                        const double b2 = pd.x + ws;
-                        double y2 = __builtin_amdgcn_rcp(b2);
-                        double e2 = __builtin_fma(-b2, y2, 1.0);
-                        y2 = __builtin_fma(y2, e2, y2);
-                        e2 = __builtin_fma(-b2, y2, 1.0);
-                        y2 = __builtin_fma(y2, e2, y2);
-                        const double sw = wx + wy;
-                        const double b1 = 2 * sw;
-                        double y1r = __builtin_amdgcn_rcp(b1);
-                        double e1 = __builtin_fma(-b1, y1r, 1.0);
-                        y1r = __builtin_fma(y1r, e1, y1r);
-                        e1 = __builtin_fma(-b1, y1r, 1.0);
-                        y1r = __builtin_fma(y1r, e1, y1r);
-                        const double a1 = wx * (dE + dW) + wy * (dN + dS);
-                        const double q1 = a1 * y1r;
-                        const double ds = __builtin_fma(__builtin_fma(-b1, q1, a1), y1r, q1); // a1 / (2 (wx + wy)): div_unscaled's operations
-                        const double a2 = (dC + pd.y) * pd.x + ws * ds;
-                        const double q2 = a2 * y2;
-                        const double u = __builtin_fma(__builtin_fma(-b2, q2, a2), y2, q2); // .cpp:671
-                        // the lanes whose result is the reference's: mode 3, a cache hit, both exp arguments <= 200 (weights >= e^-200:
-                        // no underflow, .cpp:667-668 not taken), both numerators outside the unscaled division's tiny range, pwp != 0
-                        // (.cpp:642-643).  The state is bounded by the int16 start values + half a pixel per sweep, so no upper guard.
-                        // The masks known EARLY in the chain select what is written; the two that need the numerators only decide whether
-                        // the row is redone, so the row's result never waits for them.
-                        const u64 m_try = m_lv & m_ew & m_ns; // (a live pixel without a valid pair keeps dC, .cpp:655)
-                        const u64 m_early = m_try & RF_IEQ(crel, rel) & RF_FLE(fmax(tx, ty), 200.0) & RF_FGT(pd.x, 0.0);
-                        val = rf_sel(m_early) ? u : dC;
-                        m_redo = m_try & ~(m_early & RF_FGT(fabs(a1), 0x1p-300) & RF_FGT(fabs(a2), 0x1p-300));
+                        // the common row's update; the masks known EARLY in its chain select what is written, the two that need the
+                        // numerators only decide whether the row is redone, so the row's result never waits for them
+                        double u;
+                        u64 m_early;
+                        skew_common_row(dC, dE, dW, dN, dS, pd, crel, rel, ws, m_lv & m_ew & m_ns, (ExpTab)(s_mem + LY::OFF_EXP), u, m_early, m_redo);
+                        val = rf_sel(m_early) ? u : dC; // (a live pixel without a valid pair keeps dC, .cpp:655)
                     } else
                         m_redo = m_lv & (m_ew | m_ns);
                 }
@@ -448,236 +451,6 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The same launch with TWO rows per wave and step (T = 4; a.skew_rps = 2).
-// What bounds the kernel above is the NUMBER of wave-instructions a SIMD has to issue -- of every kind: a SIMD issues about
-// one instruction per four clocks whatever its type (measured: vector + scalar + LDS + branch + memory instructions per SIMD
-// x 4 clocks = 0.83 ... 1.0 of the launch, for this kernel and for rounds 3-5's alike; every instruction-count change of the
-// earlier rounds moved the launch time by its share of THAT total) -- and a row's update is ~80 vector instructions inside ~170.
-// The rest is per step, not per row: the step's scalar bookkeeping, its branches, waits and barrier, the lane masks'
-// scalar halves, the address arithmetic.  So a wave advances rows r and r + 1 of its sweep in one step: the levels are
-// three rows apart (sweep t's rows 2u - 3t, 2u - 3t + 1 in step u need sweep t - 1 up to 2u - 3t + 2, written a step before),
-// a level's ring holds six rows, the cache rows of 3T + 2 = 14 rows are resident (47.8 KB of LDS: three workgroups per CU --
-// with the issue slots as the bound, twelve waves of two independent rows each fill them as well as twenty of one), a step
-// stages a pair of rows per stream three steps ahead (three buffers: the loop is unrolled by the rings' period of three steps),
-// and everything per step is paid once per two rows.  Same values, bit for bit; same rare path (skew_rare_row per row).
-template <int T>
-struct Skew2Lds {
-    static constexpr int NE = 3 * T + 2;       // cache rows resident: rows 2u - 3T .. 2u + 1 are in use or arriving in step u
-    static constexpr int RPB = 68 * 8;         // a ring row: columns x0 - 2 .. x0 + 65
-    static constexpr int RING = 6 * RPB;       // a level's ring: six rows
-    static constexpr int OFF_D = 0;
-    static constexpr int OFF_ENT = OFF_D + T * RING;
-    static constexpr int OFF_KEY = OFF_ENT + NE * 2048;
-    static constexpr int OFF_EMIT = OFF_KEY + NE * 256;
-    static constexpr int OFF_EXP = OFF_EMIT + NE * 16;
-    static constexpr int OFF_ML = OFF_EXP + 2048;
-    static constexpr int SIZE = OFF_ML + T * 64; // T = 4: 47 840 B
-};
-
-// .cpp:652-672 for a row whose live pixels all have four neighbours, straight-line on all lanes (the common row of the kernels
-// in this file): the update `u`, the lanes whose `u` is the reference's as far as the masks known early in the chain say
-// (`m_early`), and the lanes the rare path has to redo (`m_redo`).
-__device__ __forceinline__ void skew_common_row(double dC, double dE, double dW, double dN, double dS, double2 pd, int crel, int rel, double ws, u64 m_try,
-                                                ExpTab tab, double &u, u64 &m_early, u64 &m_redo) {
-    const double ex = fabs(dE - dC) - fabs(dW - dC);
-    const double ey = fabs(dS - dC) - fabs(dN - dC);
-    const double tx = ex * ex, ty = ey * ey;
-    double wx, wy;
-    exp_neg2_small(tx, ty, wx, wy, tab); // .cpp:665-666 (the bits of exp_neg for t < 512)
-    const double b2 = pd.x + ws;         // the second division's reciprocal needs pwp only: two Newton steps beside the exps
-    double y2 = __builtin_amdgcn_rcp(b2);
-    double e2 = __builtin_fma(-b2, y2, 1.0);
-    y2 = __builtin_fma(y2, e2, y2);
-    e2 = __builtin_fma(-b2, y2, 1.0);
-    y2 = __builtin_fma(y2, e2, y2);
-    const double b1 = 2 * (wx + wy);
-    double y1r = __builtin_amdgcn_rcp(b1);
-    double e1 = __builtin_fma(-b1, y1r, 1.0);
-    y1r = __builtin_fma(y1r, e1, y1r);
-    e1 = __builtin_fma(-b1, y1r, 1.0);
-    y1r = __builtin_fma(y1r, e1, y1r);
-    const double a1 = wx * (dE + dW) + wy * (dN + dS);
-    const double q1 = a1 * y1r;
-    const double ds = __builtin_fma(__builtin_fma(-b1, q1, a1), y1r, q1); // a1 / (2 (wx + wy)): div_unscaled's operations
-    const double a2 = (dC + pd.y) * pd.x + ws * ds;
-    const double q2 = a2 * y2;
-    u = __builtin_fma(__builtin_fma(-b2, q2, a2), y2, q2); // .cpp:671
-    m_early = m_try & RF_IEQ(crel, rel) & RF_FLE(fmax(tx, ty), 200.0) & RF_FGT(pd.x, 0.0);
-    m_redo = m_try & ~(m_early & RF_FGT(fabs(a1), 0x1p-300) & RF_FGT(fabs(a2), 0x1p-300));
-}
-
-template <int TOP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_refine_skew2(StageArgs a) {
-    constexpr int T = 4;
-    typedef Skew2Lds<T> LY;
-    constexpr int NE = LY::NE, RPB = LY::RPB;
-    __shared__ __attribute__((aligned(16))) char s_mem[LY::SIZE];
-    const DirArgs &d = a.d[blockIdx.z];
-    const int W = a.W;
-    const int XL = d.own.XL, XR = d.own.XR, YL = d.own.YL, YR = d.own.YR;
-    const int UW = a.skew_uw;
-    const int x0 = ((XL + 1 - (T - 1)) & ~7) + (int)blockIdx.x * UW;                     // lane 0's column
-    const int xa = max(x0 + T - 1, XL + 1), xb = min(x0 + T - 1 + UW, XR);               // owned columns [xa, xb)
-    const int ya = YL + 1 + (int)blockIdx.y * a.skew_rows, yb = min(ya + a.skew_rows, YR); // owned rows [ya, yb)
-    if (xa >= xb || ya >= YR) return; // workgroup-uniform
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = wid + 1; // this wave's sweep within the launch
-    {
-        unsigned long long *w = (unsigned long long *)(s_mem + LY::OFF_EXP);
-        w[threadIdx.x] = RSM_EXP_TAB[threadIdx.x];
-        if (threadIdx.x < 2 * NE) ((u64 *)(s_mem + LY::OFF_EMIT))[threadIdx.x] = 0ull;
-    }
-    const int x = x0 + lane;
-    const int y0 = max(YL, ya - T), y1 = min(YR, yb - 1 + T); // staged rows [y0, y1]; everything below counts rows from y0
-    const int nrows = y1 - y0 + 1;
-    const int cy_lo = max(YL + 1, ya - (T - t)) - y0, cy_hi = min(YR - 1, yb - 1 + (T - t)) - y0; // what sweep t can compute here
-    const bool colok = lane >= t - 1 && lane <= 64 - t && x >= XL + 1 && x <= XR - 1;
-    const bool last = t == T;
-    const u64 m_col = __builtin_amdgcn_ballot_w64(colok), m_own = __builtin_amdgcn_ballot_w64(x >= xa && x < xb);
-    const u64 m_store = last ? m_own : 0ull;
-    const unsigned shard = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7u) & (RF_UPD_SHARDS - 1);
-    const double ws = a.ws;
-    const u64 m_wsbad = (ws >= 0x1p-200 && ws <= 0x1p200) ? 0ull : ~0ull;
-    const unsigned c_lo = cy_hi >= cy_lo ? (unsigned)cy_lo : 0x40000000u, c_span = cy_hi >= cy_lo ? (unsigned)(cy_hi - cy_lo) : 0u;
-
-    // ---- this wave's stream (0 state, 1 keys, 2 / 3 the ways' entries): a PAIR of rows per step, three pairs in flight
-    const char *gbase; // row y0, lane 0's piece
-    unsigned gpitch, st_base, st_pitch, st_wrap;
-    int nl;
-    {
-        const size_t p0 = (size_t)y0 * W + x0;
-        if (wid == 0) gbase = (const char *)(d.f64_a + p0 - 2), gpitch = (unsigned)W * 8u, nl = 34, st_base = LY::OFF_D, st_pitch = RPB, st_wrap = 6 * RPB;
-        else if (wid == 1) gbase = (const char *)(d.rf_key + p0), gpitch = (unsigned)W * 4u, nl = 16, st_base = LY::OFF_KEY, st_pitch = 256, st_wrap = NE * 256;
-        else gbase = (const char *)(d.rf_ent + p0 + (size_t)(wid - 2) * a.rf_stride), gpitch = (unsigned)W * 16u, nl = 64, st_base = LY::OFF_ENT + (wid - 2) * 1024, st_pitch = 2048, st_wrap = NE * 2048;
-    }
-    const u64 st_mask = __builtin_amdgcn_ballot_w64(lane < nl);
-    unsigned voff = (unsigned)min(lane, nl - 1) * 16u;
-    const bool st_key = wid == 1;
-    unsigned st_off = 0;
-    const unsigned lane16 = (unsigned)lane * 16u, lane8 = (unsigned)lane * 8u, lane4 = (unsigned)lane * 4u;
-#define SKEW_LD16(dst, base, off)                                    \
-    do {                                                             \
-        asm volatile("" : "+v"(off));                                \
-        dst = *(const double2 *)((base) + (off));                    \
-    } while (0)
-    // the pair staged in step k = rows 2k, 2k + 1 (a row beyond the chunk's last re-reads that one: nothing valid reads its slot)
-    auto row_ptr = [&](int row) { return gbase + (size_t)(unsigned)min(row, nrows - 1) * gpitch; };
-    double2 stg[3][2];
-    const int steps = (nrows + 3 * T - 2 + 1) / 2 + 1; // the last row leaves level T in step ceil((nrows + 3T - 2) / 2)
-    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(d.f64_b), 0, 0, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < 2; k++) { // pairs 0 and 1 are in flight when the loop starts -- with the stores a step would have issued in between,
-                                  // so that the first steps meet the operations in flight every other step meets
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) SKEW_LD16(stg[k][rr], row_ptr(2 * k + rr), voff);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(skew_v2i, 0.0), rs_none, 0xffffffffu, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(skew_v2i, 0.0), rs_none, 0xffffffffu, 0, 0);
-    }
-    stg[2][0] = stg[2][1] = make_double2(0.0, 0.0);
-    // ---- this wave's rows: step u advances rows 2u - 3t and 2u - 3t + 1
-    const unsigned v_rd = LY::OFF_D + (unsigned)(t - 1) * LY::RING + lane8; // ring t - 1, column x0 - 2 + lane
-    int ra = -3 * t;                                                          // the upper row of the pair
-    unsigned ea = (unsigned)(((ra % NE) + NE) % NE) * 256u;                   // its slot in the cache rows, x 256 B
-    const char *optr = (const char *)(d.f64_b + ((ptrdiff_t)y0 + ra) * W + x0); // level T's output rows (lane 0)
-    const unsigned opitch2 = (unsigned)W * 16u, obelow = (unsigned)W * 8u;
-    __syncthreads();
-#pragma unroll 1
-    for (int u3 = 0; u3 < steps; u3 += 3) {
-#pragma unroll
-        for (int K = 0; K < 3; K++) {
-            // (1) the pair three steps ahead
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++) SKEW_LD16(stg[(K + 2) % 3][rr], row_ptr(2 * (u3 + K + 2) + rr), voff);
-            // (2) this wave's two rows
-            const unsigned eb = ea + 256u == NE * 256u ? 0u : ea + 256u;
-            const u64 cmp_a = (unsigned)ra - c_lo <= c_span ? m_col : 0ull, cmp_b = (unsigned)(ra + 1) - c_lo <= c_span ? m_col : 0ull; // rows sweep t can compute here
-            const unsigned sN = ((2 * K + 2) % 6) * RPB, sA = ((2 * K + 3) % 6) * RPB, sB = ((2 * K + 4) % 6) * RPB, sS = ((2 * K + 5) % 6) * RPB;
-            double cN = *(const double *)(s_mem + v_rd + sN + 16), cS = *(const double *)(s_mem + v_rd + sS + 16);
-            double wA = *(const double *)(s_mem + v_rd + sA + 8), cA = *(const double *)(s_mem + v_rd + sA + 16), eA = *(const double *)(s_mem + v_rd + sA + 24);
-            double wB = *(const double *)(s_mem + v_rd + sB + 8), cB = *(const double *)(s_mem + v_rd + sB + 16), eB = *(const double *)(s_mem + v_rd + sB + 24);
-            uint32_t kA = *(const uint32_t *)(s_mem + LY::OFF_KEY + ea + lane4), kB = *(const uint32_t *)(s_mem + LY::OFF_KEY + eb + lane4);
-            asm volatile("" : "+v"(cN), "+v"(cS), "+v"(wA), "+v"(eA), "+v"(wB), "+v"(eB), "+v"(kA), "+v"(kB)); // (one LDS round trip)
-            const double NM = (double)NOMATCH;
-            double valA = cA, valB = cB;
-            u64 redoA = 0ull, redoB = 0ull;
-            const u64 lvA = cmp_a & RF_FNE(cA, NM), lvB = cmp_b & RF_FNE(cB, NM); // .cpp:613
-            if (lvA | lvB) { // wave-uniform: rows without a live pixel copy through
-                const u64 nA = RF_FNE(cA, NM), nB = RF_FNE(cB, NM);
-                const u64 ewA = RF_FNE(eA, NM) & RF_FNE(wA, NM), nsA = nB & RF_FNE(cN, NM); // .cpp:620
-                const u64 ewB = RF_FNE(eB, NM) & RF_FNE(wB, NM), nsB = nA & RF_FNE(cS, NM);
-                if (!((lvA & (ewA ^ nsA)) | (lvB & (ewB ^ nsB)) | m_wsbad)) { // no live pixel with exactly one valid neighbour pair: the common rows
-                    const int relA = (int)(cA - 1.5), relB = (int)(cB - 1.5); // .cpp:625 (iMatch - x)
-                    const int wayA = relA & 1, wayB = relB & 1;
-                    const double2 pdA = *(const double2 *)__builtin_assume_aligned(s_mem + LY::OFF_ENT + ea * 8u + (unsigned)wayA * 1024u + lane16, 16);
-                    const double2 pdB = *(const double2 *)__builtin_assume_aligned(s_mem + LY::OFF_ENT + eb * 8u + (unsigned)wayB * 1024u + lane16, 16);
-                    const int crA = (int)(int16_t)(kA >> (wayA << 4)), crB = (int)(int16_t)(kB >> (wayB << 4));
-                    double uA, uB;
-                    u64 earlyA, earlyB;
-                    skew_common_row(cA, eA, wA, cN, cB, pdA, crA, relA, ws, lvA & ewA & nsA, (ExpTab)(s_mem + LY::OFF_EXP), uA, earlyA, redoA);
-                    skew_common_row(cB, eB, wB, cA, cS, pdB, crB, relB, ws, lvB & ewB & nsB, (ExpTab)(s_mem + LY::OFF_EXP), uB, earlyB, redoB);
-                    valA = rf_sel(earlyA) ? uA : cA;
-                    valB = rf_sel(earlyB) ? uB : cB;
-                } else {
-                    redoA = lvA & (ewA | nsA);
-                    redoB = lvB & (ewB | nsB);
-                }
-            }
-            if (!last) {
-                *(double *)(s_mem + v_rd + LY::RING + (2 * K) * RPB + 16) = valA;
-                *(double *)(s_mem + v_rd + LY::RING + (2 * K + 1) * RPB + 16) = valB;
-            }
-            const u64 stA = lvA & m_store & ~redoA, stB = lvB & m_store & ~redoB; // level T's computable rows are the owned rows
-            if (__builtin_expect((redoA | redoB) != 0ull, 0)) { // wave-uniform, rare
-#pragma unroll 1
-                for (int rr = 0; rr < 2; rr++) {
-                    const u64 m_redo = rr ? redoB : redoA;
-                    if (!m_redo) continue;
-                    SkewRare q;
-                    q.A = d.img4_own, q.B = d.img4_oth;
-                    q.upd = a.upd_list + (size_t)shard * a.upd_cap;
-                    q.cnt = a.upd_cnt + (a.flag3 & 1) * RF_UPD_SHARDS + shard;
-                    q.gout = last ? (double *)(optr + (rr ? obelow : 0u)) : nullptr;
-                    q.lds = s_mem;
-                    q.ws = ws;
-                    q.W = W, q.H = a.H, q.upd_cap = a.upd_cap;
-                    q.x0 = x0, q.r = y0 + ra + rr;
-                    const unsigned ring = LY::OFF_D + (unsigned)(t - 1) * LY::RING + 16;
-                    q.rdC = ring + (rr ? sB : sA);
-                    q.rdN = ring + (rr ? sA : sN);
-                    q.rdS = ring + (rr ? sS : sB);
-                    q.wr = ring + LY::RING + (2 * K + rr) * RPB;
-                    const unsigned er = rr ? eb : ea;
-                    q.ent = LY::OFF_ENT + er * 8u, q.key = LY::OFF_KEY + er, q.emit = LY::OFF_EMIT + (er >> 4), q.ml = LY::OFF_ML + wid * 64, q.tab = LY::OFF_EXP;
-                    q.dir = (uint32_t)blockIdx.z << 31;
-                    q.owned_row = q.r >= ya && q.r < yb;
-                    skew_rare_row(q, m_redo, m_own);
-                }
-                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): nothing of the rare path is in flight when the common path resumes
-            }
-            // (3) the pair issued two steps ago goes to LDS (rows 2u, 2u + 1: adjacent slots of every stream)
-            if (rf_sel(st_mask)) {
-                *(double2 *)(s_mem + st_base + st_off + lane16) = stg[K][0];
-                *(double2 *)(s_mem + st_base + st_off + st_pitch + lane16) = stg[K][1];
-            }
-            asm volatile("" ::"v"(stg[K][0].x), "v"(stg[K][0].y), "v"(stg[K][1].x), "v"(stg[K][1].y));
-            if (st_key && lane < 4) *(u64 *)(s_mem + LY::OFF_EMIT + (st_off >> 4) + lane8) = 0ull; // the two slots' emit masks with their keys
-            st_off += 2 * st_pitch;
-            if (st_off == st_wrap) st_off = 0;
-            // (4) level T's rows go out: two buffer stores that every wave issues (lanes with nothing to store point beyond the descriptor)
-            {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(optr), 0, obelow + 512u, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(skew_v2i, valA), rs, rf_sel(stA) ? lane8 : 0xffffffffu, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(skew_v2i, valB), rs, rf_sel(stB) ? lane8 + obelow : 0xffffffffu, 0, 0);
-            }
-            ra += 2;
-            optr += opitch2;
-            ea = eb + 256u == NE * 256u ? 0u : eb + 256u;
-            __syncthreads();
-        }
-    }
-#undef SKEW_LD16
-}
-
 // strips of 64 lanes the interior of margin m takes (strip b owns the columns [xorg + T - 1 + b uw, + uw) of [XL + 1, XR - 1])
 int refine_skew_strips(const Mg &m, int T, int uw) {
     const int xorg = (m.XL + 1 - (T - 1)) & ~7;
@@ -713,10 +486,7 @@ void launch_refine_skew(const StageArgs &a, int T, hipStream_t st, hipEvent_t ev
     } while (0)
     if (T == 2) RF_LAUNCH(2);
     else if (T == 3) RF_LAUNCH(3);
-    else if (a.skew_rps == 2) { // two rows per wave and step (T = 4 only)
-        if (a.flag) hipLaunchKernelGGL(k_refine_skew2<1>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_refine_skew2<0>, grid, dim3(256), 0, st, a);
-    } else RF_LAUNCH(4);
+    else RF_LAUNCH(4);
 #undef RF_LAUNCH
     if (ev1) (void)hipEventRecord(ev1, st);
     launch_refine_apply(a, st);

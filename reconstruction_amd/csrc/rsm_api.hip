@@ -74,7 +74,9 @@ struct rsm_ctx {
     int *d_margins = nullptr; // N*2*4 ints
     int32_t *S1[RSM_MAX_LEVELS][2]{}, *S2[RSM_MAX_LEVELS][2]{}, *tmp1 = nullptr, *tmp2 = nullptr; // per level and view
     uint32_t *img4[RSM_MAX_LEVELS][2]{};
-    int16_t *d16a[2]{}, *BL[2]{}, *BR[2]{}; // d16a: scratch (cloud flags, Rectify's mask temp)
+    int16_t *d16a[2]{}, *BL[2]{}, *BR[2]{}; // d16a: scratch (Rectify's mask temp)
+    uint8_t *cloud_flags = nullptr;         // k_cloud's per-pixel "emitted a point" flags of the last run: rsm_filter_last_cloud's lattice reads them
+                                            // long after rsm_run_pair has returned, so they have a buffer nothing else borrows
     int16_t *d16i[RSM_MAX_LEVELS][2]{}, *d16s[RSM_MAX_LEVELS][2]{}, *d16m[RSM_MAX_LEVELS][2]{}; // per level: initial-match / constraint-stage / median maps, pre-filled NOMATCH
     double *f64[3][2]{};
     int32_t *nv[2]{};
@@ -145,7 +147,6 @@ struct rsm_ctx {
                                          // workgroups at different points of their chunks share a CU better than 1 280 in lockstep (measured: 0.28 against 0.34 ms)
     int opt_refine_skew_waves_alone = 3840; // ... when no other context of the device is inside rsm_run_pair (0: the same)
     int opt_refine_skew_rows = 0;        // > 0: rows per chunk, overrides refine_skew_waves (tests)
-    int opt_refine_skew_rps = 1;         // rows a wave of the time-skewed kernel advances per step (T = 4): 1 or 2
     int opt_refine_skew_prio = 0;        // the time-skewed kernel's waves rotate their issue priority every 2^this shader clocks (0: never)
     int opt_refine_skew_uw = 0;          // columns a strip owns; 0: 66 - 2T, all its last level can compute (an even number <= that: A/B)
 
@@ -394,6 +395,7 @@ static int ensure_workspace(rsm_ctx *c, const rsm_pair_in *in) {
     DALLOC(c, c->tmp2, px);
     for (int v = 0; v < 2; v++) {
         DALLOC(c, c->d16a[v], px);
+        if (v == 0) DALLOC(c, c->cloud_flags, px);
         DALLOC(c, c->BL[v], px);
         DALLOC(c, c->BR[v], px);
         for (int i = 0; i < 3; i++) DALLOC(c, c->f64[i][v], px);
@@ -521,7 +523,6 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "refine_skew_T")) c->opt_refine_skew_T = (int)std::max(2LL, std::min(value, 4LL));
     else if (!strcmp(name, "refine_skew_min_px")) c->opt_refine_skew_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "refine_skew_waves")) c->opt_refine_skew_waves = (int)std::max(1LL, std::min(value, 1000000LL));
-    else if (!strcmp(name, "refine_skew_rps")) c->opt_refine_skew_rps = value == 2 ? 2 : 1;
     else if (!strcmp(name, "refine_skew_prio")) c->opt_refine_skew_prio = (int)std::max(0LL, std::min(value, 40LL));
     else if (!strcmp(name, "refine_skew_uw")) { // an even number of columns (the state row's 16-byte pieces start on even columns)
         if (value < 0 || value > 62 || (value & 1)) return set_err(c, RSM_E_INVALID, "refine_skew_uw %lld: 0 (= 66 - 2T) or an even number <= 66 - 2T", value);
@@ -709,7 +710,6 @@ static int refine_sweeps(rsm_ctx *c, StageArgs &a, double *const bufA[2], double
     if (skew) {
         (void)hipMemsetAsync(a.upd_cnt, 0, sizeof(int32_t) * 2 * RF_UPD_SHARDS, st);
         a.skew_prio = c->opt_refine_skew_prio;
-        a.skew_rps = skewT == 4 ? c->opt_refine_skew_rps : 1;
         a.skew_uw = (c->opt_refine_skew_uw > 0 && c->opt_refine_skew_uw <= 66 - 2 * skewT) ? c->opt_refine_skew_uw : 66 - 2 * skewT;
         int rows = 1, strips = 0;
         for (int v = 0; v < a.ndir; v++) {
@@ -960,7 +960,7 @@ extern "C" int rsm_run_pair(rsm_ctx *c) {
         const int ksize = (int)ceil(0.02 * H); // .cpp:703; spans, Q, R, T: upload_cloud_params
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_cloudprep, 0));
         launch_cloud(c->f64[par][0], c->prefix, c->img[k][0], W, H, ksize, c->d_cj1, c->d_cj2, c->d_q, c->d_R, c->d_T,
-                     c->mg[k][0], (uint8_t *)c->d16a[0], c->blk, c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
+                     c->mg[k][0], c->cloud_flags, c->blk, c->row_count, c->row_offset, c->d_npoints, c->xyz, c->bgr, (int64_t)c->cap_px, st);
         const Mg &m = c->mg[k][0];
         prof_end(c, ps14, ST_CLOUD, 4, 28.0 * (double)(m.XR - m.XL + 1) * (m.YR - m.YL + 1));
     }
@@ -1837,7 +1837,7 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
                 if (!(fabs(d - (i == j ? 1.0 : 0.0)) < 1e-9)) use_lat = false;
             }
         const double scale = (double)c->Wk[0] / c->in.origin_width * (1 << k); // .cpp:692
-        lat.flags = (const uint8_t *)c->d16a[0];
+        lat.flags = c->cloud_flags;
         lat.row_offset = c->row_offset;
         lat.W = c->Wk[k];
         lat.XL = mg.XL, lat.XR = mg.XR, lat.YL = mg.YL, lat.YR = mg.YR;

@@ -71,7 +71,6 @@ struct StageArgs {
     int flag3;         // refine: k_refine_first: bit 1 = no prefill of the second way; k_refine_skew: launch index (counter set)
     int skew_rows;     // refine (k_refine_skew): rows per chunk
     int skew_uw;       // refine (k_refine_skew): columns a strip owns (<= 66 - 2T)
-    int skew_rps;      // refine (k_refine_skew, T = 4): rows a wave advances per step (1 or 2)
     int skew_prio;     // refine (k_refine_skew): issue priority rotates every 2^skew_prio shader clocks (0: never)
     int opt_ncc_bytes;              // force the generic byte-wise NCC kernel (A/B validation)
     int opt_no_exact;               // skip k_ncc_exact (timing A/B only: ties then follow the integer form)

@@ -16,8 +16,6 @@ from helpers import NOMATCH, cloud_scale, diff_report, host_libm_is_glibc_with_f
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_SKEW_RPS = 1  # rsm_api.hip: opt_refine_skew_rps
-
 CASES = {
     "s96x64_r2": dict(width=96, height=64, levels=2, radius=2, offset=2, pair=0),
     "s128x96_r2_neg_holes": dict(width=128, height=96, levels=3, radius=2, offset=2, pair=1, holes=True,
@@ -381,18 +379,15 @@ def test_whole_pair_against_the_libm_exp_oracle(ctx):
         assert np.array_equal(res.xyz, ref["xyz"], equal_nan=True)
 
 
-@pytest.mark.parametrize("T,first,rows,uw,rps", [(2, 1, 0, 0, 1), (3, 1, 7, 0, 1), (4, 1, 16, 0, 1), (3, 5, 0, 0, 1), (4, 9, 33, 0, 1), (2, 30, 12, 0, 1), (3, 2, 1000, 0, 1),
-                                                 (4, 22, 0, 0, 1), (4, 1, 0, 56, 1), (4, 2, 5, 56, 1), (4, 3, 1000, 40, 1), (4, 9, 33, 2, 1), (2, 3, 9, 62, 1), (3, 4, 11, 30, 1),
-                                                 (4, 1, 16, 0, 2), (4, 1, 17, 0, 2), (4, 9, 33, 0, 2), (4, 22, 0, 0, 2), (4, 1, 0, 56, 2), (4, 2, 5, 56, 2), (4, 3, 1000, 40, 2), (4, 5, 12, 2, 2)])
-def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows, uw, rps):
+@pytest.mark.parametrize("T,first,rows,uw", [(2, 1, 0, 0), (3, 1, 7, 0), (4, 1, 16, 0), (3, 5, 0, 0), (4, 9, 33, 0), (2, 30, 12, 0), (3, 2, 1000, 0),
+                                             (4, 22, 0, 0), (4, 1, 0, 56), (4, 2, 5, 56), (4, 3, 1000, 40), (4, 9, 33, 2), (2, 3, 9, 62), (3, 4, 11, 30), (4, 1, 17, 0)])
+def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows, uw):
     """k_refine_skew (T Jacobi sweeps per launch: wave t of a workgroup streams down a strip of 64 lanes with sweep t on row
     s - 2t + 1, the state rings and both cache ways' rows in LDS, one 16-byte load and LDS write per wave and step, the common
     row straight-line with unscaled divisions and its guards looked at afterwards, cache updates deferred to the update list)
     from sweep `first` on -- from the first cached sweep, where nearly every pixel misses and every row takes the rare path, to
     the settled regime -- gives the single-sweep result, i.e. the oracle's, bit for bit; chunk heights from 4T rows to the whole
-    level, sweep counts that leave 0..T-1 single sweeps at the end, strips of 66 - 2T columns (the default) and narrower; rps = 2:
-    the form of the T = 4 kernel in which a wave advances two rows per step (levels three rows apart, even and odd chunk heights)."""
-    ctx.set_option("refine_skew_rps", rps)
+    level, sweep counts that leave 0..T-1 single sweeps at the end, strips of 66 - 2T columns (the default) and narrower."""
     ctx.set_option("refine_skew_from", first)
     ctx.set_option("refine_skew_T", T)
     ctx.set_option("refine_skew_min_px", 0)
@@ -408,13 +403,12 @@ def test_refine_time_skewed_sweeps_are_bit_identical(ctx, T, first, rows, uw, rp
                 for iters in (q["iters"], q["iters"] - 1):
                     want = q["out"] if iters == q["iters"] else orc.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
                     g = ctx.disparity_refine(q["inp"], fin["imgs"][k][v], fin["imgs"][k][1 - v], iters, cfg.ws, q["mg"][v])
-                    assert np.array_equal(g, want), diff_report("skew T %d from %d rows %d uw %d rps %d %s L%d v%d iters %d" % (T, first, rows, uw, rps, name, k, v, iters), g, want)
+                    assert np.array_equal(g, want), diff_report("skew T %d from %d rows %d uw %d %s L%d v%d iters %d" % (T, first, rows, uw, name, k, v, iters), g, want)
             res = ctx.match_pair(cfg)
             for v in range(2):
                 assert np.array_equal(res.disparity[v], fin["disparity"][v])
     finally:
-        ctx.set_option("refine_skew_rps", DEFAULT_SKEW_RPS)  # the defaults
-        ctx.set_option("refine_skew_from", 22)
+        ctx.set_option("refine_skew_from", 22)  # the defaults
         ctx.set_option("refine_skew_T", 4)
         ctx.set_option("refine_skew_min_px", 1000000)
         ctx.set_option("refine_skew_rows", 0)
