@@ -186,8 +186,11 @@ __device__ __forceinline__ int skew_stream(int w, int j) {
     return w == 0 ? j : 2 + j; // T = 2
 }
 
+#ifndef SKEW_WPE
+#define SKEW_WPE 5 // waves per SIMD the register budget is set for (5: 96 VGPRs, what the LDS per workgroup allows)
+#endif
 template <int T, int TOP>
-__global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_refine_skew(StageArgs a) {
+__global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(SKEW_WPE, SKEW_WPE))) void k_refine_skew(StageArgs a) {
     typedef SkewLds<T> LY;
     constexpr int NE = LY::NE, RPB = LY::RPB;
     constexpr int NSTR = T == 4 ? 1 : 2; // streams a wave carries
