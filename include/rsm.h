@@ -246,7 +246,7 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          nothing on the default two rounds
  *   "cu_share" = n         n > 1: the context's streams are confined to one of n equal shares of the compute units (the
  *                          context's creation ordinal on its device picks the share; measured slower than sharing the whole
- *                          chip in turns); 0 / 1 = the whole chip.  The masked streams are BLOCKING streams
+ *                          chip in turns, profiles/LAB_NOTES.md 4); 0 / 1 = the whole chip.  The masked streams are BLOCKING streams
  *                          (hipExtStreamCreateWithCUMask has no non-blocking flag): legacy null-stream work of the process then
  *                          synchronises with them.  RSM_E_STATE while the context is inside rsm_run_pair
  *   "filter_list"          ... its list passes (a thread per query the tile pass left over, windows read from the lattice copy): bit 0

@@ -1,4 +1,4 @@
-// Probe for the one-wave-per-strip form of the time-skewed refine kernel:
+// Probe for the one-wave-per-strip form of the time-skewed refine kernel (profiles/LAB_NOTES.md 4, round 5):
 //  (a) fp64 fma issue rate of a SIMD as a function of resident waves x independent dependent-chains per wave,
 //  (b) the lane shifts v_mov_b32_dpp wave_shr:1 / wave_shl:1 on gfx950 (which way they move, what the edge lanes get),
 //  (c) how many 128-thread workgroups of 39 296 B of LDS (two strips + the exp table) a CU holds at once.

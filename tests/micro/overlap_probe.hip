@@ -1,4 +1,4 @@
-// Probe (round 5): do a wave's outstanding global loads make progress while the SIMD's vector unit issues fp64
+// Probe (round 5, profiles/LAB_NOTES.md 4): do a wave's outstanding global loads make progress while the SIMD's vector unit issues fp64
 // fma back to back?  Two waves per SIMD (256 VGPRs each would allow no more), every wave streams down its own 512-byte column
 // of a row-major array, PF steps of prefetch into registers, and runs `fmas` dependent-chain fp64 fma (4 chains) per step.
 //   loads only, fma only, both: if both ~ max(loads, fma) the two overlap; if ~ sum, they do not.
