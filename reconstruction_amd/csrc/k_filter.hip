@@ -476,7 +476,13 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float *__restrict__ xyz, 
 #define WIN_TX 32
 #define WIN_TY 8
 #define WIN_NB 32   // distance bins per query over [0, bound^2): the rank's bin holds ~1.5 (k + 1) / (its index) values, a handful
-#define WIN_LCAP 32 // values of the rank's bin a query can list (more: undecided -> the ladder); the list reuses the counters' LDS
+#define WIN_LCAP 24 // values of the rank's bin a query can list (more: undecided -> the ladder); the list reuses the counters' LDS
+#ifndef WIN_DRAIN_W
+#define WIN_DRAIN_W 4 // waiting values whose square roots are taken together (reads in flight together, sequences interleaved)
+#endif
+#ifndef WIN_TILE_CH
+#define WIN_TILE_CH 9 // candidates per chunk of the tile form (two register buffers of that many 16-byte entries)
+#endif
 struct WinGeom {
     int gw, gh;         // lattice copy incl. the border: (XR - XL + 1 + 2 PAD) x (YR - YL + 1 + 2 PAD)
     double qz;          // Q[2][3] scaled (.cpp:698)
@@ -534,6 +540,17 @@ constexpr int win_halfwidth(int WR, int b) { // widest |a| of the disc's row b, 
     const int a = win_isqrt((WR + 1) * (WR + 1) - 1 - b * b);
     return a < WR ? a : WR;
 }
+// a row of wd candidates in nch chunks: the first wd % nch one longer
+template <int wd, int nch>
+struct WinSplit {
+    static constexpr int nmax = (wd + nch - 1) / nch;
+    static constexpr int size(int j) { return wd / nch + (j < wd % nch ? 1 : 0); }
+    static constexpr int off(int j) {
+        int o = 0;
+        for (int i = 0; i < j; i++) o += size(i);
+        return o;
+    }
+};
 template <int WR, int CH, class Loader>
 __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, const WinGeom &g, int mean_k, unsigned int *col, float *out, double *lim_out) {
     constexpr int NC = 2 * WR + 1;
@@ -566,33 +583,43 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
         const float dz = P.z - o.z;
         return (sq.x + sq.y) + dz * dz;
     };
-    // n candidates of window row r from column c0 on: all reads first (in flight together), then the arithmetic
-    auto chunk_d2 = [&](int r, int c0, auto n_, float *d2) {
-        constexpr int n = decltype(n_)::value;
-        float4 o[n];
-#pragma unroll
-        for (int i = 0; i < n; i++) o[i] = ld(r, c0 + i);
-#pragma unroll
-        for (int i = 0; i < n; i++) asm volatile("" : "+v"(o[i].w)); // (keeps the reads 16-byte ones: twice the LDS rate of the 12-byte form -- AFTER all of them
-                                                                     // have been issued: a use right behind each read puts a wait for it there)
-#pragma unroll
-        for (int i = 0; i < n; i++) d2[i] = d2_of(o[i]); // NaN for a pixel without a point: every test below fails
-    };
-    // the disc, a row class at a time (rolled loops over the rows of a class, the columns in chunks of at most CH)
-    auto for_disc = [&](auto &&body) {
+    // The disc, a row class at a time.  A row is cut into an even number of chunks of at most CH candidates and the chunks stream
+    // through two register buffers: the 16-byte reads of the NEXT chunk (of this row, or the first of the next row) are issued
+    // before the arithmetic of the current one, so a wave computes while its own reads are under way (round 5 read a whole row,
+    // waited, computed: with the two waves per SIMD that 75 KB of LDS leave, the vector unit idled a third of the time).
+    // pre(n) before a chunk of n candidates, body(d2) per candidate; NaN for a pixel without a point: every test fails.
+    auto for_disc = [&](auto &&pre, auto &&body) {
         auto rows = [&](int lo, int hi, auto hw_) { // the rows with |b| in [lo, hi] (lo = 0: one run of rows, else one above and one below), half width hw
-            constexpr int hw = decltype(hw_)::value, wd = 2 * hw + 1, full = wd / CH, tail = wd % CH;
+            constexpr int hw = decltype(hw_)::value, wd = 2 * hw + 1, nch0 = (wd + CH - 1) / CH, nch = nch0 + (nch0 & 1);
+            typedef WinSplit<wd, nch> S;
+            float4 buf[2][S::nmax];
+            auto issue = [&](auto j_, auto b_, int r) { // the reads of chunk j of window row r, into buffer b
+                constexpr int j = decltype(j_)::value, bb = decltype(b_)::value;
+#pragma unroll
+                for (int i = 0; i < S::size(j); i++) buf[bb][i] = ld(r, WR - hw + S::off(j) + i);
+            };
+            auto use = [&](auto j_, auto b_) {
+                constexpr int j = decltype(j_)::value, bb = decltype(b_)::value;
+#pragma unroll
+                for (int i = 0; i < S::size(j); i++) asm volatile("" : "+v"(buf[bb][i].w)); // (keeps the reads 16-byte ones: twice the LDS rate of the 12-byte form)
+                pre(S::size(j));
+#pragma unroll
+                for (int i = 0; i < S::size(j); i++) body(d2_of(buf[bb][i]));
+            };
+            auto steps = [&](auto &&self, auto j_, int r, int rn) -> void {
+                constexpr int j = decltype(j_)::value;
+                if constexpr (j + 1 < nch) issue(std::integral_constant<int, j + 1>(), std::integral_constant<int, (j + 1) & 1>(), r);
+                else issue(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), rn);
+                __builtin_amdgcn_sched_barrier(0); // (the reads stay ahead of the arithmetic)
+                use(j_, std::integral_constant<int, j & 1>());
+                if constexpr (j + 1 < nch) self(self, std::integral_constant<int, j + 1>(), r, rn);
+            };
 #pragma unroll 1
             for (int run = 0; run < (lo == 0 ? 1 : 2); run++) {
                 const int r0 = lo == 0 ? WR - hi : (run ? WR + lo : WR - hi), r1 = lo == 0 ? WR + hi : (run ? WR + hi : WR - lo);
+                issue(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), r0);
 #pragma unroll 1
-                for (int r = r0; r <= r1; r++) {
-                    if (full > 0) {
-#pragma unroll 1
-                        for (int c = 0; c < full; c++) body(r, WR - hw + c * CH, std::integral_constant<int, (full > 0 ? CH : 1)>());
-                    }
-                    if (tail > 0) body(r, WR - hw + full * CH, std::integral_constant<int, (tail > 0 ? tail : 1)>());
-                }
+                for (int r = r0; r <= r1; r++) steps(steps, std::integral_constant<int, 0>(), r, r + (r < r1 ? 1 : 0)); // (after the last row: its first chunk once more, unused)
             }
         };
         constexpr int g1 = WR / 2, g2 = 3 * WR / 4, g3 = 7 * WR / 8;
@@ -603,39 +630,40 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
     };
     // pass 1: histogram of the window's squared distances (the point itself included: d2 = 0, as nearestKSearch(k + 1)); branch-free:
     // what lies beyond the bound goes to the sink row
-    for_disc([&](int r, int c0, auto n_) {
-        constexpr int n = decltype(n_)::value;
-        float d2[n];
-        chunk_d2(r, c0, n_, d2);
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            const int b = bin_of(d2[i]);
+    for_disc([](int) {}, [&](float d2) {
+        const int b = bin_of(d2);
 #if defined(WIN_EXP) && (WIN_EXP & 1) // timing experiment (results invalid): no histogram updates
-            asm volatile("" ::"v"(b));
+        asm volatile("" ::"v"(b));
 #else
-            atomicAdd(col + 256 * b, 1u); // (no return value: a fire-and-forget ds_add)
+        atomicAdd(col + 256 * b, 1u); // (no return value: a fire-and-forget ds_add)
 #endif
-        }
     });
-    // the bin holding rank `want`
+    // the bin holding rank `want` (all counters read first: one LDS round trip, not one per bin)
     int below = 0, bstar = -1, in_bin = 0;
-#pragma unroll 1
-    for (int b = 0; b < WIN_NB; b++) {
-        const int h = (int)col[256 * b];
-        if (bstar < 0 && below + h >= want) {
-            bstar = b;
-            in_bin = h;
+    {
+        int h[WIN_NB];
+#pragma unroll
+        for (int b = 0; b < WIN_NB; b++) h[b] = (int)col[256 * b];
+#pragma unroll
+        for (int b = 0; b < WIN_NB; b++) {
+            const bool hit = bstar < 0 && below + h[b] >= want;
+            bstar = hit ? b : bstar;
+            in_bin = hit ? h[b] : in_bin;
+            below = bstar < 0 ? below + h[b] : below;
         }
-        if (bstar < 0) below += h;
     }
     if (!(bstar >= 0 && in_bin <= WIN_LCAP)) return false; // fewer than k + 1 points within the bound in the window, or too many (nearly) equal distances
     // pass 2: the exact sum below the bin, the bin's values listed (over the counters: they are dead now).  The bin tests become
-    // two float compares: t_lo / t_hi = the smallest floats whose bin is >= bstar / > bstar (bin_of is monotone)
+    // two float compares: t_lo / t_hi = the smallest floats whose bin is >= bstar / > bstar (bin_of is monotone).
+    // A tenth of a wave's lanes has a value below t_lo per candidate, so a square root taken where the value is met runs its whole
+    // sequence for a few lanes nearly every time (36 instructions per candidate, round 5).  Instead every value below t_hi WAITS in
+    // the lane's own column -- rows in_bin .. WIN_NB, the rows the bin's list leaves free -- and before a chunk that some lane has
+    // no room for, the wave takes the square roots of everything waiting, eight rows at a time (the reads in flight together, the
+    // sequences interleaved): most lanes busy, a tenth as often.  The sum is exact in double (order-free), so its bits are those
+    // of the sum in window order.
     float *lst = (float *)col;
     double sum = 0.0;
     int nl = 0;
-    float pend = 0.0f;               // (WIN_PENDING_SQRT) the lane's value waiting for its square root
-    unsigned long long m_full = 0ull; // ... the lanes whose slot is taken
     unsigned int odd_min = 0xffffffffu; // tracks whether an input outside the trimmed square root's range (0 < d2 < 2^-96) was met
     auto first_in = [&](int b) { // smallest float t >= 0 with bin_of(t) >= b, b in 1 .. WIN_NB
         float t = (float)b / inv_w;
@@ -645,70 +673,87 @@ __device__ __forceinline__ bool win_query(const Loader &ld, const float4 P, cons
     };
     const float t_lo = bstar > 0 ? first_in(bstar) : 0.0f;
     const float t_hi = fminf(first_in(bstar + 1), range); // (a value at the bound's edge can round into the last bin: it is not listed, the count then disagrees and the query is left undecided)
-#if !(defined(WIN_EXP) && (WIN_EXP & 2)) // (timing experiment, results invalid: no second pass)
-    for_disc([&](int r, int c0, auto n_) {
-        constexpr int n = decltype(n_)::value;
-        float d2[n];
-        chunk_d2(r, c0, n_, d2);
+    static_assert(WIN_NB + 1 - WIN_LCAP >= CH, "a lane's waiting rows hold at least one chunk");
+    typedef __attribute__((address_space(3))) float lds_float; // (32-bit LDS addresses: a generic pointer costs 64-bit arithmetic per candidate)
+    lds_float *const wait0 = (lds_float *)lst + 256 * in_bin, *const wait_end = (lds_float *)lst + 256 * (WIN_NB + 1), *const wait_last = wait_end - 256;
+    lds_float *wait = wait0;
+    asm volatile("" : "+v"(wait)); // (one register, not base + offset: an addition less per waiting value)
+    auto drain = [&]() {
+        // (the trimmed square root itself; an input it is not made for -- positive and below 2^-96: float32 coordinates do not
+        // produce such differences -- marks the query `odd`, and it is left to the later passes, which take sqrtf)
+#pragma unroll 1
+        for (const lds_float *p = wait0; p < wait; p += WIN_DRAIN_W * 256) {
+            float v[WIN_DRAIN_W];
 #pragma unroll
-        for (int i = 0; i < n; i++) {
-#ifdef WIN_PENDING_SQRT
-            // A value below t_lo waits in the lane's one-entry slot (0 = empty: its square root adds nothing); the square roots are
-            // taken for the whole wave only when some lane's slot is taken AND it has another value -- every second or third candidate
-            // instead of every one (a tenth of the lanes has a value per candidate, so some lane nearly always does).
-            const unsigned long long mq = __builtin_amdgcn_fcmpf(d2[i], t_lo, 4); // ordered <
-            if (mq & m_full) {
-                odd_min = min(odd_min, __float_as_uint(pend) - 1u);
-                sum += (double)sqrtf_rn_core(pend);
-                pend = 0.0f;
-                m_full = 0ull;
-            }
-            pend = __builtin_amdgcn_inverse_ballot_w64(mq) ? d2[i] : pend;
-            m_full |= mq;
-            if (!(d2[i] < t_lo) && d2[i] < t_hi) {
-#else
-            if (d2[i] < t_lo) {
-                // (the trimmed square root itself; an input it is not made for -- positive and below 2^-96: float32 coordinates do not
-                // produce such differences -- marks the query `odd`, and it is left to the later passes, which take sqrtf)
-                odd_min = min(odd_min, __float_as_uint(d2[i]) - 1u); // (the smallest positive pattern met, minus one; 0 wraps to the top)
-                sum += (double)sqrtf_rn_core(d2[i]);
-            } else if (d2[i] < t_hi) {
-#endif
-                lst[min(nl, WIN_NB) * 256] = d2[i]; // (nl <= in_bin <= WIN_LCAP by the histogram; the clamp keeps a disagreement inside the column)
-                nl++;
+            for (int t = 0; t < WIN_DRAIN_W; t++) v[t] = *(p + 256 * t < wait_last ? p + 256 * t : wait_last); // (rows at or beyond `wait`: read, not used)
+#pragma unroll
+            for (int t = 0; t < WIN_DRAIN_W; t++) {
+                const bool live = p + 256 * t < wait, low = v[t] < t_lo;
+                if (live && !low) { // one of the bin's own values: to the list
+                    lst[min(nl, in_bin) * 256] = v[t]; // (nl <= in_bin by the histogram; the clamp keeps a disagreement inside the column -- it then
+                    nl++;                              // spoils a waiting value of a query that is left undecided anyway)
+                }
+                const float u = live && low ? v[t] : 0.0f;       // (the square root of 0 adds nothing)
+                odd_min = min(odd_min, __float_as_uint(u) - 1u); // (the smallest positive pattern met, minus one; 0 wraps to the top)
+                sum += (double)sqrtf_rn_core(u);
             }
         }
-    });
+        wait = wait0;
+        asm volatile("" : "+v"(wait));
+    };
+#if !(defined(WIN_EXP) && (WIN_EXP & 2)) // (timing experiment, results invalid: no second pass)
+    for_disc(
+        [&](int n) {
+            if (__builtin_expect(__any(wait + 256 * n > wait_end), 0)) drain();
+        },
+        [&](float d2) {
+            if (d2 < t_hi) // below the bin or in it: waits (NaN -- a pixel without a point -- fails the test).  *wait++ = d2 with a row's stride, as
+                           // the two instructions it is (the compiler adds into a temporary and copies it back: a third of this region)
+            {
+                *wait = d2;
+                wait += 256;
+            }
+        });
 #endif
-#ifdef WIN_PENDING_SQRT
-    odd_min = min(odd_min, __float_as_uint(pend) - 1u);
-    sum += (double)sqrtf_rn_core(pend);
-#endif
-    (void)pend;
-    (void)m_full;
-    // tau = the (want - below)-th smallest of the listed values (by value: ties are equal distances)
+    drain();
+    // tau = the (want - below)-th smallest of the listed values (by value: ties are equal distances): the list into registers
+    // (unused slots +inf), sorted by Batcher's merge exchange on the bit patterns (non-negative floats order as unsigned integers)
     const int rank = want - below; // 1 .. in_bin
-    float tau = 0.0f;
-    int less = 0;
-#pragma unroll 1
-    for (int i = 0; i < nl; i++) {
-        const float v = lst[i * 256];
-        int lt = 0, le = 0;
-#pragma unroll 1
-        for (int j = 0; j < nl; j++) {
-            const float u = lst[j * 256];
-            lt += u < v;
-            le += u <= v;
-        }
-        if (lt < rank && rank <= le) { // v is the rank-th smallest
-            tau = v;
-            less = lt;
+    unsigned int u[WIN_LCAP];
+#pragma unroll
+    for (int j = 0; j < WIN_LCAP; j++) u[j] = __float_as_uint(lst[j * 256]);
+#pragma unroll
+    for (int j = 0; j < WIN_LCAP; j++) u[j] = j < nl ? u[j] : 0x7f800000u;
+#pragma unroll
+    for (int pp = 1; pp < WIN_LCAP; pp *= 2) {
+#pragma unroll
+        for (int k = pp; k >= 1; k /= 2) {
+#pragma unroll
+            for (int j = k % pp; j + k < WIN_LCAP; j += 2 * k) {
+#pragma unroll
+                for (int i = 0; i < (k < WIN_LCAP - j - k ? k : WIN_LCAP - j - k); i++) {
+                    if ((i + j) / (2 * pp) == (i + j + k) / (2 * pp)) {
+                        const unsigned int lo = min(u[i + j], u[i + j + k]), hi = max(u[i + j], u[i + j + k]);
+                        u[i + j] = lo;
+                        u[i + j + k] = hi;
+                    }
+                }
+            }
         }
     }
-#pragma unroll 1
-    for (int i = 0; i < nl; i++) {
-        const float v = lst[i * 256];
-        if (v < tau) sum += (double)sqrtf_rn(v);
+    unsigned int tau_b = 0u;
+#pragma unroll
+    for (int j = 0; j < WIN_LCAP; j++) tau_b = (j == rank - 1) ? u[j] : tau_b;
+    const float tau = __uint_as_float(tau_b);
+    int less = 0;
+#pragma unroll
+    for (int j = 0; j < WIN_LCAP; j++) less += u[j] < tau_b;
+#pragma unroll
+    for (int j = 0; j < WIN_LCAP; j++) { // the values below tau are the first `less` of the sorted list
+        if (!__any(j < less)) break;
+        const float x = j < less ? __uint_as_float(u[j]) : 0.0f;
+        odd_min = min(odd_min, __float_as_uint(x) - 1u);
+        sum += (double)sqrtf_rn_core(x);
     }
     if (!(nl == in_bin && tau < range) || odd_min < 0x0f7fffffu) return false;
     // every point outside the window is farther than sqrt(tau): the k + 1 smallest are all here
@@ -743,7 +788,7 @@ __global__ __launch_bounds__(256) void k_sor_window(const float4 *__restrict__ l
     auto ld = [&](int r, int c) { return s_t[ty + r][tx + c]; };
     float res = 0.0f;
     double lim = 0.0;
-    const bool ok = valid && win_query<WR, 2 * WR + 1>(ld, P, g, mean_k, &s_u[0][tid], &res, &lim);
+    const bool ok = valid && win_query<WR, WIN_TILE_CH>(ld, P, g, mean_k, &s_u[0][tid], &res, &lim);
     if (PROBE) {
         const unsigned long long mv = __ballot(valid), mo = __ballot(ok);
         float sl = valid ? (float)fmax(lim, 0.0) : 0.0f; // the mean bound: what the queries this radius leaves over have in common (tau >= lim^2)
@@ -813,8 +858,10 @@ __global__ __launch_bounds__(256) void k_sor_window_wave(const float4 *__restric
     const int ncx = x1 - x0 + 1, M = ncx * (y1 - y0 + 1);
     const float4 *base = lat + (size_t)y0 * g.gw + x0;
     const int gw = g.gw;
+    // (row of candidate c by a multiplication: c / ncx exactly for c ncx < 2^32 -- the integer division was half of this kernel's instructions)
+    const unsigned int ncx_inv = 0xffffffffu / (unsigned int)ncx + 1u;
     auto cand = [&](int c) -> float { // NaN for a pixel without a point: every comparison fails
-        const int r = c / ncx, col = c - r * ncx;
+        const int r = ncx > 1 ? (int)__umulhi((unsigned int)c, ncx_inv) : c, col = c - r * ncx; // (ncx = 1: the reciprocal does not fit)
         const float4 o = base[(size_t)r * gw + col];
         return fdist2(P.x, P.y, P.z, o.x, o.y, o.z);
     };
@@ -1142,27 +1189,9 @@ __device__ void pcl_plane_from_cov(const double *cov, double *nrm, double *curva
     *curvature = (tr != 0.0) ? fabs(ev / tr) : 0.0;
 }
 
-// normal_3d.h computePointNormal over the radius neighbourhood + flipNormalTowardsViewpoint(origin) + the turn toward
-// CamCenter (CCloudOptimization.cpp:114-121); thread = sorted point, result stored at the point's original position
-__global__ __launch_bounds__(256) void k_cloud_normals(const float4 *__restrict__ sxyz, const unsigned long long *__restrict__ keys, int n,
-                                                        FGrid g, float r2, float cx, float cy, float cz, float4 *__restrict__ normals) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const float4 p = sxyz[j];
-    int rs[9], re[9];
-    ranges9(keys, n, g, p.x, p.y, p.z, rs, re);
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < 9; r++)
-        for (int q = rs[r]; q < re[r]; q++) {
-            const float4 o = sxyz[q];
-            if (!(fdist2(p.x, p.y, p.z, o.x, o.y, o.z) < r2)) continue;
-            const double x = o.x, y = o.y, z = o.z;
-            a0 += x * x; a1 += x * y; a2 += x * z; a3 += y * y; a4 += y * z; a5 += z * z;
-            a6 += x; a7 += y; a8 += z;
-            cnt++;
-        }
+// computePointNormal's covariance from the nine sums, the plane, flipNormalTowardsViewpoint(origin) + the turn toward CamCenter
+__device__ float4 normal_from_sums(double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7, double a8, int cnt, const float4 p,
+                                   float cx, float cy, float cz) {
     float4 out;
     if (cnt < 3) {
         out.x = out.y = out.z = out.w = __uint_as_float(0x7fc00000u);
@@ -1186,7 +1215,92 @@ __global__ __launch_bounds__(256) void k_cloud_normals(const float4 *__restrict_
         if (nx * vx + ny * vy + nz * vz < 0.0f) { nx = -nx; ny = -ny; nz = -nz; } // :116-120
         out = make_float4(nx, ny, nz, (float)curv);
     }
-    normals[__float_as_uint(p.w)] = out;
+    return out;
+}
+
+// normal_3d.h computePointNormal over the radius neighbourhood + flipNormalTowardsViewpoint(origin) + the turn toward
+// CamCenter (CCloudOptimization.cpp:114-121); thread = sorted point, result stored at the point's original position
+__global__ __launch_bounds__(256) void k_cloud_normals(const float4 *__restrict__ sxyz, const unsigned long long *__restrict__ keys, int n,
+                                                        FGrid g, float r2, float cx, float cy, float cz, float4 *__restrict__ normals) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float4 p = sxyz[j];
+    int rs[9], re[9];
+    ranges9(keys, n, g, p.x, p.y, p.z, rs, re);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 9; r++)
+        for (int q = rs[r]; q < re[r]; q++) {
+            const float4 o = sxyz[q];
+            if (!(fdist2(p.x, p.y, p.z, o.x, o.y, o.z) < r2)) continue;
+            const double x = o.x, y = o.y, z = o.z;
+            a0 += x * x; a1 += x * y; a2 += x * z; a3 += y * y; a4 += y * z; a5 += z * z;
+            a6 += x; a7 += y; a8 += z;
+            cnt++;
+        }
+    normals[__float_as_uint(p.w)] = normal_from_sums(a0, a1, a2, a3, a4, a5, a6, a7, a8, cnt, p, cx, cy, cz);
+}
+
+// ---- normals on the pixel lattice (round 6).  The radius search of the normals is a window search too: every point within r of
+// P lies inside the (2 w + 1)^2 pixels around P's own as soon as the window's bound (k_sor_window's: the distance from P to every
+// ray at a pixel distance >= w + 1) exceeds r -- solved for w per point; the lattice copy, with the removed points blanked, replaces
+// the sort of the filtered cloud into a grid of r-cells and the walk over 27 of them.
+__device__ __forceinline__ int win_need(const float4 P, const WinGeom &g, double r) {
+    const double dx = (double)P.x - g.T[0], dy = (double)P.y - g.T[1], dz = (double)P.z - g.T[2];
+    const double F2 = fabs(g.rz[0] * dx + g.rz[1] * dy + g.rz[2] * dz), nP = sqrt(dx * dx + dy * dy + dz * dz);
+    const double iw = F2 / fabs(g.qz);
+    const double coord = fmax(fmax(fabs((double)P.x), fabs((double)P.y)), fabs((double)P.z)) + nP;
+    const double rr = (r * (1.0 + 2e-6) + 4e-7 * coord) / (1.0 - 1e-5); // LB (1 - 1e-5) - 4e-7 coord > r (1 + 2e-6): k_sor_window's margins
+    if (!(F2 > rr)) return 1 << 20;                                     // LB(w) = F2 (w + 1) / (nP / iw + w + 1) never reaches it
+    const double x = rr * (nP / fmax(iw, 1e-300)) / (F2 - rr);          // LB(w) > rr  <=>  w + 1 > x
+    return x < (double)(1 << 20) ? (int)x : 1 << 20;
+}
+__global__ __launch_bounds__(256) void k_normal_need(const float4 *__restrict__ lat, const unsigned int *__restrict__ cell_of, int64_t n, WinGeom g, double r,
+                                                      int *__restrict__ wmax) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int need = 0;
+    if (i < n) {
+        const float4 P = lat[cell_of[i]];
+        if (P.x == P.x) need = win_need(P, g, r);
+    }
+    for (int o = 32; o > 0; o >>= 1) need = max(need, __shfl_xor(need, o));
+    if ((threadIdx.x & 63) == 0 && need > *(volatile int *)wmax) atomicMax(wmax, need); // (same-address atomics retire ~88 per microsecond: one per wave was 0.7 ms)
+}
+__global__ void k_lattice_drop(const unsigned int *__restrict__ flag, const unsigned int *__restrict__ cell_of, int64_t n, float4 *__restrict__ lat) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !flag[i]) lat[cell_of[i]].x = __uint_as_float(0x7fc00000u);
+}
+// thread = a point of the filtered cloud; the arithmetic of k_cloud_normals over the window's points (row by row instead of cell by cell)
+__global__ __launch_bounds__(256) void k_normals_lattice(const float4 *__restrict__ lat, const unsigned int *__restrict__ cell_of,
+                                                          const int32_t *__restrict__ kept_index, int64_t m, WinGeom g, double r, float r2, float cx, float cy,
+                                                          float cz, float4 *__restrict__ normals) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 p = make_float4(__uint_as_float(0x7fc00000u), 0.0f, 0.0f, 0.0f);
+    unsigned int cell = 0;
+    if (o < m) {
+        cell = cell_of[kept_index[o]];
+        p = lat[cell];
+    }
+    const bool live = p.x == p.x; // (a non-finite point has no lattice entry: its normal stays NaN)
+    int w = live ? win_need(p, g, r) : 0;
+    for (int t = 32; t > 0; t >>= 1) w = max(w, __shfl_xor(w, t)); // one window per wave: its points are neighbours on a row
+    w = min(w, WIN_PAD);
+    if (!live) return;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+    int cnt = 0;
+    for (int b = -w; b <= w; b++) {
+        const float4 *row = lat + (size_t)cell + (ptrdiff_t)b * g.gw;
+        for (int a = -w; a <= w; a++) {
+            const float4 q = row[a];
+            if (!(fdist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2)) continue; // (NaN: a pixel without a point, or a removed one)
+            const double x = q.x, y = q.y, z = q.z;
+            a0 += x * x; a1 += x * y; a2 += x * z; a3 += y * y; a4 += y * z; a5 += z * z;
+            a6 += x; a7 += y; a8 += z;
+            cnt++;
+        }
+    }
+    normals[o] = normal_from_sums(a0, a1, a2, a3, a4, a5, a6, a7, a8, cnt, p, cx, cy, cz);
 }
 
 __global__ void k_pack_filtered16(const double *__restrict__ xyz, const uint8_t *__restrict__ bgr, const int32_t *__restrict__ kept, int64_t m,
@@ -1319,9 +1433,11 @@ bool sample_extent(FilterArena *A, const float *d_xyz, int64_t n, hipStream_t st
         for (int s = 0; s < S; s++)
             if (std::isfinite(h[3 * (size_t)s]) && std::isfinite(h[3 * (size_t)s + 1]) && std::isfinite(h[3 * (size_t)s + 2])) v.push_back(h[3 * (size_t)s + a]);
         if (v.empty()) v.push_back(0.0f);
-        std::sort(v.begin(), v.end());
-        lo[a] = v[(size_t)(0.01 * (v.size() - 1))];
-        hi[a] = v[(size_t)(0.99 * (v.size() - 1))];
+        const size_t q_lo = (size_t)(0.01 * (v.size() - 1)), q_hi = (size_t)(0.99 * (v.size() - 1)); // (two selections: a full sort of the
+        std::nth_element(v.begin(), v.begin() + q_lo, v.end());                                        // three samples took 0.8 ms of every call)
+        lo[a] = v[q_lo];
+        std::nth_element(v.begin() + q_lo, v.begin() + q_hi, v.end());
+        hi[a] = v[q_hi];
     }
     return true;
 }
@@ -1420,7 +1536,6 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     if (n <= 0) return RSM_OK;
     if (n >= (1ll << 31) || mean_k < 1 || !A) return RSM_E_INVALID;
     float lo[3], hi[3], flo[3], fhi[3];
-    if (!sample_extent(A, d_xyz, n, st, lo, hi)) return RSM_E_HIP;
     // exact bounding box (the sample's extremes are not the cloud's) and the number of finite points: only they take
     // part in the searches (PCL: the k-d tree skips the others)
     unsigned int *d_bb = A->get<unsigned int>(8);
@@ -1449,20 +1564,7 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     // first cell edge: ~sqrt(k + 1) point spacings of a surface patch whose area is the product of the two largest
     // robust extents; queries that cannot be decided inside their 27 cells (fewer than k + 1 points within h: thick or
     // sparse parts of the cloud, patch corners, isolated points) are retried on a grid with twice the edge; what is left
-    // after KNN_LEVELS grids (or once only a handful remain) is searched against all points by the whole chip
-    double e[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
-    std::sort(e, e + 3);
-    const double area = std::max(e[2] * e[1], 1e-12), spacing = sqrt(area / (0.98 * 0.98 * 0.98 * (double)std::max<int64_t>(nv, 1)));
-    float h = (float)(spacing * sqrt((double)(mean_k + 1)));
-    if (!(h > 0.0f) || !std::isfinite(h)) h = 1.0f;
-    // the grid box: the robust extent grown by a few cells, inside the exact bounding box (far outliers are clamped
-    // into the border cells instead of blowing up the cell count)
-    float glo[3], ghi[3];
-    for (int a = 0; a < 3; a++) {
-        glo[a] = std::max(flo[a], lo[a] - 4.0f * h);
-        ghi[a] = std::min(fhi[a], hi[a] + 4.0f * h);
-        if (!(ghi[a] >= glo[a])) ghi[a] = glo[a];
-    }
+    // after KNN_LEVELS grids (or once only a handful remain) is searched against all points by the whole chip.
     // One cell edge does not fit a whole cloud: a perspective depth map is 25 times denser (per unit of space) in its near
     // part than in its far part (C2: 1.25 vs 6 units between neighbours), and the surface estimate above is off for a deep
     // or thick one.  The search therefore runs over a ladder of grids from fine to coarse, h doubling: a query is decided
@@ -1472,7 +1574,30 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     // (a single level at the surface estimate ran the near part's queries over ~50 000 candidates each: 390 ms).
     // The ladder starts one octave below the surface estimate (on C2 two octaves below decides 10 % of the queries for
     // a quarter of the search time, three octaves below nothing).
-    h *= 0.5f;
+    // All of it only when a grid is built at all: the cloud of a matched pair is searched on its pixel lattice and the sample, its
+    // round trip and its quantiles stay out of the call.
+    float h = 0.0f, h_floor = 0.0f, glo[3] = {0.0f, 0.0f, 0.0f}, ghi[3] = {0.0f, 0.0f, 0.0f};
+    bool have_grid_box = false;
+    auto grid_box = [&]() -> bool {
+        if (have_grid_box) return true;
+        if (!sample_extent(A, d_xyz, n, st, lo, hi)) return false;
+        double e[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
+        std::sort(e, e + 3);
+        const double area = std::max(e[2] * e[1], 1e-12), spacing = sqrt(area / (0.98 * 0.98 * 0.98 * (double)std::max<int64_t>(nv, 1)));
+        h = (float)(spacing * sqrt((double)(mean_k + 1)));
+        if (!(h > 0.0f) || !std::isfinite(h)) h = 1.0f;
+        // the grid box: the robust extent grown by a few cells, inside the exact bounding box (far outliers are clamped
+        // into the border cells instead of blowing up the cell count)
+        for (int a = 0; a < 3; a++) {
+            glo[a] = std::max(flo[a], lo[a] - 4.0f * h);
+            ghi[a] = std::min(fhi[a], hi[a] + 4.0f * h);
+            if (!(ghi[a] >= glo[a])) ghi[a] = glo[a];
+        }
+        h *= 0.5f;
+        if (h_floor > h) h = h_floor;
+        have_grid_box = true;
+        return true;
+    };
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const int KNN_LEVELS = 12;
     if (hipMemsetAsync(d_dist, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return RSM_E_HIP; // non-finite points: distance 0, as PCL
@@ -1481,12 +1606,18 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     int s = RSM_OK;
     const size_t mark = A->off;
     bool prepassed = false, wave_done = false;
+    float4 *lat_keep = nullptr;          // the lattice copy, kept for the normals while no grid level has taken its arena space
+    const unsigned int *cell_keep = nullptr;
+    size_t mark_lat = mark;
     const float4 *lat_all = nullptr;
     int64_t lat_cells = 0;
     if (pre && mean_k <= 128 && nv > 0) { // the pixel-window pass: what it cannot decide becomes the ladder's first query list
         float4 *lat = A->get<float4>(cloud_lattice_bytes(pre->XL, pre->XR, pre->YL, pre->YR) / sizeof(float4));
         unsigned int *cell_of = A->get<unsigned int>((size_t)n);
         if (!lat || !cell_of) return RSM_E_NOMEM;
+        lat_keep = lat;
+        cell_keep = cell_of;
+        mark_lat = A->off;
         hipLaunchKernelGGL(k_finite_flags, dim3(blocks), dim3(256), 0, st, d_xyz, n, d_flag, d_redo2);
         launch_cloud_lattice(pre->flags, pre->row_offset, pre->W, pre->XL, pre->XR, pre->YL, pre->YR, pre->xyz64, n, lat, cell_of, st);
         // which window?  pre->radius > 0: the caller's; 0: the smallest of 7 / 12 / 16 pixels that decides >= 85 % of a sparse
@@ -1512,8 +1643,8 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
                     float sum_lim;
                     memcpy(&sum_lim, &h_pc[2], sizeof sum_lim);
                     // (1.25 x the mean bound: a level at the bound itself would decide almost none of them)
-                    const float h_floor = 1.25f * sum_lim / (float)h_pc[0];
-                    if (std::isfinite(h_floor) && h_floor > h) h = h_floor;
+                    const float hf = 1.25f * sum_lim / (float)h_pc[0];
+                    if (std::isfinite(hf)) h_floor = hf;
                 }
             }
         }
@@ -1583,8 +1714,10 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
     // after the wave passes a handful is left at most (isolated points): straight to the whole-chip search, over the lattice copy
     // as the point array (its empty pixels are NaN: never below any threshold) -- no grid level, no sort
     const bool skip_ladder = wave_done && nq <= 48 && lat_all != nullptr;
+    if (nq > 0 && !skip_ladder && !grid_box()) return RSM_E_HIP;
     for (int level = 0; level < KNN_LEVELS && nq > 0 && !skip_ladder; level++, h *= 2.0f) {
         A->off = mark; // the previous level's grid is done (its kernels are ordered before this level's on the stream)
+        lat_keep = nullptr;
         s = build_grid(A, d_xyz, n, nv, h, glo, ghi, st, G);
         if (s != RSM_OK) return s;
         if (level == 0 && !prepassed) queries = G.vals; // every point, in grid order (coherent waves)
@@ -1630,7 +1763,7 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
             hipLaunchKernelGGL(k_xq_finish, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_xq, list, cnt, mean_k, (int)nv, d_dist);
         }
     }
-    A->off = mark;
+    A->off = lat_keep ? mark_lat : mark;
     // mean / stddev exactly as PCL forms them (a sequential loop over the per-point distances in point order): on the
     // device when no addition can round (k_dist_stats), else on the host
     double sum = 0.0, sq_sum = 0.0;
@@ -1639,6 +1772,13 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
         *h_stats = init;
         if (hipMemcpyAsync(d_stats, h_stats, sizeof init, hipMemcpyHostToDevice, st) != hipSuccess) return RSM_E_HIP;
         hipLaunchKernelGGL(k_dist_stats, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st, d_dist, n, d_stats);
+        h_cnt[3] = 1 << 20;
+        if (lat_keep && d_normals) { // the widest window a normal's radius search needs on the lattice (read back with the statistics)
+            if (hipMemsetAsync(d_cnt + 3, 0, sizeof(int), st) != hipSuccess) return RSM_E_HIP;
+            hipLaunchKernelGGL(k_normal_need, dim3(blocks), dim3(256), 0, st, lat_keep, cell_keep, n, win_geom(pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T),
+                               normal_radius, d_cnt + 3);
+            if (hipMemcpyAsync(h_cnt + 3, d_cnt + 3, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return RSM_E_HIP;
+        }
         if (hipMemcpyAsync(h_stats, d_stats, sizeof init, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return RSM_E_HIP;
         auto exact = [](double total, int q) { // every partial sum is a multiple of 2^q below 2^(q + 53)
@@ -1680,8 +1820,25 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
         return RSM_E_HIP;
     const int64_t m = (int64_t)h_last[0] + h_last[1];
     *n_kept = m;
+    A->off = lat_keep ? mark_lat : mark;
+    if (m == 0 || !d_normals) {
+        A->off = mark;
+        return RSM_OK;
+    }
+    // normals of the filtered cloud.  On the lattice copy when it is still there and a window of at most NRM_WMAX pixels holds every
+    // normal's neighbourhood (k_normal_need: a property of the rig -- the search radius in pixel spacings at the nearest point)
+    const int NRM_WMAX = 8;
+    if (lat_keep && h_cnt[3] <= NRM_WMAX) {
+        const WinGeom g = win_geom(pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T);
+        hipLaunchKernelGGL(k_lattice_drop, dim3(blocks), dim3(256), 0, st, d_flag, cell_keep, n, lat_keep);
+        if (hipMemsetD32Async((hipDeviceptr_t)d_normals, 0x7fc00000, (size_t)4 * m, st) != hipSuccess) return RSM_E_HIP;
+        hipLaunchKernelGGL(k_normals_lattice, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, lat_keep, cell_keep, d_kept_index, m, g, normal_radius,
+                           (float)(normal_radius * normal_radius), cam_center[0], cam_center[1], cam_center[2], d_normals);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return RSM_E_HIP;
+        A->off = mark;
+        return RSM_OK;
+    }
     A->off = mark;
-    if (m == 0 || !d_normals) return RSM_OK;
     // normals of the filtered cloud: grid with cell edge = search radius; the non-finite points (all kept: distance 0)
     // sort behind the finite ones and keep the NaN normal the buffer is filled with
     FilterGridDev G2;
