@@ -50,7 +50,7 @@ def main():
                     help="1 (default, N = 1): two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one pair in a child process give "
                          "roofline.traffic; 0: quote profiles/pmc_traffic.json while it still describes this kernel source")
     ap.add_argument("--adapter-inflight", type=int, default=0,
-                    help="pairs in flight inside the C++ adapter's MatchAll (0: two more than --inflight: a slot's pair is uploading or downloading part of the time; measured on C2 with 18 pairs: 3 slots 250, 4 271, 5 276, 6 281 Mdisp/s)")
+                    help="pairs in flight inside the C++ adapter's MatchAll (0: three more than --inflight: a slot's pair is uploading, being filtered or downloading part of the time; measured on C2 with 36 pairs, plain / with the filter inside: 5 slots 302 / 210, 6 303 / 219, 7 301 / 210 Mdisp/s)")
     ap.add_argument("--adapter-pairs", type=int, default=18,
                     help="pairs matched through the compiled C++ adapter (tests/cpp/adapter_bench.cpp) for value_adapter_pcie_inclusive; 0: skip")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
@@ -515,7 +515,7 @@ def main():
             # the drop-in as a maintainer integrates it: the compiled C++ adapter's MatchAll (include/rsm_stereo_adapter.hpp),
             # host images in, InsertPoint stream out, PCIe included -- never `value`
             try:
-                ab = adapter_bench(cfgs, args.adapter_pairs, args.adapter_inflight if args.adapter_inflight > 0 else F + 2, int(res.v_top))
+                ab = adapter_bench(cfgs, args.adapter_pairs, args.adapter_inflight if args.adapter_inflight > 0 else F + 3, int(res.v_top))
                 out["adapter"] = ab["records16"]
                 out["value_adapter_pcie_inclusive"] = ab["records16"]["value"]
                 # ... and once the loop's pipeline runs (from the first pair's replay to the last one's: the job's fill left out)

@@ -255,6 +255,11 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          whole-chip search for the handful beyond -- no grid level at all; bits 3 / 4: the 49 x 49 / 81 x 81 pass in
  *                          that wave form too instead of a thread per query (coalesced reads of the lattice rows; on C2's cloud the
  *                          81 x 81 pass gains, 1.4 against 3.9 ms, the 49 x 49 pass does not); default 23, 0 = tile pass + grid ladder only
+ *   "filter_low_priority"  1 (default): rsm_filter_last_cloud runs on a stream of the lowest priority the device offers -- with pairs in
+ *                          flight the dispatcher then hands compute units to the other contexts' matching first (the adapter loop with
+ *                          the filter inside: 36 C2 pairs, 6 in flight, 219 against 215 Mdisp/s; 5 in flight 210 against 196); 0: on the
+ *                          context's own stream.  The environment variable RSM_FILTER_LOW_PRIORITY=0/1 sets the default of contexts
+ *                          created afterwards (for callers that reach the library through the adapter only)
  *   "filter_window"        rsm_filter_last_cloud's pixel-window pass: 1 (default) radius from a sparse probe (remembered by the context:
  *                          probed again on every 8th call, for another k or image size, when it stops deciding 70 % of the queries and
  *                          after any "filter_*" option), 0 off (the generic grid

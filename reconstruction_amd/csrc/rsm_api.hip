@@ -98,6 +98,8 @@ struct rsm_ctx {
     int ordinal = 0;               // n-th context created on its device
     int opt_cu_share = 0;          // > 1: the context's streams are confined to one of that many equal shares of the compute units
     hipEvent_t ev_heavy = nullptr; // end of this context's last bandwidth-bound section (heavy_begin / heavy_end)
+    hipStream_t stream_filter = nullptr; // rsm_filter_last_cloud's stream: the lowest priority the device offers (filter_stream())
+    hipEvent_t ev_filter = nullptr;      // orders the filter behind whatever `stream` still holds
     hipEvent_t ev_heavy2 = nullptr; // ... of its last issue-bound (time-skewed) section: lane 1
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // the two directions of a time-skewed section on two streams (refine_sweeps)
     RfUpd *upd_list2 = nullptr;     // the second direction's update list / counters while the two run as separate launch chains
@@ -119,6 +121,7 @@ struct rsm_ctx {
     FilterArena *filt_arena = nullptr; // the cloud filter's scratch (created on first use, grows with the cloud)
     int opt_filter_list = 23;          // ... and the 24-pixel window a thread each for what the tile pass leaves over
     int filt_memo_radius = 0, filt_memo_k = 0, filt_memo_w = 0, filt_memo_h = 0, filt_memo_uses = 0; // rsm_filter_last_cloud: the last probe's choice
+    int opt_filter_low_priority = 1;   // rsm_filter_last_cloud on a stream of the lowest priority (1) or on the context's own (0)
     int opt_filter_window = 1;         // rsm_filter_last_cloud: the pixel-window k-nearest pass in front of the grid ladder (1: radius from a sparse probe; 0: off; else the radius)
     int64_t filt_tile_left = 0;        // ... queries the tile pass alone left over
     int64_t filt_info[4]{};            // last rsm_filter_last_cloud: window pass used, queries it left to the ladder, points in, points kept
@@ -294,6 +297,7 @@ extern "C" int rsm_create(rsm_ctx **out, int hip_device) {
         delete c;
         return RSM_E_HIP;
     }
+    if (const char *e = getenv("RSM_FILTER_LOW_PRIORITY")) c->opt_filter_low_priority = atoi(e) != 0; // (A/B of the adapter loop, whose contexts take no options)
     for (int k = 0; k < RSM_MAX_LEVELS; k++)
         if (hipEventCreateWithFlags(&c->ev_prep[k], hipEventDisableTiming) != hipSuccess) {
             delete c;
@@ -331,6 +335,8 @@ extern "C" void rsm_destroy(rsm_ctx *c) {
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
     for (int k = 0; k < RSM_MAX_LEVELS; k++) (void)hipEventDestroy(c->ev_prep[k]);
+    if (c->ev_filter) (void)hipEventDestroy(c->ev_filter);
+    if (c->stream_filter) (void)hipStreamDestroy(c->stream_filter);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -511,6 +517,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "heavy_from_sweep")) c->opt_heavy_from_sweep = (int)std::max(1LL, std::min(value, 100000LL));
     else if (!strcmp(name, "heavy_min_px")) c->opt_heavy_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "heavy_lanes")) c->opt_heavy_lanes = (int)std::max(1LL, std::min(value, 2LL));
+    else if (!strcmp(name, "filter_low_priority")) c->opt_filter_low_priority = value != 0;
     else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = (int)std::max(0LL, std::min(value, 2LL));
     else if (!strcmp(name, "no_rowgemm")) c->opt_no_rowgemm = value != 0 ? 1 : 0;
     else if (!strcmp(name, "wide_rows")) c->opt_no_rowgemm = (value >= 0 && value <= 3) ? (int)value : 0;
@@ -1809,6 +1816,26 @@ extern "C" int rsm_filter_cloud(rsm_ctx *c, const float *xyz, int64_t n, const r
     return finish(c, t);
 }
 
+// The stream of the per-pair cloud filter.  With several pairs in flight on a GPU the filter of one pair runs beside the matching of
+// the others, and its large kernels (21 000 workgroups of 75 KB LDS) took the compute units the matchers' dependent launches -- the
+// top level's refine sweeps, the loop's critical path -- were waiting for: 29.5 ms per pair in the adapter's loop for 15.3 ms of
+// matching + 9.5 ms of filter.  On a stream of the lowest priority the dispatcher hands compute units to the matchers first.
+static hipStream_t filter_stream(rsm_ctx *c) {
+    if (!c->opt_filter_low_priority) return c->stream;
+    if (!c->stream_filter) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, least) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_filter, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->stream_filter) (void)hipStreamDestroy(c->stream_filter);
+            c->stream_filter = nullptr;
+            return c->stream;
+        }
+    }
+    if (hipEventRecord(c->ev_filter, c->stream) != hipSuccess || hipStreamWaitEvent(c->stream_filter, c->ev_filter, 0) != hipSuccess) return c->stream;
+    return c->stream_filter;
+}
+
 extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, rsm_point16 *d_points, float *d_normals,
                                      int64_t max_points, int64_t *n_kept, double *stats) {
     if (!c || !n_kept || !filter_params_ok(prm)) return RSM_E_INVALID;
@@ -1862,10 +1889,11 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
     if (use_lat && memo_ok) lat.radius = c->filt_memo_radius;
     const int sb = filter_buffers(c, n, d_normals != nullptr, &dx, &dk, &df, &dn, use_lat ? cloud_lattice_bytes(mg.XL, mg.XR, mg.YL, mg.YR) + (size_t)n * 4 + 8192 : 0);
     if (sb != RSM_OK) return sb;
-    launch_f64_to_f32x3(c->xyz, n, dx, c->stream); // InsertPoint's cast, CCloudOptimization.cpp:61
+    const hipStream_t fs = filter_stream(c);
+    launch_f64_to_f32x3(c->xyz, n, dx, fs); // InsertPoint's cast, CCloudOptimization.cpp:61
     int64_t m = 0;
     const int s = filter_cloud_device(c->filt_arena, dx, n, prm->sor_mean_k, prm->sor_std_mul, prm->normal_radius, prm->cam_center, dk, df, dn, &m, stats,
-                                      c->stream, use_lat ? &lat : nullptr);
+                                      fs, use_lat ? &lat : nullptr);
     if (s != RSM_OK) return set_err(c, s, "cloud filter failed");
     if (use_lat && c->opt_filter_window == 1) {
         if (memo_ok && tile_left >= 0 && (double)tile_left <= 0.3 * (double)n) c->filt_memo_uses++; // still a good choice
@@ -1883,9 +1911,10 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
     c->filt_info[2] = n;
     c->filt_info[3] = m;
     if (m > max_points) return set_err(c, RSM_E_INVALID, "rsm_filter_last_cloud: %lld points survive, capacity %lld", (long long)m, (long long)max_points);
-    if (m > 0 && d_points) launch_pack_filtered16(c->xyz, c->bgr, dk, m, d_points, c->stream);
-    if (m > 0 && d_normals) HIPCHK(c, hipMemcpyAsync(d_normals, dn, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
+    if (m > 0 && d_points) launch_pack_filtered16(c->xyz, c->bgr, dk, m, d_points, fs);
+    if (m > 0 && d_normals) HIPCHK(c, hipMemcpyAsync(d_normals, dn, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice, fs));
     *n_kept = m;
+    if (fs != c->stream) HIPCHK(c, hipStreamSynchronize(fs));
     return finish(c, t);
 }
 
