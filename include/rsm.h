@@ -255,6 +255,9 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          whole-chip search for the handful beyond -- no grid level at all; bits 3 / 4: the 49 x 49 / 81 x 81 pass in
  *                          that wave form too instead of a thread per query (coalesced reads of the lattice rows; on C2's cloud the
  *                          81 x 81 pass gains, 1.4 against 3.9 ms, the 49 x 49 pass does not); default 23, 0 = tile pass + grid ladder only
+ *   "filter_normals_window" rsm_filter_last_cloud: the normals' radius search reads the pixel lattice (the k-nearest pass's copy, the removed
+ *                          points blanked) while no point needs a window wider than this many pixels -- default 8, at most 40; beyond it, or
+ *                          with 0, the filtered cloud is sorted into a grid of radius-cells as for a generic cloud (C2: 0.15 against 1.8 ms)
  *   "filter_low_priority"  1 (default): rsm_filter_last_cloud runs on a stream of the lowest priority the device offers -- with pairs in
  *                          flight the dispatcher then hands compute units to the other contexts' matching first (the adapter loop with
  *                          the filter inside: 36 C2 pairs, 6 in flight, 219 against 215 Mdisp/s; 5 in flight 210 against 196); 0: on the
@@ -408,6 +411,10 @@ int rsm_filter_last_cloud(rsm_ctx *ctx, const rsm_filter_params *params, rsm_poi
  * points kept.  Option "filter_window" (rsm_set_option): 1 = probe (default), 0 = no window pass, 7 / 12 / 16 / 20 / 24 = that
  * radius (A/B; the results are the same bits either way). */
 int rsm_filter_last_info(rsm_ctx *ctx, int64_t info[4]);
+/* ... and its normals: info[0] = the pixel window (radius) their radius search ran over on the cloud's pixel lattice, 0 when it ran on a
+ * grid of radius-cells over the filtered cloud instead; info[1] = the widest window any point needed (the search radius in pixel
+ * spacings at the nearest point: a property of the rig), -1 when the lattice was not available.  Option "filter_normals_window". */
+int rsm_filter_last_normals_info(rsm_ctx *ctx, int64_t info[2]);
 /* The same with HOST output buffers (page-locked ones from rsm_host_alloc arrive at the link's rate): what a pipeline that
  * replaces the first half of CCloudOptimization::filter (CCloudOptimization.cpp:82-121) downloads instead of the raw cloud --
  * the surviving points and their oriented normals (the reference's cloud_normal, :110-121).  h_normals may be NULL. */

@@ -72,7 +72,7 @@ class RectifyOut(C.Structure):
 
 # every symbol include/rsm.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
-    "rsm_create", "rsm_destroy", "rsm_last_error", "rsm_version", "rsm_abi_version", "rsm_device_count", "rsm_filter_last_cloud_host", "rsm_filter_last_info", "rsm_match_pair", "rsm_upload_pair",
+    "rsm_create", "rsm_destroy", "rsm_last_error", "rsm_version", "rsm_abi_version", "rsm_device_count", "rsm_filter_last_cloud_host", "rsm_filter_last_info", "rsm_filter_last_normals_info", "rsm_match_pair", "rsm_upload_pair",
     "rsm_upload_pair_device", "rsm_run_pair", "rsm_download_pair", "rsm_result_device", "rsm_export_cloud_device",
     "rsm_set_option", "rsm_profile_enable", "rsm_profile_stage_count", "rsm_profile_stage_name", "rsm_profile_get",
     "rsm_stage_find_margin", "rsm_stage_pyr_down", "rsm_stage_erode_ellipse", "rsm_stage_initial_match",

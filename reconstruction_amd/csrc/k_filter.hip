@@ -1773,7 +1773,7 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
         if (hipMemcpyAsync(d_stats, h_stats, sizeof init, hipMemcpyHostToDevice, st) != hipSuccess) return RSM_E_HIP;
         hipLaunchKernelGGL(k_dist_stats, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st, d_dist, n, d_stats);
         h_cnt[3] = 1 << 20;
-        if (lat_keep && d_normals) { // the widest window a normal's radius search needs on the lattice (read back with the statistics)
+        if (lat_keep && d_normals && pre->normals_wmax > 0) { // the widest window a normal's radius search needs on the lattice (read back with the statistics)
             if (hipMemsetAsync(d_cnt + 3, 0, sizeof(int), st) != hipSuccess) return RSM_E_HIP;
             hipLaunchKernelGGL(k_normal_need, dim3(blocks), dim3(256), 0, st, lat_keep, cell_keep, n, win_geom(pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T),
                                normal_radius, d_cnt + 3);
@@ -1825,10 +1825,14 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
         A->off = mark;
         return RSM_OK;
     }
-    // normals of the filtered cloud.  On the lattice copy when it is still there and a window of at most NRM_WMAX pixels holds every
+    // normals of the filtered cloud.  On the lattice copy when it is still there and a window of at most pre->normals_wmax pixels holds every
     // normal's neighbourhood (k_normal_need: a property of the rig -- the search radius in pixel spacings at the nearest point)
-    const int NRM_WMAX = 8;
-    if (lat_keep && h_cnt[3] <= NRM_WMAX) {
+    if (pre && pre->normals_out) {
+        pre->normals_out[0] = 0;
+        pre->normals_out[1] = lat_keep ? h_cnt[3] : -1;
+    }
+    if (lat_keep && h_cnt[3] <= pre->normals_wmax) {
+        if (pre->normals_out) pre->normals_out[0] = std::max(h_cnt[3], 1);
         const WinGeom g = win_geom(pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T);
         hipLaunchKernelGGL(k_lattice_drop, dim3(blocks), dim3(256), 0, st, d_flag, cell_keep, n, lat_keep);
         if (hipMemsetD32Async((hipDeviceptr_t)d_normals, 0x7fc00000, (size_t)4 * m, st) != hipSuccess) return RSM_E_HIP;

@@ -171,6 +171,8 @@ struct FilterLattice {
     int list_pass;      // 1: what the tile pass leaves over gets a 24-pixel window a thread each before the grid ladder
     int *undecided_out; // optional: queries the window passes left to the grid ladder
     int *tile_left_out; // optional: queries the tile pass alone left over
+    int normals_wmax;   // the normals' radius search on the lattice copy while no point needs a window wider than this (0: always on a grid of radius-cells)
+    int *normals_out;   // optional, 2 ints: the window the normals used (0: the grid), the widest window a point needed
 };
 size_t cloud_lattice_bytes(int XL, int XR, int YL, int YR);
 int filter_cloud_device(FilterArena *a, const float *d_xyz, int64_t n, int mean_k, double std_mul, double normal_radius,

@@ -157,6 +157,52 @@ def test_pixel_window_pass_gives_the_generic_searchs_results(ctx, case, k):
         assert info["radius"] == 7 and info["undecided"] < 0.15 * res.n_points, info
 
 
+@pytest.mark.parametrize("case", range(len(PAIRS_W)))
+@pytest.mark.parametrize("radius", [2.5, 9.0])
+def test_normals_on_the_pixel_lattice_equal_the_grid_normals(ctx, case, radius):
+    """Round 6: the radius search of the normals runs over a pixel window of the lattice copy (the removed points blanked) whenever
+    the bound that decides the k-nearest windows says a window of at most `filter_normals_window` pixels holds every point within the
+    radius; otherwise, and for a generic cloud, over a grid of radius-cells.  Both orders of summation on the same neighbourhoods:
+    the same NaN pattern (fewer than 3 neighbours), the same normals to 1e-6 (the nine sums are exact in double for the few dozen
+    float products of a neighbourhood, so in practice the same bits) -- for the reference's radius 2.5 (a pixel or two on these rigs,
+    often less than one: no normals at all) and for a wider one (windows up to the lattice's border)."""
+    cfg = synth.config_small(**PAIRS_W[case])
+    res = ctx.match_pair(cfg)
+    cam = (3.0 * case, -2.0, 1.0)
+    out = {}
+    try:
+        for wmax in (0, 8, 40):
+            ctx.set_option("filter_normals_window", wmax)
+            rec, nrm, st = ctx.filter_last_cloud_host(100, 1.0, radius, cam)
+            out[wmax] = (rec.tobytes(), nrm.copy(), ctx.filter_last_info())
+    finally:
+        ctx.set_option("filter_normals_window", 8)
+    info0, info8, info40 = out[0][2], out[8][2], out[40][2]
+    need = info40["normals_need"]
+    print("case %d radius %.1f: widest window a normal needs %d pixels; used %d / %d / %d" % (case, radius, need, info0["normals_window"], info8["normals_window"], info40["normals_window"]))
+    assert info0["normals_window"] == 0 and need >= -1   # (-1: a grid level of the k-nearest search took the lattice copy's arena space)
+    assert info8["normals_window"] == (max(need, 1) if 0 <= need <= 8 else 0) and info40["normals_window"] == (max(need, 1) if 0 <= need <= 40 else 0)
+    for wmax in (8, 40):
+        assert out[wmax][0] == out[0][0]                                   # the same surviving points
+        a, b = out[wmax][1], out[0][1]
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        ok = ~np.isnan(b[:, 0])
+        print("   window limit %d: %d of %d points have a normal, largest difference %.1e" % (wmax, ok.sum(), len(b), np.abs(a[ok] - b[ok]).max() if ok.any() else 0.0))
+        assert not ok.any() or np.abs(a[ok] - b[ok]).max() < 1e-6, (case, wmax)
+
+
+def test_some_test_pair_takes_the_lattice_normals(ctx):
+    """... and the window form is what the default settings run on at least one of the test rigs (the others need wider windows
+    than the default 8 pixels: close-range rigs whose pixel spacing is a small fraction of the radius)."""
+    used = []
+    for case in range(len(PAIRS_W)):
+        ctx.match_pair(synth.config_small(**PAIRS_W[case]))
+        ctx.filter_last_cloud_host(100, 1.0, 2.5, (0.0, 0.0, 0.0))
+        used.append(ctx.filter_last_info()["normals_window"])
+    print("normals windows of the test pairs:", used)
+    assert any(w > 0 for w in used), used
+
+
 def test_pixel_window_pass_against_the_brute_force_oracle(ctx):
     """... and against oracle/cloud_oracle.c (PCL's statistical outlier removal restated by brute force) on a pair small enough
     for O(n^2): the kept set and the statistics' bits."""
