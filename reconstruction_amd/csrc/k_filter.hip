@@ -176,7 +176,9 @@ __device__ __forceinline__ void ranges9(const unsigned long long *__restrict__ k
 // and the wave form of the pixel-window search (k_sor_window_wave: a window of the lattice copy).
 template <class Cand>
 __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2, int want, float *mine, int lane, unsigned int *undecided_slot,
-                                              float &tau_out, double &sum_out, int &less_out) {
+                                              float &tau_out, double &sum_out, int &less_out, int K_pre = -1) {
+    // K_pre >= 0: `mine` already holds the candidates within h2 (the first KNN_CAP of the K_pre there are, in a fixed order): the
+    // workgroup form's four waves have made the first pass together
     const float inf = __uint_as_float(0x7f800000u);
     // Only candidates within h of the query matter (a query is decided here iff k + 1 of them exist): the squared
     // distances are computed in chunks of KNN_B loads per lane in flight, those <= h^2 are compacted into the wave's
@@ -188,8 +190,8 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
         return false;
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int K = 0; // candidates within h so far (uniform)
-    for (int c0 = 0; c0 < M; c0 += 64 * KNN_B) { // uniform
+    int K = K_pre >= 0 ? K_pre : 0; // candidates within h so far (uniform)
+    for (int c0 = 0; c0 < M && K_pre < 0; c0 += 64 * KNN_B) { // uniform
         float v[KNN_B];
 #pragma unroll
         for (int i = 0; i < KNN_B; i++) {
@@ -873,6 +875,81 @@ __global__ __launch_bounds__(256) void k_sor_window_wave(const float4 *__restric
     if (lane == 0) dist[pt] = (float)((sum + (double)(want - less) * (double)sqrtf(tau)) / mean_k);
 }
 
+// Workgroup form: the wave form's query with its first pass -- every candidate of the window, those within the bound kept -- made by
+// four waves together, for the passes that have only hundreds of queries left (C2: 564 at 80 pixels, 15 at 160): a wave per query
+// leaves the chip idle and takes as long as its 400 ... 1 600 chunks of candidates do.  Wave w takes the chunks w, w + 4, ... into
+// its own quarter of the list (a fixed order: the sum's bits do not depend on timing), the quarters are put together and wave 0
+// selects as the wave form does; a quarter that overflows leaves the whole query to wave 0.
+__global__ __launch_bounds__(256) void k_sor_window_wg(const float4 *__restrict__ lat, const unsigned int *__restrict__ cell_of, WinGeom g, int mean_k, int WR,
+                                                        const unsigned int *__restrict__ list, int nq, float *__restrict__ dist, unsigned int *__restrict__ undecided) {
+    __shared__ float s_seg[4][KNN_CAP / 4];
+    __shared__ float s_d2[KNN_CAP];
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qi = blockIdx.x;
+    const unsigned int pt = list[qi];
+    const unsigned int cell = cell_of[pt];
+    const int cy = (int)(cell / (unsigned int)g.gw), cx = (int)(cell - (unsigned int)cy * (unsigned int)g.gw);
+    const float4 P = lat[cell];
+    const double dx = (double)P.x - g.T[0], dy = (double)P.y - g.T[1], dz = (double)P.z - g.T[2];
+    const double F2 = fabs(g.rz[0] * dx + g.rz[1] * dy + g.rz[2] * dz), nP = sqrt(dx * dx + dy * dy + dz * dz);
+    const double iw = F2 / fabs(g.qz);
+    const double LB = F2 * (WR + 1) / (nP / fmax(iw, 1e-300) + (WR + 1));
+    const double coord = fmax(fmax(fabs((double)P.x), fabs((double)P.y)), fabs((double)P.z)) + nP;
+    const double lim = LB * (1.0 - 1e-5) - 4e-7 * coord;
+    const float range = (lim > 0.0) ? (float)(lim * lim * (1.0 - 1e-6)) : 0.0f; // (k_sor_window_wave's bound, the same expressions)
+    if (!(range > 0.0f && isfinite(range))) { // uniform
+        if (threadIdx.x == 0) undecided[qi] = 1u;
+        return;
+    }
+    const float h2 = __uint_as_float(__float_as_uint(range) - 1u);
+    const int x0 = max(cx - WR, 0), x1 = min(cx + WR, g.gw - 1), y0 = max(cy - WR, 0), y1 = min(cy + WR, g.gh - 1);
+    const int ncx = x1 - x0 + 1, M = ncx * (y1 - y0 + 1);
+    const float4 *base = lat + (size_t)y0 * g.gw + x0;
+    const int gw = g.gw;
+    const unsigned int ncx_inv = 0xffffffffu / (unsigned int)ncx + 1u;
+    auto cand = [&](int c) -> float {
+        const int r = ncx > 1 ? (int)__umulhi((unsigned int)c, ncx_inv) : c, col = c - r * ncx;
+        const float4 o = base[(size_t)r * gw + col];
+        return fdist2(P.x, P.y, P.z, o.x, o.y, o.z);
+    };
+    const float inf = __uint_as_float(0x7f800000u);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int Kw = 0;
+    for (int c0 = w * 64 * KNN_B; c0 < M; c0 += 4 * 64 * KNN_B) { // wave-uniform
+        float v[KNN_B];
+#pragma unroll
+        for (int i = 0; i < KNN_B; i++) {
+            const int c = c0 + lane + 64 * i;
+            v[i] = (c < M) ? cand(c) : inf;
+        }
+#pragma unroll
+        for (int i = 0; i < KNN_B; i++) {
+            const bool keep = v[i] <= h2;
+            const unsigned long long mm = __ballot(keep);
+            const int pos = Kw + __popcll(mm & lt);
+            if (keep && pos < KNN_CAP / 4) s_seg[w][pos] = v[i];
+            Kw += __popcll(mm);
+        }
+    }
+    if (lane == 0) s_cnt[w] = Kw;
+    __syncthreads();
+    const int k0 = s_cnt[0], k1 = s_cnt[1], k2 = s_cnt[2], k3 = s_cnt[3];
+    const bool fits = k0 <= KNN_CAP / 4 && k1 <= KNN_CAP / 4 && k2 <= KNN_CAP / 4 && k3 <= KNN_CAP / 4;
+    if (fits) {
+        const int off = w == 0 ? 0 : (w == 1 ? k0 : (w == 2 ? k0 + k1 : k0 + k1 + k2));
+        for (int j = lane; j < Kw; j += 64) s_d2[off + j] = s_seg[w][j];
+    }
+    __syncthreads();
+    if (w != 0) return;
+    float tau;
+    double sum;
+    int less;
+    const int want = mean_k + 1;
+    if (!wave_knn_core(cand, M, h2, want, s_d2, lane, &undecided[qi], tau, sum, less, fits ? k0 + k1 + k2 + k3 : -1)) return;
+    if (lane == 0) dist[pt] = (float)((sum + (double)(want - less) * (double)sqrtf(tau)) / mean_k);
+}
+
 void launch_cloud_lattice(const uint8_t *flags, const int64_t *row_offset, int W, int XL, int XR, int YL, int YR, const double *xyz, int64_t n, float4 *lat,
                           unsigned int *cell_of, hipStream_t st) {
     const int gw = XR - XL + 1 + 2 * WIN_PAD, gh = YR - YL + 1 + 2 * WIN_PAD;
@@ -904,7 +981,10 @@ void launch_sor_window_wave(const float4 *lat, const unsigned int *cell_of, int 
                             int radius, const unsigned int *list, int nq, float *dist, unsigned int *undecided, hipStream_t st) {
     if (nq <= 0) return;
     const WinGeom g = win_geom(XL, XR, YL, YR, qz, R, T);
-    hipLaunchKernelGGL(k_sor_window_wave, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, lat, cell_of, g, mean_k, radius, list, nq, dist, undecided);
+    if (nq <= 2048) // (few enough to leave most of the chip idle at a wave each: four waves per query)
+        hipLaunchKernelGGL(k_sor_window_wg, dim3((unsigned)nq), dim3(256), 0, st, lat, cell_of, g, mean_k, radius, list, nq, dist, undecided);
+    else
+        hipLaunchKernelGGL(k_sor_window_wave, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, lat, cell_of, g, mean_k, radius, list, nq, dist, undecided);
 }
 size_t cloud_lattice_bytes(int XL, int XR, int YL, int YR) {
     return sizeof(float4) * (size_t)(XR - XL + 1 + 2 * WIN_PAD) * (size_t)(YR - YL + 1 + 2 * WIN_PAD);
