@@ -318,8 +318,9 @@ class Context:
         """What the last filter_last_cloud[_host] did: whether the pixel-window pass ran, how many queries it left to the grid search."""
         v = (C.c_int64 * 4)()
         self._chk(self._lib.rsm_filter_last_info(self._h, v))
-        w = (C.c_int64 * 2)()
-        self._chk(self._lib.rsm_filter_last_normals_info(self._h, w))
+        w = (C.c_int64 * 2)(0, -1)
+        if hasattr(self._lib, "rsm_filter_last_normals_info"):   # (absent from the older libraries the A/B scripts load)
+            self._chk(self._lib.rsm_filter_last_normals_info(self._h, w))
         return dict(window=bool(v[0]), radius=int(v[0]), undecided=int(v[1]), points=int(v[2]), kept=int(v[3]), normals_window=int(w[0]), normals_need=int(w[1]))
 
     def filter_last_cloud_host(self, mean_k=100, std_mul=1.0, normal_radius=2.5, cam_center=(0.0, 0.0, 0.0), want_normals=True):
