@@ -174,11 +174,12 @@ __device__ __forceinline__ void ranges9(const unsigned long long *__restrict__ k
 // smallest among those <= h2 and the exact double sum of the square roots below it.  Returns false -- nothing written but
 // `undecided` -- when fewer than `want` candidates lie within h2.  Shared by the grid search (k_sor_knn: the 27 cells of a query)
 // and the wave form of the pixel-window search (k_sor_window_wave: a window of the lattice copy).
-template <class Cand>
+template <int C_ = KNN_C, class Cand>
 __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2, int want, float *mine, int lane, unsigned int *undecided_slot,
                                               float &tau_out, double &sum_out, int &less_out, int K_pre = -1) {
-    // K_pre >= 0: `mine` already holds the candidates within h2 (the first KNN_CAP of the K_pre there are, in a fixed order): the
+    // K_pre >= 0: `mine` already holds the candidates within h2 (the first CAP_ of the K_pre there are, in a fixed order): the
     // workgroup form's four waves have made the first pass together
+    constexpr int CAP_ = 64 * C_; // the list's capacity: C_ registers per lane in the selection
     const float inf = __uint_as_float(0x7f800000u);
     // Only candidates within h of the query matter (a query is decided here iff k + 1 of them exist): the squared
     // distances are computed in chunks of KNN_B loads per lane in flight, those <= h^2 are compacted into the wave's
@@ -203,7 +204,7 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
             const bool keep = v[i] <= h2;
             const unsigned long long mm = __ballot(keep);
             const int pos = K + __popcll(mm & lt);
-            if (keep && pos < KNN_CAP) mine[pos] = v[i];
+            if (keep && pos < CAP_) mine[pos] = v[i];
             K += __popcll(mm);
         }
     }
@@ -211,19 +212,19 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
     // appends per microsecond -- 62 ms for a level that decides nothing)
     if (lane == 0) *undecided_slot = K < want;
     if (K < want) return false; // not decidable among these candidates
-    if (K > KNN_CAP && h2 > 0.0f) {
+    if (K > CAP_ && h2 > 0.0f) {
         // More candidates within h than the list holds (a wide window over a dense part, a too-coarse grid level): two more passes
         // narrow them down instead of a 30-step bisection that re-reads them all in every step -- a histogram of the squared
-        // distances over KNN_CAP equal bins of [0, h2] (the list's LDS), the bin b* holding rank `want`, then the list again with
+        // distances over CAP_ equal bins of [0, h2] (the list's LDS), the bin b* holding rank `want`, then the list again with
         // the candidates of bins <= b* only (bin() is monotone: they are exactly the values up to some threshold, the rank's among
         // them).  Falls through to the bisection only if even that is too many (thousands of equal distances).
         int *hist = (int *)mine;
-        const float inv_w = (float)KNN_CAP / h2;
-        auto bin_of = [&](float v) { return min((int)(v * inv_w), KNN_CAP - 1); };
+        const float inv_w = (float)CAP_ / h2;
+        auto bin_of = [&](float v) { return min((int)(v * inv_w), CAP_ - 1); };
         if (isfinite(inv_w) && inv_w > 0.0f) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < KNN_C; i++) hist[lane + 64 * i] = 0;
+            for (int i = 0; i < C_; i++) hist[lane + 64 * i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (int c0 = 0; c0 < M; c0 += 64 * KNN_B) { // uniform
@@ -242,7 +243,7 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
             // lane l owns bins [32 l, 32 l + 32): its total, the wave's exclusive prefix, then the bin inside the owning lane
             int mine_sum = 0;
 #pragma unroll
-            for (int i = 0; i < KNN_C; i++) mine_sum += hist[lane * KNN_C + i];
+            for (int i = 0; i < C_; i++) mine_sum += hist[lane * C_ + i];
             int incl = mine_sum;
             for (int o = 1; o < 64; o <<= 1) {
                 const int t = __shfl_up(incl, o);
@@ -250,17 +251,17 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
             }
             const unsigned long long has = __ballot(incl >= want);
             const int owner = __builtin_ctzll(has); // (K >= want: some lane reaches it)
-            int run = __shfl(incl - mine_sum, owner), bstar = owner * KNN_C, upto = 0;
-            for (int i = 0; i < KNN_C; i++) { // uniform: every lane reads the owner's bins
-                const int hcount = hist[owner * KNN_C + i];
+            int run = __shfl(incl - mine_sum, owner), bstar = owner * C_, upto = 0;
+            for (int i = 0; i < C_; i++) { // uniform: every lane reads the owner's bins
+                const int hcount = hist[owner * C_ + i];
                 run += hcount;
                 if (run >= want) {
-                    bstar = owner * KNN_C + i;
+                    bstar = owner * C_ + i;
                     upto = run;
                     break;
                 }
             }
-            if (upto >= want && upto <= KNN_CAP) {
+            if (upto >= want && upto <= CAP_) {
                 __builtin_amdgcn_wave_barrier();
                 K = 0;
                 for (int c0 = 0; c0 < M; c0 += 64 * KNN_B) { // uniform
@@ -275,30 +276,30 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
                         const bool keep = v[i] <= h2 && bin_of(v[i]) <= bstar;
                         const unsigned long long mm = __ballot(keep);
                         const int pos = K + __popcll(mm & lt);
-                        if (keep && pos < KNN_CAP) mine[pos] = v[i];
+                        if (keep && pos < CAP_) mine[pos] = v[i];
                         K += __popcll(mm);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             } else {
-                K = KNN_CAP + 1; // (the list's LDS holds the histogram now: the bisection below reads the candidates themselves)
+                K = CAP_ + 1; // (the list's LDS holds the histogram now: the bisection below reads the candidates themselves)
             }
         }
     }
     float tau;
     double sum = 0.0;
     int less = 0;
-    if (K <= KNN_CAP) {
+    if (K <= CAP_) {
         __builtin_amdgcn_wave_barrier();
-        float d2[KNN_C];
+        float d2[C_];
         const int nreg = (K + 63) >> 6; // wave-uniform
 #pragma unroll
-        for (int i = 0; i < KNN_C; i++) {
+        for (int i = 0; i < C_; i++) {
             d2[i] = inf;
             if (i < nreg && lane + 64 * i < K) d2[i] = mine[lane + 64 * i];
         }
 #pragma unroll
-        for (int i = 0; i < KNN_C; i++) asm volatile("" : "+v"(d2[i])); // materialise: the values live in registers from here on (the fences AFTER
+        for (int i = 0; i < C_; i++) asm volatile("" : "+v"(d2[i])); // materialise: the values live in registers from here on (the fences AFTER
                                                                         // the last read: one right behind each read makes it a round trip of its own)
         auto count4 = [&](float t, int i0) {
             int cnt = 0;
@@ -309,7 +310,7 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
         auto count_le = [&](float t) { // registers past nreg hold +inf; whole groups of 4 are skipped (uniform)
             int cnt = count4(t, 0);
 #pragma unroll
-            for (int g4 = 1; g4 < KNN_C / 4; g4++)
+            for (int g4 = 1; g4 < C_ / 4; g4++)
                 if (nreg > 4 * g4) cnt += count4(t, 4 * g4);
             return cnt;
         };
@@ -325,7 +326,7 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
                 const float fm = __uint_as_float(mid);
                 float m = 0.0f;
 #pragma unroll
-                for (int i = 0; i < KNN_C; i++)
+                for (int i = 0; i < C_; i++)
                     if (i < nreg && d2[i] <= fm) m = fmaxf(m, d2[i]);
                 for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
                 lo = hi = __float_as_uint(m);
@@ -336,12 +337,12 @@ __device__ __forceinline__ bool wave_knn_core(const Cand &cand, int M, float h2,
         }
         tau = __uint_as_float(lo);
 #pragma unroll
-        for (int i = 0; i < KNN_C; i++)
+        for (int i = 0; i < C_; i++)
             if (i < nreg && d2[i] < tau) {
                 sum += (double)sqrtf(d2[i]);
                 less++;
             }
-    } else { // more than KNN_CAP points within h (a far too coarse first level): bisection straight on the candidates
+    } else { // more than CAP_ points within h (a far too coarse first level): bisection straight on the candidates
         auto count_le = [&](float t) {
             int cnt = 0;
             for (int c0 = 0; c0 < M; c0 += 64) { // uniform trip count
@@ -882,8 +883,10 @@ __global__ __launch_bounds__(256) void k_sor_window_wave(const float4 *__restric
 // selects as the wave form does; a quarter that overflows leaves the whole query to wave 0.
 __global__ __launch_bounds__(256) void k_sor_window_wg(const float4 *__restrict__ lat, const unsigned int *__restrict__ cell_of, WinGeom g, int mean_k, int WR,
                                                         const unsigned int *__restrict__ list, int nq, float *__restrict__ dist, unsigned int *__restrict__ undecided) {
-    __shared__ float s_seg[4][KNN_CAP / 4];
-    __shared__ float s_d2[KNN_CAP];
+    constexpr int WG_C = 64, WG_CAP = 64 * WG_C; // (twice the wave form's list: these few queries' windows hold thousands of candidates within the
+                                                 // bound, and one pass over them by four waves beats three by one)
+    __shared__ float s_seg[4][WG_CAP / 4];
+    __shared__ float s_d2[WG_CAP];
     __shared__ int s_cnt[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int qi = blockIdx.x;
@@ -928,14 +931,14 @@ __global__ __launch_bounds__(256) void k_sor_window_wg(const float4 *__restrict_
             const bool keep = v[i] <= h2;
             const unsigned long long mm = __ballot(keep);
             const int pos = Kw + __popcll(mm & lt);
-            if (keep && pos < KNN_CAP / 4) s_seg[w][pos] = v[i];
+            if (keep && pos < WG_CAP / 4) s_seg[w][pos] = v[i];
             Kw += __popcll(mm);
         }
     }
     if (lane == 0) s_cnt[w] = Kw;
     __syncthreads();
     const int k0 = s_cnt[0], k1 = s_cnt[1], k2 = s_cnt[2], k3 = s_cnt[3];
-    const bool fits = k0 <= KNN_CAP / 4 && k1 <= KNN_CAP / 4 && k2 <= KNN_CAP / 4 && k3 <= KNN_CAP / 4;
+    const bool fits = k0 <= WG_CAP / 4 && k1 <= WG_CAP / 4 && k2 <= WG_CAP / 4 && k3 <= WG_CAP / 4;
     if (fits) {
         const int off = w == 0 ? 0 : (w == 1 ? k0 : (w == 2 ? k0 + k1 : k0 + k1 + k2));
         for (int j = lane; j < Kw; j += 64) s_d2[off + j] = s_seg[w][j];
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(256) void k_sor_window_wg(const float4 *__restrict_
     double sum;
     int less;
     const int want = mean_k + 1;
-    if (!wave_knn_core(cand, M, h2, want, s_d2, lane, &undecided[qi], tau, sum, less, fits ? k0 + k1 + k2 + k3 : -1)) return;
+    if (!wave_knn_core<WG_C>(cand, M, h2, want, s_d2, lane, &undecided[qi], tau, sum, less, fits ? k0 + k1 + k2 + k3 : -1)) return;
     if (lane == 0) dist[pt] = (float)((sum + (double)(want - less) * (double)sqrtf(tau)) / mean_k);
 }
 
