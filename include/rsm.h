@@ -255,6 +255,8 @@ int rsm_gather_plan(int rank, int world, int root, int n_local, const int *pair_
  *                          whole-chip search for the handful beyond -- no grid level at all; bits 3 / 4: the 49 x 49 / 81 x 81 pass in
  *                          that wave form too instead of a thread per query (coalesced reads of the lattice rows; on C2's cloud the
  *                          81 x 81 pass gains, 1.4 against 3.9 ms, the 49 x 49 pass does not); default 23, 0 = tile pass + grid ladder only
+ *   "filter_wg_max"        ... the wave passes run four waves per query (the first pass over the window shared, a 4 096-entry selection list)
+ *                          while at most this many queries are left: default 2048; 0 = always a wave per query (A/B; the same bits)
  *   "filter_normals_window" rsm_filter_last_cloud: the normals' radius search reads the pixel lattice (the k-nearest pass's copy, the removed
  *                          points blanked) while no point needs a window wider than this many pixels -- default 8, at most 40; beyond it, or
  *                          with 0, the filtered cloud is sorted into a grid of radius-cells as for a generic cloud (C2: 0.15 against 1.8 ms)

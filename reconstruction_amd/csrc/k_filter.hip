@@ -981,10 +981,10 @@ void launch_sor_window_list(const float4 *lat, const unsigned int *cell_of, int 
 }
 // the wave form over nq listed queries at any radius: dist (per point) / undecided (per list entry)
 void launch_sor_window_wave(const float4 *lat, const unsigned int *cell_of, int XL, int XR, int YL, int YR, double qz, const double *R, const double *T, int mean_k,
-                            int radius, const unsigned int *list, int nq, float *dist, unsigned int *undecided, hipStream_t st) {
+                            int radius, const unsigned int *list, int nq, float *dist, unsigned int *undecided, hipStream_t st, int wg_max = 2048) {
     if (nq <= 0) return;
     const WinGeom g = win_geom(XL, XR, YL, YR, qz, R, T);
-    if (nq <= 2048) // (few enough to leave most of the chip idle at a wave each: four waves per query)
+    if (nq <= wg_max) // (few enough to leave most of the chip idle at a wave each: four waves per query)
         hipLaunchKernelGGL(k_sor_window_wg, dim3((unsigned)nq), dim3(256), 0, st, lat, cell_of, g, mean_k, radius, list, nq, dist, undecided);
     else
         hipLaunchKernelGGL(k_sor_window_wave, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, lat, cell_of, g, mean_k, radius, list, nq, dist, undecided);
@@ -1759,7 +1759,7 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
             for (int pass = 0; pass < 2 && nq > 0; pass++) {
                 if (radii[pass] <= last || !((pre->list_pass >> pass) & 1)) continue;
                 if ((pre->list_pass >> (3 + pass)) & 1) // (A/B: the wave form at this radius instead of the thread form)
-                    launch_sor_window_wave(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, radii[pass], cur, nq, d_dist, d_flag, st);
+                    launch_sor_window_wave(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, radii[pass], cur, nq, d_dist, d_flag, st, pre->wg_max);
                 else
                     launch_sor_window_list(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, radii[pass], cur, nq, d_dist, d_flag, st);
                 if (rocprim::exclusive_scan(tp, tb, d_flag, d_pos, 0u, (size_t)nq, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
@@ -1776,7 +1776,7 @@ int filter_cloud_device(FilterArena *A, const float *d_xyz, int64_t n, int mean_
             if ((pre->list_pass & 4) && last >= 24) {
                 const int span = std::max(pre->XR - pre->XL, pre->YR - pre->YL) + 1;
                 for (int wr = std::max(80, 2 * last); nq > 0 && nq <= 65536; wr *= 2) {
-                    launch_sor_window_wave(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, wr, cur, nq, d_dist, d_flag, st);
+                    launch_sor_window_wave(lat, cell_of, pre->XL, pre->XR, pre->YL, pre->YR, pre->qz, pre->R, pre->T, mean_k, wr, cur, nq, d_dist, d_flag, st, pre->wg_max);
                     if (rocprim::exclusive_scan(tp, tb, d_flag, d_pos, 0u, (size_t)nq, rocprim::plus<unsigned int>(), st) != hipSuccess) return RSM_E_HIP;
                     hipLaunchKernelGGL(k_compact_list, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, cur, d_flag, d_pos, nq, oth, d_cnt);
                     if (hipMemcpyAsync(h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSM_E_HIP;

@@ -119,6 +119,7 @@ struct rsm_ctx {
     rsm_point16 *pack16 = nullptr; // the cloud as 16-byte records / the filter's output, staged for a host download (on first use)
     float *pack_nrm = nullptr;     // ... and the filter's normals
     FilterArena *filt_arena = nullptr; // the cloud filter's scratch (created on first use, grows with the cloud)
+    int opt_filter_wg_max = 2048;      // rsm_filter_last_cloud: the wave passes' workgroup form while at most this many queries are left (0: never)
     int opt_filter_normals_window = 8; // rsm_filter_last_cloud: the normals' radius search on the pixel lattice while no point needs a wider window than this (0: grid)
     int filt_normals[2]{};             // last rsm_filter_last_cloud: the window the normals used (0: the grid), the widest a point needed (-1: not asked)
     int opt_filter_list = 23;          // ... and the 24-pixel window a thread each for what the tile pass leaves over
@@ -519,6 +520,7 @@ extern "C" int rsm_set_option(rsm_ctx *c, const char *name, long long value) {
     else if (!strcmp(name, "heavy_from_sweep")) c->opt_heavy_from_sweep = (int)std::max(1LL, std::min(value, 100000LL));
     else if (!strcmp(name, "heavy_min_px")) c->opt_heavy_min_px = (int)std::max(0LL, std::min(value, 2000000000LL));
     else if (!strcmp(name, "heavy_lanes")) c->opt_heavy_lanes = (int)std::max(1LL, std::min(value, 2LL));
+    else if (!strcmp(name, "filter_wg_max")) c->opt_filter_wg_max = (int)std::max(0LL, std::min(value, 1LL << 30));
     else if (!strcmp(name, "filter_normals_window")) c->opt_filter_normals_window = (int)std::max(0LL, std::min(value, 40LL));
     else if (!strcmp(name, "filter_low_priority")) c->opt_filter_low_priority = value != 0;
     else if (!strcmp(name, "heavy_exclusive")) c->opt_heavy_exclusive = (int)std::max(0LL, std::min(value, 2LL));
@@ -1881,6 +1883,7 @@ extern "C" int rsm_filter_last_cloud(rsm_ctx *c, const rsm_filter_params *prm, r
     lat.undecided_out = &left;
     lat.tile_left_out = &tile_left;
     lat.list_pass = c->opt_filter_list;
+    lat.wg_max = c->opt_filter_wg_max;
     lat.normals_wmax = std::min(c->opt_filter_normals_window, 40);
     c->filt_normals[0] = 0, c->filt_normals[1] = -1;
     lat.normals_out = c->filt_normals;

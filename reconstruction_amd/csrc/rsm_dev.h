@@ -171,6 +171,7 @@ struct FilterLattice {
     int list_pass;      // 1: what the tile pass leaves over gets a 24-pixel window a thread each before the grid ladder
     int *undecided_out; // optional: queries the window passes left to the grid ladder
     int *tile_left_out; // optional: queries the tile pass alone left over
+    int wg_max;         // the wave passes take four waves per query (k_sor_window_wg) while at most this many queries are left (default 2048)
     int normals_wmax;   // the normals' radius search on the lattice copy while no point needs a window wider than this (0: always on a grid of radius-cells)
     int *normals_out;   // optional, 2 ints: the window the normals used (0: the grid), the widest window a point needed
 };

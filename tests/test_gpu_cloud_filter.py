@@ -191,6 +191,26 @@ def test_normals_on_the_pixel_lattice_equal_the_grid_normals(ctx, case, radius):
         assert not ok.any() or np.abs(a[ok] - b[ok]).max() < 1e-6, (case, wmax)
 
 
+@pytest.mark.parametrize("case", range(len(PAIRS_W)))
+def test_wave_and_workgroup_forms_of_the_wide_passes_agree(ctx, case):
+    """The passes behind the tile and list passes take a wave per listed query (k_sor_window_wave) or, once few queries are left, four
+    waves per query with a longer selection list (k_sor_window_wg, round 6): never (`filter_wg_max` 0), by the default rule, always --
+    with the list passes on, off, and in the wave form themselves (so that thousands of queries reach either form): the same bits."""
+    ctx.match_pair(synth.config_small(**PAIRS_W[case]))
+    cam = (1.0, 2.0 * case, -1.0)
+    want, _ = _filter_sig(ctx, 100, cam, 0)
+    try:
+        for fl in (23, 4, 28, 31):
+            ctx.set_option("filter_list", fl)
+            for wg_max in (0, 2048, 1 << 30):
+                ctx.set_option("filter_wg_max", wg_max)
+                got, info = _filter_sig(ctx, 100, cam, 12)
+                assert got == want, (case, fl, wg_max)
+    finally:
+        ctx.set_option("filter_list", 23)
+        ctx.set_option("filter_wg_max", 2048)
+
+
 def test_some_test_pair_takes_the_lattice_normals(ctx):
     """... and the window form is what the default settings run on at least one of the test rigs (the others need wider windows
     than the default 8 pixels: close-range rigs whose pixel spacing is a small fraction of the radius)."""
