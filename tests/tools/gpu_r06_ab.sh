@@ -4,7 +4,7 @@
 reps=$1; shift; export RSM_AB_OLD_LIBRARY=1
 cp reconstruction_amd/librsm_mi355.so /tmp/keep.so
 for r in $(seq $reps); do for n in "$@"; do
-  cp tests/_ab/$n.so reconstruction_amd/librsm_mi355.so
+  [ -f tests/_ab/$n.so ] && cp tests/_ab/$n.so reconstruction_amd/librsm_mi355.so || cp /tmp/keep.so reconstruction_amd/librsm_mi355.so   # (a name without a file: the tree's library)
   python -u bench.py --no-cpu-baseline --measure-traffic ${PMC:-0} --adapter-pairs 0 --steps 8 --warmup 2 $BENCH_OPTS 2>/tmp/err_$n.log | python -c "
 import json,sys
 try:

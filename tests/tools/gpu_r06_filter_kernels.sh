@@ -4,7 +4,7 @@ export TMPDIR=/tmp OMP_NUM_THREADS=16 RSM_AB_OLD_LIBRARY=1
 root=$PWD
 cp reconstruction_amd/librsm_mi355.so /tmp/keep.so
 for n in "$@"; do
-  cp tests/_ab/$n.so reconstruction_amd/librsm_mi355.so
+  [ -f tests/_ab/$n.so ] && cp tests/_ab/$n.so reconstruction_amd/librsm_mi355.so || cp /tmp/keep.so reconstruction_amd/librsm_mi355.so   # (a name without a file: the tree's library)
   rm -rf /tmp/fs; cd /tmp
   rocprofv3 --kernel-trace --stats -d /tmp/fs -o fs -- python $root/tests/tools/gpu_filter_run.py 6 > /tmp/fs.log 2>&1
   cd $root

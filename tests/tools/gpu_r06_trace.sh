@@ -5,7 +5,7 @@ export TMPDIR=/tmp RSM_AB_OLD_LIBRARY=1
 root=$PWD
 cp reconstruction_amd/librsm_mi355.so /tmp/keep.so
 for n in "$@"; do
-  cp tests/_ab/$n.so reconstruction_amd/librsm_mi355.so
+  [ -f tests/_ab/$n.so ] && cp tests/_ab/$n.so reconstruction_amd/librsm_mi355.so || cp /tmp/keep.so reconstruction_amd/librsm_mi355.so   # (a name without a file: the tree's library)
   out=/tmp/trace_r06; rm -rf $out; mkdir -p $out
   cd /tmp
   rocprofv3 --kernel-trace -d $out -o tr -- python $root/bench.py --pmc-child --inflight 1 --no-cpu-baseline --opt refine_split=0 $EXTRA > $out/log 2>&1
